@@ -1,0 +1,261 @@
+/*
+ * mi355r -- C ABI of the MI355X (gfx950) triangle pipeline.
+ *
+ * The library is a drop-in for the two translation units of the reference
+ * software renderer that make up its hot path,
+ *     renderer/core/graphics.c   (framebuffer, program, graphics_draw_triangle)
+ *     renderer/core/texture.c    (texture / cubemap objects, samplers, depth->texture)
+ * and exports their public functions under their original names with
+ * identical signatures and struct layouts (x86-64 SysV), so the reference's
+ * scene files, shader "high-level api" and frame driver link against it
+ * unchanged.  Every declaration below cites the reference interface it
+ * replaces.  All work runs on the GPU through hand-written HIP kernels; there
+ * is no CPU rendering path in this library.
+ *
+ * Plain C: pointers and sizes only.
+ */
+#ifndef MI355R_H
+#define MI355R_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- value types: layout-identical to renderer/core/maths.h:4-9 ---------- */
+typedef struct { float x, y; } rz_vec2;
+typedef struct { float x, y, z; } rz_vec3;
+typedef struct { float x, y, z, w; } rz_vec4;
+typedef struct { float m[3][3]; } rz_mat3;     /* row-major, column vectors */
+typedef struct { float m[4][4]; } rz_mat4;
+
+/* ---- public objects ------------------------------------------------------ */
+
+/* renderer/core/graphics.h:6-10.  Row 0 is the BOTTOM row of the image.
+ * color_buffer (RGBA8) and depth_buffer (f32) are host mirrors of the device
+ * buffers: they are only valid after framebuffer_sync(). */
+typedef struct {
+    int width, height;
+    unsigned char *color_buffer;
+    float *depth_buffer;
+} rz_framebuffer;
+
+/* renderer/core/texture.h:14-17.  buffer is the host image (float RGBA,
+ * row 0 = bottom); the device copy is (re)uploaded lazily, see
+ * texture_invalidate(). */
+typedef struct {
+    int width, height;
+    rz_vec4 *buffer;
+} rz_texture;
+
+/* renderer/core/texture.h:19-21; faces in the order +x -x +y -y +z -z */
+typedef struct {
+    rz_texture *faces[6];
+} rz_cubemap;
+
+/* renderer/core/texture.h:7-12 */
+typedef enum {
+    RZ_USAGE_LDR_COLOR,
+    RZ_USAGE_LDR_DATA,
+    RZ_USAGE_HDR_COLOR,
+    RZ_USAGE_HDR_DATA
+} rz_usage;
+
+/* renderer/core/mesh.h:8-15: the de-indexed vertex stream a mesh holds,
+ * 3 consecutive entries per face, 80 bytes each */
+typedef struct {
+    rz_vec3 position;
+    rz_vec2 texcoord;
+    rz_vec3 normal;
+    rz_vec4 tangent;
+    rz_vec4 joint;
+    rz_vec4 weight;
+} rz_vertex;
+
+/* renderer/core/graphics.h:12-15 */
+typedef struct rz_program rz_program;
+typedef rz_vec4 rz_vertex_shader(void *attribs, void *varyings, void *uniforms);
+typedef rz_vec4 rz_fragment_shader(void *varyings, void *uniforms,
+                                   int *discard, int backface);
+
+/* ---- shader families ------------------------------------------------------
+ * The device pipeline implements the reference's three shader pairs natively.
+ * program_create() recognises them by function-pointer identity (the symbols
+ * blinn_/pbr_/skybox_{vertex,fragment}_shader of the running program, or
+ * pointers registered with program_register_family) and, failing that, by the
+ * attribs/varyings/uniforms sizes.  An unknown pair aborts: there is no CPU
+ * fallback. */
+typedef enum {
+    RZ_FAMILY_BLINN = 0,    /* renderer/shaders/blinn_shader.h:8-44  */
+    RZ_FAMILY_PBR = 1,      /* renderer/shaders/pbr_shader.h:20-76   */
+    RZ_FAMILY_SKYBOX = 2    /* renderer/shaders/skybox_shader.h:8-19 */
+} rz_family;
+
+/* uniform blocks: layout-identical to the reference structs cited above */
+typedef struct rz_ibldata {                 /* pbr_shader.h:13-18 */
+    int mip_levels;
+    rz_cubemap *diffuse_map;
+    rz_cubemap *specular_maps[15];
+    rz_texture *brdf_lut;
+} rz_ibldata;
+
+typedef struct {                            /* blinn_shader.h:23-44, 344 bytes */
+    rz_vec3 light_dir;
+    rz_vec3 camera_pos;
+    rz_mat4 model_matrix;
+    rz_mat3 normal_matrix;
+    rz_mat4 light_vp_matrix;
+    rz_mat4 camera_vp_matrix;
+    rz_mat4 *joint_matrices;
+    rz_mat3 *joint_n_matrices;
+    float ambient_intensity;
+    float punctual_intensity;
+    rz_texture *shadow_map;
+    rz_vec4 basecolor;
+    float shininess;
+    rz_texture *diffuse_map;
+    rz_texture *specular_map;
+    rz_texture *emission_map;
+    float alpha_cutoff;
+    int shadow_pass;
+} rz_blinn_uniforms;
+
+typedef struct {                            /* pbr_shader.h:39-76, 440 bytes */
+    rz_vec3 light_dir;
+    rz_vec3 camera_pos;
+    rz_mat4 model_matrix;
+    rz_mat3 normal_matrix;
+    rz_mat4 light_vp_matrix;
+    rz_mat4 camera_vp_matrix;
+    rz_mat4 *joint_matrices;
+    rz_mat3 *joint_n_matrices;
+    float ambient_intensity;
+    float punctual_intensity;
+    rz_texture *shadow_map;
+    rz_vec4 basecolor_factor;
+    float metalness_factor;
+    float roughness_factor;
+    rz_texture *basecolor_map;
+    rz_texture *metalness_map;
+    rz_texture *roughness_map;
+    rz_vec4 diffuse_factor;
+    rz_vec3 specular_factor;
+    float glossiness_factor;
+    rz_texture *diffuse_map;
+    rz_texture *specular_map;
+    rz_texture *glossiness_map;
+    rz_texture *normal_map;
+    rz_texture *occlusion_map;
+    rz_texture *emission_map;
+    rz_ibldata *ibldata;
+    int workflow;                           /* 0 metalness, 1 specular */
+    float alpha_cutoff;
+    int shadow_pass;
+    int layer_view;
+} rz_pbr_uniforms;
+
+typedef struct {                            /* skybox_shader.h:16-19, 72 bytes */
+    rz_mat4 vp_matrix;
+    rz_cubemap *skybox;
+} rz_skybox_uniforms;
+
+/* attribute blocks (what program_get_attribs hands out) */
+typedef struct {                            /* blinn_shader.h:8-14, 64 bytes */
+    rz_vec3 position; rz_vec2 texcoord; rz_vec3 normal;
+    rz_vec4 joint; rz_vec4 weight;
+} rz_blinn_attribs;
+typedef rz_vertex rz_pbr_attribs;           /* pbr_shader.h:20-27, 80 bytes */
+typedef struct { rz_vec3 position; } rz_skybox_attribs;  /* skybox_shader.h:8-10 */
+
+/* ---- framebuffer management: renderer/core/graphics.h:17-21 -------------- */
+rz_framebuffer *framebuffer_create(int width, int height);          /* graphics.c:11 */
+void framebuffer_release(rz_framebuffer *framebuffer);              /* graphics.c:32 */
+void framebuffer_clear_color(rz_framebuffer *framebuffer, rz_vec4 color);   /* graphics.c:38 */
+void framebuffer_clear_depth(rz_framebuffer *framebuffer, float depth);     /* graphics.c:49 */
+
+/* ---- program management: renderer/core/graphics.h:23-30 ------------------ */
+rz_program *program_create(rz_vertex_shader *vertex_shader,
+                           rz_fragment_shader *fragment_shader,
+                           int sizeof_attribs, int sizeof_varyings,
+                           int sizeof_uniforms,
+                           int double_sided, int enable_blend);     /* graphics.c:82 */
+void program_release(rz_program *program);                          /* graphics.c:120 */
+void *program_get_attribs(rz_program *program, int nth_vertex);     /* graphics.c:134 */
+void *program_get_uniforms(rz_program *program);                    /* graphics.c:139 */
+
+/* ---- the pipeline: renderer/core/graphics.h:33 --------------------------- */
+/* graphics.c:537.  Records one triangle from the three attribute blocks; the
+ * triangle is rendered, in submission order, at the next flush point. */
+void graphics_draw_triangle(rz_framebuffer *framebuffer, rz_program *program);
+
+/* ---- textures: renderer/core/texture.h:23-41 ----------------------------- */
+rz_texture *texture_create(int width, int height);                  /* texture.c:12 */
+void texture_release(rz_texture *texture);                          /* texture.c:27 */
+rz_texture *texture_from_file(const char *filename, rz_usage usage);        /* texture.c:108 */
+void texture_from_colorbuffer(rz_texture *texture, rz_framebuffer *framebuffer);  /* texture.c:130 */
+void texture_from_depthbuffer(rz_texture *texture, rz_framebuffer *framebuffer);  /* texture.c:147 */
+rz_vec4 texture_repeat_sample(rz_texture *texture, rz_vec2 texcoord);       /* texture.c:160 */
+rz_vec4 texture_clamp_sample(rz_texture *texture, rz_vec2 texcoord);        /* texture.c:169 */
+rz_vec4 texture_sample(rz_texture *texture, rz_vec2 texcoord);              /* texture.c:178 */
+rz_cubemap *cubemap_from_files(const char *positive_x, const char *negative_x,
+                               const char *positive_y, const char *negative_y,
+                               const char *positive_z, const char *negative_z,
+                               rz_usage usage);                     /* texture.c:184 */
+void cubemap_release(rz_cubemap *cubemap);                          /* texture.c:198 */
+rz_vec4 cubemap_repeat_sample(rz_cubemap *cubemap, rz_vec3 direction);      /* texture.c:257 */
+rz_vec4 cubemap_clamp_sample(rz_cubemap *cubemap, rz_vec3 direction);       /* texture.c:264 */
+rz_vec4 cubemap_sample(rz_cubemap *cubemap, rz_vec3 direction);             /* texture.c:271 */
+
+/* ---- additions (no counterpart in the reference) -------------------------
+ * The reference is immediate-mode and synchronous; a GPU back end records
+ * draws and needs explicit points at which host-visible memory is valid. */
+
+/* Batched form of the per-face loop in the shaders' draw_model
+ * (blinn_shader.c:323-341, pbr_shader.c:561-577, skybox_shader.c:57-64):
+ * draws num_faces triangles from a de-indexed vertex stream with the
+ * program's current uniforms.  The stream is uploaded once and cached by
+ * address; call mesh_invalidate() if its contents change. */
+void graphics_draw_mesh(rz_framebuffer *framebuffer, rz_program *program,
+                        const rz_vertex *vertices, int num_faces);
+void mesh_invalidate(const rz_vertex *vertices);
+
+/* Executes everything recorded so far (asynchronously, in order). */
+void graphics_flush(void);
+/* Flushes, waits, and makes color_buffer/depth_buffer of this framebuffer
+ * valid on the host.  Any code that reads or writes those arrays directly
+ * (blit, 2D overlay, dumps) calls this first. */
+void framebuffer_sync(rz_framebuffer *framebuffer);
+/* Same for a texture written by texture_from_{color,depth}buffer. */
+void texture_sync(rz_texture *texture);
+/* Tells the library that texture->buffer was modified by the host. */
+void texture_invalidate(rz_texture *texture);
+/* Copies the finished device images into caller memory (host pointers) or
+ * into device memory (device pointers, e.g. a torch tensor), without touching
+ * the framebuffer's own host mirrors.  Either pointer may be NULL. */
+void framebuffer_read(rz_framebuffer *framebuffer, void *color_rgba8, void *depth_f32);
+void framebuffer_read_device(rz_framebuffer *framebuffer, void *color_rgba8_dev,
+                             void *depth_f32_dev);
+
+/* Explicit family registration for hosts whose shader functions are not
+ * visible as dynamic symbols. */
+void program_register_family(rz_vertex_shader *vs, rz_fragment_shader *fs,
+                             rz_family family);
+
+/* Library control / introspection.  mi355r_init selects the device
+ * (-1 = current) and creates the stream; it is called implicitly by the
+ * first object creation.  mi355r_backend returns "hip:gfx950". */
+int mi355r_init(int device);
+void mi355r_shutdown(void);
+const char *mi355r_backend(void);
+void *mi355r_stream(void);              /* hipStream_t of the pipeline */
+
+/* Counters of the last flush-to-flush interval (for measurement):
+ * index 0 triangles submitted, 1 triangles after clip/cull (raster prims),
+ * 2 fragments shaded, 3 tile-bin entries, 4 passes, 5 draws. */
+void mi355r_get_counters(unsigned long long out[8]);
+void mi355r_reset_counters(void);
+void mi355r_enable_counters(int on);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI355R_H */

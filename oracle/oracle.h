@@ -1,0 +1,44 @@
+/*
+ * TEST INFRASTRUCTURE -- declarations private to the CPU oracle build.
+ * Nothing under renderer_amd/ includes this file.
+ */
+#ifndef ORACLE_H
+#define ORACLE_H
+
+#include "../include/mi355r.h"
+
+/* the three shader pairs (oracle/shaders.c) */
+rz_vec4 blinn_vertex_shader(void *attribs, void *varyings, void *uniforms);
+rz_vec4 blinn_fragment_shader(void *varyings, void *uniforms, int *discard, int backface);
+rz_vec4 pbr_vertex_shader(void *attribs, void *varyings, void *uniforms);
+rz_vec4 pbr_fragment_shader(void *varyings, void *uniforms, int *discard, int backface);
+rz_vec4 skybox_vertex_shader(void *attribs, void *varyings, void *uniforms);
+rz_vec4 skybox_fragment_shader(void *varyings, void *uniforms, int *discard, int backface);
+
+/* varying blocks (blinn_shader.h:16-21, pbr_shader.h:29-37, skybox_shader.h:12-14) */
+typedef struct {
+    rz_vec3 world_position, depth_position;
+    rz_vec2 texcoord;
+    rz_vec3 normal;
+} o_blinn_varyings;
+
+typedef struct {
+    rz_vec3 world_position, depth_position;
+    rz_vec4 clip_position;
+    rz_vec3 world_normal, world_tangent, world_bitangent;
+    rz_vec2 texcoord;
+} o_pbr_varyings;
+
+typedef struct { rz_vec3 direction; } o_skybox_varyings;
+
+/* workload counters, accumulated over every draw since the last reset:
+ * triangles submitted, triangles rasterised after clip/cull, bounding-box
+ * pixel tests, covered pixels, fragments shaded (graphics.c:437 calls) */
+typedef struct {
+    unsigned long long triangles, prims, tests, covered, shaded;
+} oracle_stats;
+
+void oracle_get_stats(oracle_stats *out);
+void oracle_reset_stats(void);
+
+#endif

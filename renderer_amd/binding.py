@@ -1,0 +1,147 @@
+"""ctypes binding of the C ABI in include/mi355r.h plus the scene layer
+(renderer_amd/host/scene.h).  The same binding drives the GPU library
+(renderer_amd/libmi355r.so) and, in tests only, the CPU oracle
+(oracle/liboracle.so): both export identical symbols."""
+import ctypes as C
+import os
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GPU_LIB = os.path.join(REPO, "renderer_amd", "libmi355r.so")
+ASSETS = os.path.join(REPO, "assets")
+SCENES = os.path.join(REPO, "scenes")
+
+
+class Vec4(C.Structure):
+    _fields_ = [("x", C.c_float), ("y", C.c_float), ("z", C.c_float), ("w", C.c_float)]
+
+
+class Framebuffer(C.Structure):
+    _fields_ = [("width", C.c_int), ("height", C.c_int),
+                ("color_buffer", C.POINTER(C.c_ubyte)), ("depth_buffer", C.POINTER(C.c_float))]
+
+
+class Vertex(C.Structure):
+    _fields_ = [("position", C.c_float * 3), ("texcoord", C.c_float * 2), ("normal", C.c_float * 3),
+                ("tangent", C.c_float * 4), ("joint", C.c_float * 4), ("weight", C.c_float * 4)]
+
+
+class View(C.Structure):
+    _fields_ = [("eye", C.c_float * 3), ("target", C.c_float * 3), ("light_dir", C.c_float * 3),
+                ("frame_time", C.c_float), ("layer_view", C.c_int)]
+
+
+class Pipeline:
+    """One loaded library (GPU or oracle)."""
+
+    def __init__(self, path=GPU_LIB, assets=ASSETS):
+        if not os.path.exists(path):
+            raise RuntimeError(
+                f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'`; "
+                "there is no fallback path")
+        self.path = path
+        self.lib = lib = C.CDLL(path)
+        P = C.c_void_p
+        FB = C.POINTER(Framebuffer)
+        lib.framebuffer_create.restype = FB
+        lib.framebuffer_create.argtypes = [C.c_int, C.c_int]
+        lib.framebuffer_release.argtypes = [FB]
+        lib.framebuffer_clear_color.argtypes = [FB, Vec4]
+        lib.framebuffer_clear_depth.argtypes = [FB, C.c_float]
+        lib.framebuffer_sync.argtypes = [FB]
+        lib.framebuffer_read.argtypes = [FB, P, P]
+        lib.graphics_flush.argtypes = []
+        lib.mi355r_backend.restype = C.c_char_p
+        lib.rzs_set_assets_dir.argtypes = [C.c_char_p]
+        lib.rzs_scene_open.restype = P
+        lib.rzs_scene_open.argtypes = [C.c_char_p, C.c_char_p]
+        lib.rzs_scene_close.argtypes = [P]
+        lib.rzs_default_view.argtypes = [C.POINTER(View)]
+        lib.rzs_orbit_view.argtypes = [C.POINTER(View), C.c_int, C.c_int]
+        lib.rzs_scene_draw.argtypes = [P, FB, C.POINTER(View)]
+        lib.rzs_scene_info.argtypes = [P, C.POINTER(C.c_int)]
+        lib.rzs_scene_shadow_buffer.restype = FB
+        lib.rzs_scene_shadow_buffer.argtypes = [P]
+        lib.rzs_catalogue.restype = C.c_char_p
+        lib.rzs_catalogue.argtypes = [C.c_int]
+        self.backend = lib.mi355r_backend().decode()
+        self.is_gpu = self.backend.startswith("hip")
+        if self.is_gpu:
+            lib.mi355r_init.argtypes = [C.c_int]
+            lib.mi355r_init.restype = C.c_int
+            lib.framebuffer_read_device.argtypes = [FB, P, P]
+            lib.mi355r_get_counters.argtypes = [C.POINTER(C.c_ulonglong)]
+            lib.mi355r_enable_counters.argtypes = [C.c_int]
+            lib.mi355r_stream.restype = P
+        else:
+            lib.oracle_get_stats.argtypes = [C.POINTER(C.c_ulonglong)]
+        lib.rzs_set_assets_dir(assets.encode())
+
+    # -- scenes -----------------------------------------------------------
+    def open_scene(self, name, like=None):
+        h = self.lib.rzs_scene_open(name.encode(), like.encode() if like else None)
+        if not h:
+            raise KeyError(name)
+        return h
+
+    def close_scene(self, scene):
+        self.lib.rzs_scene_close(scene)
+
+    def scene_info(self, scene):
+        out = (C.c_int * 8)()
+        self.lib.rzs_scene_info(scene, out)
+        keys = ["models", "faces", "skybox", "shadow_w", "shadow_h", "blended", "skinned", "attached"]
+        return dict(zip(keys, list(out)))
+
+    def default_view(self):
+        v = View()
+        self.lib.rzs_default_view(C.byref(v))
+        return v
+
+    def orbit_view(self, index, count):
+        v = View()
+        self.lib.rzs_orbit_view(C.byref(v), index, count)
+        return v
+
+    def make_view(self, eye=None, target=None, time=0.0, layer=-1):
+        v = self.default_view()
+        if eye is not None:
+            v.eye[:] = eye
+        if target is not None:
+            v.target[:] = target
+        v.frame_time = time
+        v.layer_view = layer
+        return v
+
+    def draw(self, scene, fb, view):
+        self.lib.rzs_scene_draw(scene, fb, C.byref(view))
+
+    # -- framebuffers -------------------------------------------------------
+    def framebuffer(self, width, height):
+        return self.lib.framebuffer_create(width, height)
+
+    def release(self, fb):
+        self.lib.framebuffer_release(fb)
+
+    def read(self, fb):
+        w, h = fb.contents.width, fb.contents.height
+        color = np.empty((h, w, 4), np.uint8)
+        depth = np.empty((h, w), np.float32)
+        self.lib.framebuffer_read(fb, color.ctypes.data_as(C.c_void_p), depth.ctypes.data_as(C.c_void_p))
+        return color, depth
+
+    def render(self, scene, width, height, view=None):
+        fb = self.framebuffer(width, height)
+        self.draw(scene, fb, view if view is not None else self.default_view())
+        out = self.read(fb)
+        self.release(fb)
+        return out
+
+    def counters(self):
+        out = (C.c_ulonglong * 8)()
+        if self.is_gpu:
+            self.lib.mi355r_get_counters(out)
+        else:
+            self.lib.oracle_get_stats(out)
+        return list(out)
