@@ -1,0 +1,933 @@
+/*
+ * Host side of the MI355X triangle pipeline: the C ABI of include/mi355r.h.
+ *
+ * The reference API is immediate-mode and synchronous (graphics.c); here draw
+ * calls are RECORDED -- the program's uniform block is snapshotted and its
+ * host pointers (textures, joint matrices, IBL data) are translated to device
+ * handles -- and executed in submission order at flush points:
+ *   framebuffer_sync / framebuffer_read*, texture_from_{depth,color}buffer,
+ *   a clear of a framebuffer that has draws pending, graphics_flush, releases.
+ * A flush turns every maximal run of draws into one framebuffer into a "pass"
+ * and launches vertex -> setup -> bin -> raster for it on the library's HIP
+ * stream; nothing waits for the GPU except the calls that hand pixels back to
+ * the host.  There is no CPU rendering path: without a GPU the first call
+ * aborts with the HIP error.
+ */
+#include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <algorithm>
+#include <unordered_map>
+#include <unordered_set>
+#include <vector>
+
+#include "../../include/mi355r.h"
+#include "kernels.h"
+
+static_assert(sizeof(rz_vertex) == 80, "vertex stream layout (mesh.h:8-15)");
+static_assert(sizeof(rz_blinn_uniforms) == 344, "blinn uniform block (blinn_shader.h:23-44)");
+static_assert(sizeof(rz_pbr_uniforms) == 440, "pbr uniform block (pbr_shader.h:39-76)");
+static_assert(sizeof(rz_skybox_uniforms) == 72, "skybox uniform block (skybox_shader.h:16-19)");
+static_assert(sizeof(rz_blinn_attribs) == 64, "blinn attribs");
+static_assert(sizeof(TriRec) == 64, "TriRec is four float4");
+static_assert(sizeof(DevTex) == 24, "DevTex");
+
+[[noreturn]] static void fatal(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    fprintf(stderr, "mi355r: fatal: ");
+    vfprintf(stderr, fmt, ap);
+    fprintf(stderr, "\n");
+    va_end(ap);
+    abort();
+}
+
+#define HIP_OK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) \
+    fatal("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
+
+/* ---------------------------------------------------------------- objects -- */
+
+struct Fb {
+    rz_framebuffer pub;             /* must stay first: handed out as rz_framebuffer* */
+    uint32_t *d_color;
+    float *d_depth;
+    bool clear_color_pending, clear_depth_pending;
+    uint32_t clear_color;
+    float clear_depth;
+};
+
+struct Tex {
+    rz_texture pub;                 /* must stay first */
+    void *d_data;
+    size_t d_bytes;
+    int flags, mbits;               /* RZ_TEX_* of the device image */
+    bool device_stale;              /* host buffer is newer */
+    bool host_stale;                /* device image is newer */
+};
+
+struct rz_program {
+    int family;
+    int attrib_bytes, varying_bytes, uniform_bytes;
+    int double_sided, blend;
+    void *attribs[3];
+    void *uniforms;
+};
+
+struct Mesh {
+    void *d_vertices;
+    int num_faces;
+    int num_joints;                 /* 1 + largest joint index referenced */
+};
+
+struct Pending {
+    Fb *fb;
+    rz_program *program;
+    DrawRec rec;                    /* joints / vertices patched at flush */
+    int num_joints;
+    size_t joints_at, joint_normals_at;     /* offsets into Context::side */
+    bool transient;                 /* vertices recorded by graphics_draw_triangle */
+    std::vector<rz_vertex> verts;
+    std::vector<char> uniform_bytes;        /* for merging per-triangle calls */
+};
+
+template <typename T> struct DevBuf {
+    T *ptr = nullptr;
+    size_t cap = 0;
+};
+
+struct Context {
+    bool ready = false;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    /* per-pass scratch, grow-only; passes are serialised on the stream */
+    DevBuf<float> clip, vary, fan_vary;
+    DevBuf<TriRec> tri, fan_tri;
+    DevBuf<uint2> bbox;
+    DevBuf<uint32_t> bin_start, bin_count, bin_list;
+    /* upload ring: pinned host memory mirrored 1:1 in device memory */
+    char *ring_host = nullptr, *ring_dev = nullptr;
+    size_t ring_size = 0, ring_at = 0;
+    std::vector<size_t> control_slots;      /* ring offsets of passes in flight */
+    /* recording */
+    std::vector<Pending> pending;
+    std::vector<char> side;                 /* joint matrices snapshotted at record time */
+    /* resources */
+    std::unordered_set<Fb*> fbs;
+    std::unordered_set<Tex*> texs;
+    std::unordered_map<const void*, Mesh> meshes;
+    std::unordered_map<const void*, DevTex*> cubes;     /* rz_cubemap* -> DevTex[6] */
+    std::unordered_map<const void*, DevIbl*> ibls;      /* rz_ibldata* -> DevIbl */
+    struct Registered { void *vs, *fs; int family; };
+    std::vector<Registered> families;
+    /* measurement */
+    bool counting = false;
+    unsigned long long *d_counters = nullptr;
+    unsigned long long host_counters[8] = {0};
+};
+
+static Context g;
+
+static const size_t RING_BYTES = 64u << 20;
+
+static void ensure_ready() {
+    if (!g.ready) mi355r_init(-1);
+}
+
+template <typename T> static void reserve(DevBuf<T> &b, size_t n) {
+    if (n <= b.cap) return;
+    if (b.ptr) { HIP_OK(hipStreamSynchronize(g.stream)); HIP_OK(hipFree(b.ptr)); }
+    size_t cap = std::max(n, b.cap + b.cap / 2);
+    HIP_OK(hipMalloc((void**)&b.ptr, cap * sizeof(T)));
+    b.cap = cap;
+}
+
+static void check_passes_in_flight();
+
+static void sync_stream() {
+    HIP_OK(hipStreamSynchronize(g.stream));
+    check_passes_in_flight();
+}
+
+extern "C" int mi355r_init(int device) {
+    if (g.ready) return g.device;
+    if (device >= 0) HIP_OK(hipSetDevice(device));
+    HIP_OK(hipGetDevice(&g.device));
+    hipDeviceProp_t prop;
+    HIP_OK(hipGetDeviceProperties(&prop, g.device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        fprintf(stderr, "mi355r: warning: built for gfx950, running on %s\n", prop.gcnArchName);
+    HIP_OK(hipStreamCreate(&g.stream));
+    HIP_OK(hipHostMalloc((void**)&g.ring_host, RING_BYTES, hipHostMallocDefault));
+    HIP_OK(hipMalloc((void**)&g.ring_dev, RING_BYTES));
+    g.ring_size = RING_BYTES;
+    HIP_OK(hipMalloc((void**)&g.d_counters, 8 * sizeof(unsigned long long)));
+    HIP_OK(hipMemset(g.d_counters, 0, 8 * sizeof(unsigned long long)));
+    g.ready = true;
+    return g.device;
+}
+
+extern "C" const char *mi355r_backend(void) { return "hip:gfx950"; }
+extern "C" void *mi355r_stream(void) { ensure_ready(); return (void*)g.stream; }
+
+/* ------------------------------------------------------------ framebuffers -- */
+
+static Fb *as_fb(rz_framebuffer *p) {
+    Fb *fb = (Fb*)p;
+    if (!p || !g.fbs.count(fb)) fatal("framebuffer %p was not created by this library", (void*)p);
+    return fb;
+}
+
+static uint32_t pack_clear(rz_vec4 c) {                 /* float_to_uchar per channel, graphics.c:42-45 */
+    auto u8 = [](float v) { return (uint32_t)(unsigned char)(v * 255); };
+    return u8(c.x) | (u8(c.y) << 8) | (u8(c.z) << 16) | (u8(c.w) << 24);
+}
+
+static bool has_pending_for(Fb *fb) {
+    for (auto &p : g.pending) if (p.fb == fb) return true;
+    return false;
+}
+
+extern "C" rz_framebuffer *framebuffer_create(int width, int height) {
+    ensure_ready();
+    if (width <= 0 || height <= 0 || width > 65535 || height > 65535) fatal("framebuffer size %dx%d", width, height);
+    Fb *fb = new Fb();
+    size_t n = (size_t)width * height;
+    fb->pub.width = width;
+    fb->pub.height = height;
+    fb->pub.color_buffer = (unsigned char*)malloc(n * 4);
+    fb->pub.depth_buffer = (float*)malloc(n * sizeof(float));
+    HIP_OK(hipMalloc((void**)&fb->d_color, n * 4));
+    HIP_OK(hipMalloc((void**)&fb->d_depth, n * sizeof(float)));
+    g.fbs.insert(fb);
+    rz_vec4 black = {0, 0, 0, 1};
+    framebuffer_clear_color(&fb->pub, black);           /* graphics.c:26-27 */
+    framebuffer_clear_depth(&fb->pub, 1);
+    return &fb->pub;
+}
+
+extern "C" void framebuffer_release(rz_framebuffer *p) {
+    Fb *fb = as_fb(p);
+    graphics_flush();
+    sync_stream();
+    HIP_OK(hipFree(fb->d_color));
+    HIP_OK(hipFree(fb->d_depth));
+    free(fb->pub.color_buffer);
+    free(fb->pub.depth_buffer);
+    g.fbs.erase(fb);
+    delete fb;
+}
+
+extern "C" void framebuffer_clear_color(rz_framebuffer *p, rz_vec4 color) {
+    Fb *fb = as_fb(p);
+    if (has_pending_for(fb)) graphics_flush();
+    fb->clear_color_pending = true;
+    fb->clear_color = pack_clear(color);
+}
+
+extern "C" void framebuffer_clear_depth(rz_framebuffer *p, float depth) {
+    Fb *fb = as_fb(p);
+    if (has_pending_for(fb)) graphics_flush();
+    fb->clear_depth_pending = true;
+    fb->clear_depth = depth;
+}
+
+/* a clear that no pass consumed has to be executed on its own */
+static void apply_pending_clear(Fb *fb) {
+    if (!fb->clear_color_pending && !fb->clear_depth_pending) return;
+    size_t n = (size_t)fb->pub.width * fb->pub.height;
+    rz_clear_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, g.stream>>>(
+        fb->d_color, fb->d_depth, n, fb->clear_color_pending, fb->clear_color,
+        fb->clear_depth_pending, fb->clear_depth);
+    HIP_OK(hipGetLastError());
+    fb->clear_color_pending = fb->clear_depth_pending = false;
+}
+
+extern "C" void framebuffer_sync(rz_framebuffer *p) {
+    Fb *fb = as_fb(p);
+    framebuffer_read(p, fb->pub.color_buffer, fb->pub.depth_buffer);
+}
+
+extern "C" void framebuffer_read(rz_framebuffer *p, void *color, void *depth) {
+    Fb *fb = as_fb(p);
+    graphics_flush();
+    apply_pending_clear(fb);
+    size_t n = (size_t)fb->pub.width * fb->pub.height;
+    if (color) HIP_OK(hipMemcpyAsync(color, fb->d_color, n * 4, hipMemcpyDeviceToHost, g.stream));
+    if (depth) HIP_OK(hipMemcpyAsync(depth, fb->d_depth, n * sizeof(float), hipMemcpyDeviceToHost, g.stream));
+    sync_stream();
+}
+
+extern "C" void framebuffer_read_device(rz_framebuffer *p, void *color, void *depth) {
+    Fb *fb = as_fb(p);
+    graphics_flush();
+    apply_pending_clear(fb);
+    size_t n = (size_t)fb->pub.width * fb->pub.height;
+    if (color) HIP_OK(hipMemcpyAsync(color, fb->d_color, n * 4, hipMemcpyDeviceToDevice, g.stream));
+    if (depth) HIP_OK(hipMemcpyAsync(depth, fb->d_depth, n * sizeof(float), hipMemcpyDeviceToDevice, g.stream));
+    sync_stream();
+}
+
+/* ---------------------------------------------------------------- textures -- */
+
+static Tex *as_tex(rz_texture *p) {
+    Tex *t = (Tex*)p;
+    if (!p || !g.texs.count(t)) fatal("texture %p was not created by this library", (void*)p);
+    return t;
+}
+
+static int log2_exact(int v) {
+    int b = 0;
+    if (v <= 0 || (v & (v - 1))) return -1;
+    while ((1 << b) < v) b++;
+    return b;
+}
+
+static void choose_layout(int w, int h, int *flags, int *mbits) {
+    int lw = log2_exact(w), lh = log2_exact(h);
+    if (lw >= 0 && lh >= 0) { *flags |= RZ_TEX_MORTON; *mbits = std::min(lw, lh); }
+    else { *flags &= ~RZ_TEX_MORTON; *mbits = 0; }
+}
+
+static void drop_derived_handles();
+
+extern "C" rz_texture *texture_create(int width, int height) {      /* texture.c:12 */
+    ensure_ready();
+    if (width <= 0 || height <= 0) fatal("texture size %dx%d", width, height);
+    Tex *t = new Tex();
+    t->pub.width = width;
+    t->pub.height = height;
+    t->pub.buffer = (rz_vec4*)calloc((size_t)width * height, sizeof(rz_vec4));
+    t->d_data = nullptr;
+    t->d_bytes = 0;
+    t->flags = 0;
+    t->mbits = 0;
+    t->device_stale = true;
+    t->host_stale = false;
+    g.texs.insert(t);
+    return &t->pub;
+}
+
+extern "C" void texture_release(rz_texture *p) {                    /* texture.c:27 */
+    Tex *t = as_tex(p);
+    graphics_flush();
+    sync_stream();
+    drop_derived_handles();
+    if (t->d_data) HIP_OK(hipFree(t->d_data));
+    free(t->pub.buffer);
+    g.texs.erase(t);
+    delete t;
+}
+
+extern "C" void texture_invalidate(rz_texture *p) {
+    Tex *t = as_tex(p);
+    t->device_stale = true;
+    t->host_stale = false;
+}
+
+static void device_image(Tex *t, int flags_wanted, size_t texel_bytes) {
+    size_t bytes = (size_t)t->pub.width * t->pub.height * texel_bytes;
+    int flags = flags_wanted, mbits = 0;
+    choose_layout(t->pub.width, t->pub.height, &flags, &mbits);
+    if (t->d_bytes != bytes) {
+        /* the device address changes: cube / IBL handle tables that embed it are rebuilt */
+        if (t->d_data) { graphics_flush(); sync_stream(); drop_derived_handles(); HIP_OK(hipFree(t->d_data)); }
+        HIP_OK(hipMalloc(&t->d_data, bytes));
+        t->d_bytes = bytes;
+    }
+    t->flags = flags;
+    t->mbits = mbits;
+}
+
+/* host float4 image -> device (Morton where possible); load-time path */
+static void upload_texture(Tex *t) {
+    int w = t->pub.width, h = t->pub.height;
+    size_t bytes = (size_t)w * h * sizeof(float4);
+    graphics_flush();               /* recorded draws may still sample the old image */
+    device_image(t, 0, sizeof(float4));
+    float4 *staging;
+    HIP_OK(hipMalloc((void**)&staging, bytes));
+    HIP_OK(hipMemcpyAsync(staging, t->pub.buffer, bytes, hipMemcpyHostToDevice, g.stream));
+    rz_texture_tile_kernel<<<dim3((w + 15) / 16, (h + 15) / 16), dim3(256), 0, g.stream>>>(
+        staging, (float4*)t->d_data, w, h, t->flags, t->mbits);
+    HIP_OK(hipGetLastError());
+    HIP_OK(hipStreamSynchronize(g.stream));
+    HIP_OK(hipFree(staging));
+    t->device_stale = false;
+    t->host_stale = false;
+}
+
+static DevTex dev_tex(rz_texture *p) {
+    DevTex d;
+    memset(&d, 0, sizeof d);
+    if (!p) return d;
+    Tex *t = as_tex(p);
+    if (t->device_stale) upload_texture(t);
+    d.data = t->d_data;
+    d.w = t->pub.width;
+    d.h = t->pub.height;
+    d.flags = t->flags;
+    d.mbits = t->mbits;
+    return d;
+}
+
+extern "C" void texture_sync(rz_texture *p) {
+    Tex *t = as_tex(p);
+    if (!t->host_stale) return;
+    int w = t->pub.width, h = t->pub.height;
+    size_t bytes = (size_t)w * h * sizeof(float4);
+    graphics_flush();
+    float4 *staging;
+    HIP_OK(hipMalloc((void**)&staging, bytes));
+    rz_texture_untile_kernel<<<dim3((w + 15) / 16, (h + 15) / 16), dim3(256), 0, g.stream>>>(
+        t->d_data, staging, w, h, t->flags, t->mbits);
+    HIP_OK(hipGetLastError());
+    HIP_OK(hipMemcpyAsync(t->pub.buffer, staging, bytes, hipMemcpyDeviceToHost, g.stream));
+    sync_stream();
+    HIP_OK(hipFree(staging));
+    t->host_stale = false;
+}
+
+extern "C" void texture_from_depthbuffer(rz_texture *tp, rz_framebuffer *fp) {   /* texture.c:147 */
+    Tex *t = as_tex(tp);
+    Fb *fb = as_fb(fp);
+    if (t->pub.width != fb->pub.width || t->pub.height != fb->pub.height) fatal("texture_from_depthbuffer: size mismatch");
+    graphics_flush();
+    apply_pending_clear(fb);
+    device_image(t, RZ_TEX_R32F, sizeof(float));
+    int w = t->pub.width, h = t->pub.height;
+    rz_depth_to_texture_kernel<<<dim3((w + 15) / 16, (h + 15) / 16), dim3(256), 0, g.stream>>>(
+        fb->d_depth, (float*)t->d_data, w, h, t->flags, t->mbits);
+    HIP_OK(hipGetLastError());
+    t->device_stale = false;
+    t->host_stale = true;
+}
+
+extern "C" void texture_from_colorbuffer(rz_texture *tp, rz_framebuffer *fp) {   /* texture.c:130 */
+    Tex *t = as_tex(tp);
+    Fb *fb = as_fb(fp);
+    if (t->pub.width != fb->pub.width || t->pub.height != fb->pub.height) fatal("texture_from_colorbuffer: size mismatch");
+    graphics_flush();
+    apply_pending_clear(fb);
+    device_image(t, 0, sizeof(float4));
+    int w = t->pub.width, h = t->pub.height;
+    rz_color_to_texture_kernel<<<dim3((w + 15) / 16, (h + 15) / 16), dim3(256), 0, g.stream>>>(
+        fb->d_color, (float4*)t->d_data, w, h, t->flags, t->mbits);
+    HIP_OK(hipGetLastError());
+    t->device_stale = false;
+    t->host_stale = true;
+}
+
+/* Host-side accessors with the reference's addressing (texture.c:160-273).
+ * They read the host image (synchronising it first if the GPU wrote it); the
+ * pipeline itself samples on the device (shade.h). */
+static rz_vec4 host_texel(rz_texture *p, float u, float v) {
+    texture_sync(p);
+    int c = (int)((p->width - 1) * u), r = (int)((p->height - 1) * v);
+    return p->buffer[r * p->width + c];
+}
+extern "C" rz_vec4 texture_repeat_sample(rz_texture *p, rz_vec2 uv) {
+    return host_texel(p, uv.x - (float)floor(uv.x), uv.y - (float)floor(uv.y));
+}
+extern "C" rz_vec4 texture_clamp_sample(rz_texture *p, rz_vec2 uv) {
+    auto sat = [](float f) { return f < 0 ? 0.0f : (f > 1 ? 1.0f : f); };
+    return host_texel(p, sat(uv.x), sat(uv.y));
+}
+extern "C" rz_vec4 texture_sample(rz_texture *p, rz_vec2 uv) { return texture_repeat_sample(p, uv); }
+
+static int host_cube_face(rz_vec3 d, rz_vec2 *st) {
+    float ax = (float)fabs(d.x), ay = (float)fabs(d.y), az = (float)fabs(d.z), ma, sc, tc;
+    int face;
+    if (ax > ay && ax > az) { ma = ax; if (d.x > 0) { face = 0; sc = -d.z; tc = -d.y; } else { face = 1; sc = d.z; tc = -d.y; } }
+    else if (ay > az) { ma = ay; if (d.y > 0) { face = 2; sc = d.x; tc = d.z; } else { face = 3; sc = d.x; tc = -d.z; } }
+    else { ma = az; if (d.z > 0) { face = 4; sc = d.x; tc = -d.y; } else { face = 5; sc = -d.x; tc = -d.y; } }
+    st->x = (sc / ma + 1) / 2;
+    st->y = 1 - (tc / ma + 1) / 2;
+    return face;
+}
+extern "C" rz_vec4 cubemap_repeat_sample(rz_cubemap *c, rz_vec3 d) { rz_vec2 st; int f = host_cube_face(d, &st); return texture_repeat_sample(c->faces[f], st); }
+extern "C" rz_vec4 cubemap_clamp_sample(rz_cubemap *c, rz_vec3 d) { rz_vec2 st; int f = host_cube_face(d, &st); return texture_clamp_sample(c->faces[f], st); }
+extern "C" rz_vec4 cubemap_sample(rz_cubemap *c, rz_vec3 d) { return cubemap_repeat_sample(c, d); }
+
+/* cube maps and IBL sets are handle tables in device memory, built on first use */
+static const DevTex *dev_cube(rz_cubemap *cube) {
+    if (!cube) return nullptr;
+    auto it = g.cubes.find(cube);
+    if (it != g.cubes.end()) return it->second;
+    DevTex faces[6];
+    for (int i = 0; i < 6; i++) faces[i] = dev_tex(cube->faces[i]);
+    DevTex *d;
+    HIP_OK(hipMalloc((void**)&d, sizeof faces));
+    HIP_OK(hipMemcpy(d, faces, sizeof faces, hipMemcpyHostToDevice));
+    g.cubes[cube] = d;
+    return d;
+}
+
+static const DevIbl *dev_ibl(rz_ibldata *ibl) {
+    if (!ibl) return nullptr;
+    auto it = g.ibls.find(ibl);
+    if (it != g.ibls.end()) return it->second;
+    if (ibl->mip_levels < 1 || ibl->mip_levels > 15) fatal("ibldata with %d levels", ibl->mip_levels);
+    DevIbl *h = (DevIbl*)calloc(1, sizeof(DevIbl));
+    h->mip_levels = ibl->mip_levels;
+    h->lut = dev_tex(ibl->brdf_lut);
+    for (int f = 0; f < 6; f++) h->diffuse[f] = dev_tex(ibl->diffuse_map->faces[f]);
+    for (int l = 0; l < ibl->mip_levels; l++)
+        for (int f = 0; f < 6; f++) h->specular[l][f] = dev_tex(ibl->specular_maps[l]->faces[f]);
+    DevIbl *d;
+    HIP_OK(hipMalloc((void**)&d, sizeof(DevIbl)));
+    HIP_OK(hipMemcpy(d, h, sizeof(DevIbl), hipMemcpyHostToDevice));
+    free(h);
+    g.ibls[ibl] = d;
+    return d;
+}
+
+/* a texture went away or moved: every table that may embed its address is
+ * dropped and rebuilt on next use */
+static void drop_derived_handles() {
+    for (auto &kv : g.cubes) HIP_OK(hipFree(kv.second));
+    for (auto &kv : g.ibls) HIP_OK(hipFree(kv.second));
+    g.cubes.clear();
+    g.ibls.clear();
+}
+
+/* ---------------------------------------------------------------- programs -- */
+
+extern "C" rz_vec4 blinn_vertex_shader(void*, void*, void*);
+extern "C" rz_vec4 blinn_fragment_shader(void*, void*, int*, int);
+extern "C" rz_vec4 pbr_vertex_shader(void*, void*, void*);
+extern "C" rz_vec4 pbr_fragment_shader(void*, void*, int*, int);
+extern "C" rz_vec4 skybox_vertex_shader(void*, void*, void*);
+extern "C" rz_vec4 skybox_fragment_shader(void*, void*, int*, int);
+
+extern "C" void program_register_family(rz_vertex_shader *vs, rz_fragment_shader *fs, rz_family family) {
+    g.families.push_back({(void*)vs, (void*)fs, (int)family});
+}
+
+static int identify_family(void *vs, void *fs, int sa, int sv, int su) {
+    for (auto &r : g.families) if (r.vs == vs && r.fs == fs) return r.family;
+    /* this library's own identity tags (host/tags.c) */
+    if (vs == (void*)blinn_vertex_shader && fs == (void*)blinn_fragment_shader) return RZ_FAMILY_BLINN;
+    if (vs == (void*)pbr_vertex_shader && fs == (void*)pbr_fragment_shader) return RZ_FAMILY_PBR;
+    if (vs == (void*)skybox_vertex_shader && fs == (void*)skybox_fragment_shader) return RZ_FAMILY_SKYBOX;
+    /* the host program's shader functions, when it exports them */
+    static const char *names[3][2] = {{"blinn_vertex_shader", "blinn_fragment_shader"},
+                                      {"pbr_vertex_shader", "pbr_fragment_shader"},
+                                      {"skybox_vertex_shader", "skybox_fragment_shader"}};
+    for (int f = 0; f < 3; f++) {
+        void *v = dlsym(RTLD_DEFAULT, names[f][0]), *p = dlsym(RTLD_DEFAULT, names[f][1]);
+        if (v && p && v == vs && p == fs) return f;
+    }
+    /* struct sizes of the three families (x86-64) */
+    if (sa == 64 && sv == 44 && su == 344) return RZ_FAMILY_BLINN;
+    if (sa == 80 && sv == 84 && su == 440) return RZ_FAMILY_PBR;
+    if (sa == 12 && sv == 12 && su == 72) return RZ_FAMILY_SKYBOX;
+    return -1;
+}
+
+extern "C" rz_program *program_create(rz_vertex_shader *vs, rz_fragment_shader *fs,
+                                      int sizeof_attribs, int sizeof_varyings, int sizeof_uniforms,
+                                      int double_sided, int enable_blend) {            /* graphics.c:82 */
+    ensure_ready();
+    if (sizeof_attribs <= 0 || sizeof_varyings <= 0 || sizeof_uniforms <= 0 || sizeof_varyings % 4)
+        fatal("program_create: bad block sizes %d/%d/%d", sizeof_attribs, sizeof_varyings, sizeof_uniforms);
+    int family = identify_family((void*)vs, (void*)fs, sizeof_attribs, sizeof_varyings, sizeof_uniforms);
+    if (family < 0)
+        fatal("program_create: shader pair %p/%p (blocks %d/%d/%d bytes) is not one of the blinn, pbr or "
+              "skybox families; this library has no CPU shader path (see program_register_family)",
+              (void*)vs, (void*)fs, sizeof_attribs, sizeof_varyings, sizeof_uniforms);
+    static const int expect[3][3] = {{64, 44, 344}, {80, 84, 440}, {12, 12, 72}};
+    if (sizeof_attribs != expect[family][0] || sizeof_varyings != expect[family][1] || sizeof_uniforms != expect[family][2])
+        fatal("program_create: family %d expects blocks of %d/%d/%d bytes, got %d/%d/%d", family, expect[family][0],
+              expect[family][1], expect[family][2], sizeof_attribs, sizeof_varyings, sizeof_uniforms);
+    rz_program *p = new rz_program();
+    p->family = family;
+    p->attrib_bytes = sizeof_attribs;
+    p->varying_bytes = sizeof_varyings;
+    p->uniform_bytes = sizeof_uniforms;
+    p->double_sided = double_sided;
+    p->blend = enable_blend;
+    for (int i = 0; i < 3; i++) p->attribs[i] = calloc(1, sizeof_attribs);
+    p->uniforms = calloc(1, sizeof_uniforms);
+    return p;
+}
+
+extern "C" void program_release(rz_program *p) {                    /* graphics.c:120 */
+    graphics_flush();
+    for (int i = 0; i < 3; i++) free(p->attribs[i]);
+    free(p->uniforms);
+    delete p;
+}
+
+extern "C" void *program_get_attribs(rz_program *p, int nth) {     /* graphics.c:134 */
+    if (nth < 0 || nth > 2) fatal("program_get_attribs: vertex %d", nth);
+    return p->attribs[nth];
+}
+
+extern "C" void *program_get_uniforms(rz_program *p) { return p->uniforms; }   /* graphics.c:139 */
+
+/* ------------------------------------------------------------------ meshes -- */
+
+static Mesh &device_mesh(const rz_vertex *verts, int num_faces) {
+    auto it = g.meshes.find(verts);
+    if (it != g.meshes.end() && it->second.num_faces == num_faces) return it->second;
+    if (it != g.meshes.end()) mesh_invalidate(verts);
+    Mesh m;
+    size_t bytes = (size_t)num_faces * 3 * sizeof(rz_vertex);
+    HIP_OK(hipMalloc(&m.d_vertices, bytes));
+    HIP_OK(hipMemcpy(m.d_vertices, verts, bytes, hipMemcpyHostToDevice));
+    m.num_faces = num_faces;
+    int top = 0;
+    for (int i = 0; i < num_faces * 3; i++) {
+        const rz_vertex &v = verts[i];
+        top = std::max(top, std::max(std::max((int)v.joint.x, (int)v.joint.y), std::max((int)v.joint.z, (int)v.joint.w)));
+    }
+    m.num_joints = top + 1;
+    return g.meshes[verts] = m;
+}
+
+extern "C" void mesh_invalidate(const rz_vertex *verts) {
+    auto it = g.meshes.find(verts);
+    if (it == g.meshes.end()) return;
+    graphics_flush();
+    sync_stream();
+    HIP_OK(hipFree(it->second.d_vertices));
+    g.meshes.erase(it);
+}
+
+/* --------------------------------------------------------------- recording -- */
+
+static void copy_floats(float *dst, const void *src, int n) { memcpy(dst, src, sizeof(float) * n); }
+
+/* uniform block (host layout, host pointers) -> DrawRec (device form) */
+static void snapshot_uniforms(rz_program *p, Pending &pd, int num_joints) {
+    DrawRec &r = pd.rec;
+    memset(&r, 0, sizeof r);
+    r.family = p->family;
+    r.flags = (p->double_sided ? RZ_DRAW_DOUBLE_SIDED : 0) | (p->blend ? RZ_DRAW_BLEND : 0);
+    const rz_mat4 *joints = nullptr;
+    const rz_mat3 *joint_normals = nullptr;
+    if (p->family == RZ_FAMILY_SKYBOX) {
+        const rz_skybox_uniforms *u = (const rz_skybox_uniforms*)p->uniforms;
+        r.num_varyings = 3;
+        copy_floats(r.camera_vp, &u->vp_matrix, 16);
+        r.skybox = dev_cube(u->skybox);
+        if (!r.skybox) fatal("skybox draw without a cube map");
+    } else if (p->family == RZ_FAMILY_BLINN) {
+        const rz_blinn_uniforms *u = (const rz_blinn_uniforms*)p->uniforms;
+        r.num_varyings = 11;
+        copy_floats(r.light_dir, &u->light_dir, 3);
+        copy_floats(r.camera_pos, &u->camera_pos, 3);
+        copy_floats(r.model, &u->model_matrix, 16);
+        copy_floats(r.normal, &u->normal_matrix, 9);
+        copy_floats(r.light_vp, &u->light_vp_matrix, 16);
+        copy_floats(r.camera_vp, &u->camera_vp_matrix, 16);
+        joints = u->joint_matrices;
+        joint_normals = u->joint_n_matrices;
+        r.ambient = u->ambient_intensity;
+        r.punctual = u->punctual_intensity;
+        r.shadow_map = dev_tex(u->shadow_map);
+        copy_floats(r.base, &u->basecolor, 4);
+        r.shininess = u->shininess;
+        r.maps[0] = dev_tex(u->diffuse_map);
+        r.maps[1] = dev_tex(u->specular_map);
+        r.maps[2] = dev_tex(u->emission_map);
+        r.alpha_cutoff = u->alpha_cutoff;
+        if (u->shadow_pass) r.flags |= RZ_DRAW_SHADOW_PASS;
+    } else {
+        const rz_pbr_uniforms *u = (const rz_pbr_uniforms*)p->uniforms;
+        r.num_varyings = 21;
+        copy_floats(r.light_dir, &u->light_dir, 3);
+        copy_floats(r.camera_pos, &u->camera_pos, 3);
+        copy_floats(r.model, &u->model_matrix, 16);
+        copy_floats(r.normal, &u->normal_matrix, 9);
+        copy_floats(r.light_vp, &u->light_vp_matrix, 16);
+        copy_floats(r.camera_vp, &u->camera_vp_matrix, 16);
+        joints = u->joint_matrices;
+        joint_normals = u->joint_n_matrices;
+        r.ambient = u->ambient_intensity;
+        r.punctual = u->punctual_intensity;
+        r.shadow_map = dev_tex(u->shadow_map);
+        r.workflow = u->workflow;
+        if (u->workflow == 0) {
+            copy_floats(r.base, &u->basecolor_factor, 4);
+            r.metalness = u->metalness_factor;
+            r.roughness = u->roughness_factor;
+            r.maps[0] = dev_tex(u->basecolor_map);
+            r.maps[1] = dev_tex(u->metalness_map);
+            r.maps[2] = dev_tex(u->roughness_map);
+        } else {
+            copy_floats(r.base, &u->diffuse_factor, 4);
+            copy_floats(r.specular, &u->specular_factor, 3);
+            r.glossiness = u->glossiness_factor;
+            r.maps[0] = dev_tex(u->diffuse_map);
+            r.maps[1] = dev_tex(u->specular_map);
+            r.maps[2] = dev_tex(u->glossiness_map);
+        }
+        r.maps[3] = dev_tex(u->normal_map);
+        r.maps[4] = dev_tex(u->occlusion_map);
+        r.maps[5] = dev_tex(u->emission_map);
+        r.ibl = dev_ibl(u->ibldata);
+        r.alpha_cutoff = u->alpha_cutoff;
+        r.layer_view = u->layer_view;
+        if (u->shadow_pass) r.flags |= RZ_DRAW_SHADOW_PASS;
+    }
+    /* joint matrices are rewritten in place by the skeleton every frame
+     * (skeleton.c:336-337): copy them now */
+    pd.num_joints = 0;
+    if (joints) {
+        if (!joint_normals && !(r.flags & RZ_DRAW_SHADOW_PASS)) fatal("joint matrices without joint normal matrices");
+        pd.num_joints = num_joints;
+        r.flags |= RZ_DRAW_SKINNED;
+        pd.joints_at = g.side.size();
+        g.side.insert(g.side.end(), (const char*)joints, (const char*)joints + sizeof(rz_mat4) * num_joints);
+        pd.joint_normals_at = g.side.size();
+        if (joint_normals)
+            g.side.insert(g.side.end(), (const char*)joint_normals, (const char*)joint_normals + sizeof(rz_mat3) * num_joints);
+        while (g.side.size() % 16) g.side.push_back(0);
+    }
+}
+
+extern "C" void graphics_draw_mesh(rz_framebuffer *fp, rz_program *program, const rz_vertex *vertices, int num_faces) {
+    Fb *fb = as_fb(fp);
+    if (num_faces <= 0) return;
+    Pending pd;                     /* built aside: texture uploads below may flush the list */
+    pd.fb = fb;
+    pd.program = program;
+    pd.transient = false;
+    snapshot_uniforms(program, pd, device_mesh(vertices, num_faces).num_joints);
+    Mesh &m = device_mesh(vertices, num_faces);
+    pd.rec.vertices = m.d_vertices;
+    pd.rec.num_faces = num_faces;
+    g.pending.push_back(std::move(pd));
+}
+
+/* graphics.c:537: one triangle from the program's three attribute blocks.
+ * Consecutive calls with an unchanged uniform block extend one draw. */
+extern "C" void graphics_draw_triangle(rz_framebuffer *fp, rz_program *program) {
+    Fb *fb = as_fb(fp);
+    rz_vertex tri[3];
+    memset(tri, 0, sizeof tri);
+    int top = 0;
+    for (int j = 0; j < 3; j++) {
+        rz_vertex &v = tri[j];
+        if (program->family == RZ_FAMILY_BLINN) {
+            const rz_blinn_attribs *a = (const rz_blinn_attribs*)program->attribs[j];
+            v.position = a->position; v.texcoord = a->texcoord; v.normal = a->normal;
+            v.joint = a->joint; v.weight = a->weight;
+        } else if (program->family == RZ_FAMILY_PBR) {
+            v = *(const rz_vertex*)program->attribs[j];
+        } else {
+            v.position = ((const rz_skybox_attribs*)program->attribs[j])->position;
+        }
+        top = std::max(top, std::max(std::max((int)v.joint.x, (int)v.joint.y), std::max((int)v.joint.z, (int)v.joint.w)));
+    }
+    const char *ub = (const char*)program->uniforms;
+    if (!g.pending.empty()) {
+        Pending &last = g.pending.back();
+        if (last.transient && last.fb == fb && last.program == program && last.num_joints == 0 &&
+            last.uniform_bytes.size() == (size_t)program->uniform_bytes &&
+            memcmp(last.uniform_bytes.data(), ub, program->uniform_bytes) == 0) {
+            last.verts.insert(last.verts.end(), tri, tri + 3);
+            last.rec.num_faces++;
+            return;
+        }
+    }
+    Pending pd;
+    pd.fb = fb;
+    pd.program = program;
+    pd.transient = true;
+    snapshot_uniforms(program, pd, top + 1);
+    pd.uniform_bytes.assign(ub, ub + program->uniform_bytes);
+    pd.verts.assign(tri, tri + 3);
+    pd.rec.num_faces = 1;
+    g.pending.push_back(std::move(pd));
+}
+
+/* ------------------------------------------------------------------- flush -- */
+
+static size_t ring_alloc(size_t bytes) {
+    bytes = (bytes + 255) & ~(size_t)255;
+    if (bytes > g.ring_size) fatal("a single pass needs %zu bytes of upload space (ring is %zu)", bytes, g.ring_size);
+    if (g.ring_at + bytes > g.ring_size) {
+        sync_stream();              /* everything that used the ring has finished */
+        g.ring_at = 0;
+    }
+    size_t at = g.ring_at;
+    g.ring_at += bytes;
+    return at;
+}
+
+static void check_passes_in_flight() {
+    for (size_t at : g.control_slots) {
+        const uint32_t *c = (const uint32_t*)(g.ring_host + at);
+        if (c[2] & RZ_ERR_FAN_OVERFLOW) fatal("clipped-triangle buffer overflow (%u blocks needed)", c[0]);
+        if (c[2] & RZ_ERR_BIN_OVERFLOW) fatal("bin list overflow (%u entries needed)", c[1]);
+        g.host_counters[3] += c[1];
+    }
+    g.control_slots.clear();
+}
+
+static void run_pass(size_t first, size_t last) {
+    Fb *fb = g.pending[first].fb;
+    const int D = (int)(last - first);
+    size_t T = 0;
+    for (size_t i = first; i < last; i++) T += (size_t)g.pending[i].rec.num_faces;
+    if (D > 65535) fatal("%d draws in one pass (limit 65535)", D);
+    if (T > 0x3fffffffu) fatal("%zu triangles in one pass", T);
+
+    /* blob: control | DrawRec[D] | first_tri[D+1] | joint matrices | transient vertices */
+    size_t off_control = 0;
+    size_t off_draws = 256;
+    size_t off_first = off_draws + sizeof(DrawRec) * D;
+    size_t off_side = (off_first + sizeof(uint32_t) * (D + 1) + 15) & ~(size_t)15;
+    size_t total = off_side;
+    std::vector<size_t> side_at(D, 0), verts_at(D, 0);
+    for (int i = 0; i < D; i++) {
+        Pending &pd = g.pending[first + i];
+        if (pd.num_joints) {
+            side_at[i] = total;
+            total += (sizeof(rz_mat4) + sizeof(rz_mat3)) * pd.num_joints;
+            total = (total + 15) & ~(size_t)15;
+        }
+        if (pd.transient) {
+            verts_at[i] = total;
+            total += pd.verts.size() * sizeof(rz_vertex);
+            total = (total + 15) & ~(size_t)15;
+        }
+    }
+    size_t at = ring_alloc(total);
+    char *hb = g.ring_host + at, *db = g.ring_dev + at;
+    uint32_t *first_tri = (uint32_t*)(hb + off_first);
+    uint32_t running = 0;
+    for (int i = 0; i < D; i++) {
+        Pending &pd = g.pending[first + i];
+        DrawRec rec = pd.rec;
+        if (pd.num_joints) {
+            size_t jb = sizeof(rz_mat4) * pd.num_joints;
+            memcpy(hb + side_at[i], g.side.data() + pd.joints_at, jb);
+            memcpy(hb + side_at[i] + jb, g.side.data() + pd.joint_normals_at, sizeof(rz_mat3) * pd.num_joints);
+            rec.joints = (const float*)(db + side_at[i]);
+            rec.joint_normals = (const float*)(db + side_at[i] + jb);
+            if (rec.flags & RZ_DRAW_SHADOW_PASS) rec.joint_normals = nullptr;
+        }
+        if (pd.transient) {
+            memcpy(hb + verts_at[i], pd.verts.data(), pd.verts.size() * sizeof(rz_vertex));
+            rec.vertices = db + verts_at[i];
+        }
+        memcpy(hb + off_draws + sizeof(DrawRec) * i, &rec, sizeof rec);
+        first_tri[i] = running;
+        running += (uint32_t)rec.num_faces;
+    }
+    first_tri[D] = running;
+    HIP_OK(hipMemcpyAsync(db + off_draws, hb + off_draws, total - off_draws, hipMemcpyHostToDevice, g.stream));
+    HIP_OK(hipMemsetAsync(db + off_control, 0, 256, g.stream));
+
+    const int W = fb->pub.width, H = fb->pub.height;
+    const int bins_x = (W + RZ_BIN - 1) / RZ_BIN, bins_y = (H + RZ_BIN - 1) / RZ_BIN;
+    const size_t bins = (size_t)bins_x * bins_y;
+    const size_t fan_cap = std::min<size_t>(T, 1u << 18);
+    const size_t list_cap = std::min<size_t>(T * bins, std::max<size_t>(T * 16, 1u << 20));
+    reserve(g.clip, T * 3 * 4);
+    reserve(g.vary, T * 3 * RZ_VARY_STRIDE);
+    reserve(g.tri, T);
+    reserve(g.bbox, T);
+    reserve(g.fan_tri, fan_cap * RZ_MAX_FAN);
+    reserve(g.fan_vary, fan_cap * RZ_MAX_POLY * RZ_VARY_STRIDE);
+    reserve(g.bin_start, bins);
+    reserve(g.bin_count, bins);
+    reserve(g.bin_list, list_cap);
+
+    PassParams P;
+    memset(&P, 0, sizeof P);
+    P.color = fb->d_color;
+    P.depth = fb->d_depth;
+    P.width = W;
+    P.height = H;
+    P.clear_color_pending = fb->clear_color_pending;
+    P.clear_depth_pending = fb->clear_depth_pending;
+    P.clear_color = fb->clear_color;
+    P.clear_depth = fb->clear_depth;
+    P.draws = (const DrawRec*)(db + off_draws);
+    P.first_tri = (const uint32_t*)(db + off_first);
+    P.num_draws = D;
+    P.num_tris = (int)T;
+    P.clip = g.clip.ptr;
+    P.vary = g.vary.ptr;
+    P.tri = g.tri.ptr;
+    P.bbox = g.bbox.ptr;
+    P.fan_tri = g.fan_tri.ptr;
+    P.fan_vary = g.fan_vary.ptr;
+    P.fan_capacity = (int)fan_cap;
+    P.bins_x = bins_x;
+    P.bins_y = bins_y;
+    P.bin_start = g.bin_start.ptr;
+    P.bin_count = g.bin_count.ptr;
+    P.bin_list = g.bin_list.ptr;
+    P.bin_capacity = (uint32_t)list_cap;
+    P.control = (uint32_t*)(db + off_control);
+    P.counters = g.counting ? g.d_counters : nullptr;
+
+    const unsigned vblocks = (unsigned)((T * 3 + 255) / 256), tblocks = (unsigned)((T + 255) / 256);
+    const int tiles_x = (W + RZ_TILE - 1) / RZ_TILE, tiles_y = (H + RZ_TILE - 1) / RZ_TILE;
+    rz_vertex_kernel<<<dim3(vblocks), dim3(256), 0, g.stream>>>(P);
+    rz_setup_kernel<<<dim3(tblocks), dim3(256), 0, g.stream>>>(P);
+    rz_bin_kernel<<<dim3((unsigned)bins), dim3(256), 0, g.stream>>>(P);
+    rz_raster_kernel<<<dim3((unsigned)(tiles_x * tiles_y)), dim3(256), 0, g.stream>>>(P);
+    HIP_OK(hipGetLastError());
+    HIP_OK(hipMemcpyAsync(hb + off_control, db + off_control, 64, hipMemcpyDeviceToHost, g.stream));
+    g.control_slots.push_back(at + off_control);
+
+    fb->clear_color_pending = fb->clear_depth_pending = false;
+    g.host_counters[0] += T;
+    g.host_counters[4] += 1;
+    g.host_counters[5] += (unsigned long long)D;
+}
+
+extern "C" void graphics_flush(void) {
+    if (!g.ready || g.pending.empty()) return;
+    size_t n = g.pending.size(), first = 0;
+    while (first < n) {
+        size_t last = first + 1;
+        while (last < n && g.pending[last].fb == g.pending[first].fb) last++;
+        run_pass(first, last);
+        first = last;
+    }
+    g.pending.clear();
+    g.side.clear();
+}
+
+/* -------------------------------------------------------------- measurement -- */
+
+extern "C" void mi355r_enable_counters(int on) {
+    ensure_ready();
+    graphics_flush();
+    g.counting = on != 0;
+}
+
+extern "C" void mi355r_reset_counters(void) {
+    ensure_ready();
+    graphics_flush();
+    sync_stream();
+    HIP_OK(hipMemset(g.d_counters, 0, 8 * sizeof(unsigned long long)));
+    memset(g.host_counters, 0, sizeof g.host_counters);
+}
+
+extern "C" void mi355r_get_counters(unsigned long long out[8]) {
+    ensure_ready();
+    graphics_flush();
+    sync_stream();
+    unsigned long long dev[8];
+    HIP_OK(hipMemcpy(dev, g.d_counters, sizeof dev, hipMemcpyDeviceToHost));
+    for (int i = 0; i < 8; i++) out[i] = g.host_counters[i];
+    out[1] = dev[1];
+    out[2] = dev[2];
+}
+
+extern "C" void mi355r_shutdown(void) {
+    if (!g.ready) return;
+    graphics_flush();
+    sync_stream();
+}

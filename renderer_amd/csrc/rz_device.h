@@ -1,0 +1,145 @@
+/*
+ * Device-side data layout of the pipeline (shared by the host-side recorder
+ * in api.hip and the kernels).  Everything here lives in HBM for the duration
+ * of one pass; a "pass" is a maximal run of draws into one framebuffer.
+ *
+ *   draws[D]        one DrawRec per draw call: family, state, uniforms in
+ *                   device form (texture handles resolved to DevTex)
+ *   first_tri[D+1]  exclusive prefix of the draws' face counts: triangle t of
+ *                   the pass belongs to the draw d with first_tri[d] <= t
+ *   clip[3T]        clip-space position per vertex            (vertex kernel)
+ *   vary[3T][24]    varying floats per vertex, 96-byte stride  (vertex kernel)
+ *   tri[T]          TriRec per input triangle                  (setup kernel)
+ *   bbox[T]         packed screen bounding box per triangle    (setup kernel)
+ *   fan_tri / fan_vary   records and varyings of clipped triangles' fans
+ *   bin_*           per 64x64-pixel bin: ordered list of triangle indices
+ *
+ * Triangle index == submission order (draw order, then face order); every
+ * later stage walks triangles in ascending index, which is what preserves the
+ * reference's last-writer-wins / blend order per pixel.
+ */
+#ifndef RZ_DEVICE_H
+#define RZ_DEVICE_H
+
+#include <stdint.h>
+
+#define RZ_VARY_STRIDE 24           /* floats per vertex in vary[] (max used: 21) */
+#define RZ_MAX_POLY 10              /* corners of a triangle clipped by 7 planes */
+#define RZ_MAX_FAN 8                /* RZ_MAX_POLY - 2 */
+#define RZ_BIN 64                   /* bin edge in pixels */
+#define RZ_TILE 16                  /* raster workgroup tile edge (4 waves of 8x8) */
+
+enum { RZ_FMT_RGBA32F = 0, RZ_FMT_R32F = 1 };
+enum { RZ_TEX_MORTON = 1, RZ_TEX_R32F = 2 };
+
+/* a sampled image; data == nullptr means "no map bound" */
+struct DevTex {
+    const void *data;
+    int32_t w, h;
+    int32_t flags;                  /* RZ_TEX_* */
+    int32_t mbits;                  /* Morton: interleaved low bits per axis */
+};
+
+struct DevIbl {                     /* pbr_shader.h:13-18 in device form */
+    int32_t mip_levels;
+    int32_t pad;
+    DevTex lut;
+    DevTex diffuse[6];
+    DevTex specular[15][6];
+};
+
+enum {
+    RZ_DRAW_DOUBLE_SIDED = 1,
+    RZ_DRAW_BLEND = 2,
+    RZ_DRAW_SHADOW_PASS = 4,
+    RZ_DRAW_SKINNED = 8
+};
+
+struct DrawRec {
+    int32_t family;                 /* rz_family */
+    int32_t flags;                  /* RZ_DRAW_* */
+    int32_t num_varyings;           /* floats: 11 blinn, 21 pbr, 3 skybox */
+    int32_t num_faces;
+    const void *vertices;           /* rz_vertex[3 * num_faces] on the device */
+    const float *joints;            /* mat4[] for skinning or nullptr */
+    const float *joint_normals;     /* mat3[] or nullptr */
+    /* uniforms common to blinn and pbr (blinn_shader.h:23-34, pbr_shader.h:39-50);
+     * the skybox keeps its vp matrix in camera_vp */
+    float light_dir[3];
+    float camera_pos[3];
+    float model[16];
+    float normal[9];
+    float light_vp[16];
+    float camera_vp[16];
+    float ambient, punctual;
+    DevTex shadow_map;
+    /* surface: blinn basecolor / pbr basecolor_factor or diffuse_factor */
+    float base[4];
+    float shininess;                /* blinn */
+    float metalness, roughness;     /* pbr metal-rough factors */
+    float specular[3];              /* pbr spec-gloss */
+    float glossiness;
+    /* maps: blinn {diffuse, specular, emission};
+     * pbr {basecolor|diffuse, metalness|specular, roughness|glossiness,
+     *      normal, occlusion, emission} */
+    DevTex maps[6];
+    const DevIbl *ibl;
+    const DevTex *skybox;           /* 6 faces */
+    int32_t workflow;               /* 0 metal-rough, 1 spec-gloss */
+    float alpha_cutoff;
+    int32_t layer_view;
+    int32_t pad;
+};
+
+/* One rasterisable triangle: what rasterize_triangle (graphics.c:472-535)
+ * derives before its pixel loop.  For an input triangle that had to be
+ * clipped the main record only points at its fan. */
+struct TriRec {
+    float ax, ay;                   /* screen position of corner a */
+    float abx, aby, acx, acy;       /* edges b-a and c-a */
+    float factor;                   /* 1 / (ab x ac) */
+    float z[3];                     /* screen depth per corner */
+    float rw[3];                    /* 1 / clip.w per corner */
+    uint32_t meta;                  /* draw | backface << 16 | clipped << 17 | fan_count << 18 */
+    uint32_t bx, by;                /* own bounding box: min | max << 16 */
+};
+
+#define RZ_META_DRAW(m) ((m) & 0xffffu)
+#define RZ_META_BACKFACE(m) (((m) >> 16) & 1u)
+#define RZ_META_CLIPPED(m) (((m) >> 17) & 1u)
+#define RZ_META_FAN(m) (((m) >> 18) & 15u)
+#define RZ_BBOX_EMPTY_X 0x0000ffffu  /* min 65535 > max 0 */
+
+struct PassParams {
+    /* target */
+    uint32_t *color;                /* RGBA8, row 0 = bottom */
+    float *depth;
+    int32_t width, height;
+    int32_t clear_color_pending, clear_depth_pending;
+    uint32_t clear_color;
+    float clear_depth;
+    /* geometry */
+    const DrawRec *draws;
+    const uint32_t *first_tri;      /* num_draws + 1 */
+    int32_t num_draws, num_tris;
+    float *clip;                    /* float4 per vertex */
+    float *vary;
+    TriRec *tri;
+    uint2 *bbox;
+    TriRec *fan_tri;                /* fan_capacity * RZ_MAX_FAN */
+    float *fan_vary;                /* fan_capacity * RZ_MAX_POLY * RZ_VARY_STRIDE */
+    int32_t fan_capacity;
+    /* binning */
+    int32_t bins_x, bins_y;
+    uint32_t *bin_start, *bin_count;
+    uint32_t *bin_list;
+    uint32_t bin_capacity;
+    /* scalars written by the device: [0] fan blocks used, [1] bin entries
+     * used, [2] error bits, [3..] counters */
+    uint32_t *control;
+    unsigned long long *counters;   /* nullptr unless counting is enabled */
+};
+
+enum { RZ_ERR_FAN_OVERFLOW = 1, RZ_ERR_BIN_OVERFLOW = 2 };
+
+#endif

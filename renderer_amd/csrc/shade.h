@@ -1,0 +1,394 @@
+/*
+ * Device maths, texture sampling and the fragment shaders of the three shader
+ * families (gfx950).  Every expression keeps the association order of the
+ * reference routine it replaces (cited per function) and the translation unit
+ * is compiled with -ffp-contract=off, correctly rounded f32 divide/sqrt and
+ * denormals on, so everything except the double-precision pow() calls is
+ * bit-identical to the strict CPU path.
+ *
+ * A fragment shader here runs for the lanes of one wave that passed the depth
+ * test of ONE triangle: the draw's uniforms are wave-uniform (scalar loads),
+ * varyings are per lane.
+ */
+#ifndef RZ_SHADE_H
+#define RZ_SHADE_H
+
+#include <hip/hip_runtime.h>
+#include "rz_device.h"
+
+#define RZ_EPS 1e-5f                /* macro.h:4 */
+#define RZ_PI_F 3.1415927f          /* macro.h:5 */
+
+struct f3 { float x, y, z; };
+struct f4 { float x, y, z, w; };
+
+#define RZ_DEV static __device__ __forceinline__
+
+RZ_DEV float d_max(float a, float b) { return a > b ? a : b; }                 /* maths.c:13 */
+RZ_DEV float d_min(float a, float b) { return a < b ? a : b; }                 /* maths.c:9 */
+RZ_DEV float d_mix(float a, float b, float t) { return a + (b - a) * t; }      /* maths.c:17 */
+RZ_DEV float d_sat(float f) { return f < 0 ? 0 : (f > 1 ? 1 : f); }            /* maths.c:25 */
+RZ_DEV float d_srgb(float v) { return (float)pow((double)v, 1 / 2.2); }        /* maths.c:41 */
+RZ_DEV float d_aces(float v) {                                                 /* maths.c:49 */
+    float a = 2.51f, b = 0.03f, c = 2.43f, d = 0.59f, e = 0.14f;
+    v = (v * (a * v + b)) / (v * (c * v + d) + e);
+    return d_sat(v);
+}
+RZ_DEV f3 mk3(float x, float y, float z) { f3 v; v.x = x; v.y = y; v.z = z; return v; }
+RZ_DEV f4 mk4(float x, float y, float z, float w) { f4 v; v.x = x; v.y = y; v.z = z; v.w = w; return v; }
+RZ_DEV f3 add3(f3 a, f3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
+RZ_DEV f3 sub3(f3 a, f3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
+RZ_DEV f3 scale3(f3 v, float f) { return mk3(v.x * f, v.y * f, v.z * f); }
+RZ_DEV f3 div3(f3 v, float d) { return scale3(v, 1 / d); }                     /* maths.c:157 */
+RZ_DEV f3 neg3(f3 v) { return mk3(-v.x, -v.y, -v.z); }
+RZ_DEV f3 mul3(f3 a, f3 b) { return mk3(a.x * b.x, a.y * b.y, a.z * b.z); }
+RZ_DEV float dot3(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }    /* maths.c:173 */
+RZ_DEV f3 unit3(f3 v) { return div3(v, sqrtf(dot3(v, v))); }                   /* maths.c:165-171 */
+RZ_DEV f3 cross3(f3 a, f3 b) {                                                 /* maths.c:177 */
+    return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+RZ_DEV f3 mix3(f3 a, f3 b, float t) { return mk3(d_mix(a.x, b.x, t), d_mix(a.y, b.y, t), d_mix(a.z, b.z, t)); }
+RZ_DEV f3 xyz(f4 v) { return mk3(v.x, v.y, v.z); }
+
+/* row-major 4x4 * column vector, ((a + b) + c) + d per row (maths.c:551) */
+RZ_DEV f4 m4v4(const float *m, f4 v) {
+    f4 o;
+    o.x = m[0] * v.x + m[1] * v.y + m[2] * v.z + m[3] * v.w;
+    o.y = m[4] * v.x + m[5] * v.y + m[6] * v.z + m[7] * v.w;
+    o.z = m[8] * v.x + m[9] * v.y + m[10] * v.z + m[11] * v.w;
+    o.w = m[12] * v.x + m[13] * v.y + m[14] * v.z + m[15] * v.w;
+    return o;
+}
+RZ_DEV f3 m3v3(const float *m, f3 v) {                                          /* maths.c:387 */
+    return mk3(m[0] * v.x + m[1] * v.y + m[2] * v.z,
+               m[3] * v.x + m[4] * v.y + m[5] * v.z,
+               m[6] * v.x + m[7] * v.y + m[8] * v.z);
+}
+
+/* ---- texture addressing -------------------------------------------------- */
+
+RZ_DEV uint32_t spread_bits(uint32_t x) {      /* abcd -> 0a0b0c0d (16 bits) */
+    x &= 0xffffu;
+    x = (x | (x << 8)) & 0x00ff00ffu;
+    x = (x | (x << 4)) & 0x0f0f0f0fu;
+    x = (x | (x << 2)) & 0x33333333u;
+    x = (x | (x << 1)) & 0x55555555u;
+    return x;
+}
+
+/* Morton (Z-order) inside the largest square power of two, remaining high
+ * bits of the longer axis on top; row-major for other sizes */
+RZ_DEV uint32_t texel_index(int w, int flags, int mbits, int c, int r) {
+    if (flags & RZ_TEX_MORTON) {
+        uint32_t mask = (1u << mbits) - 1u;
+        uint32_t lo = spread_bits((uint32_t)c & mask) | (spread_bits((uint32_t)r & mask) << 1);
+        uint32_t hi = ((uint32_t)c >> mbits) | ((uint32_t)r >> mbits);
+        return lo | (hi << (2 * mbits));
+    }
+    return (uint32_t)r * (uint32_t)w + (uint32_t)c;
+}
+
+RZ_DEV f4 fetch_texel(const DevTex &t, int c, int r) {
+    c = c < 0 ? 0 : (c > t.w - 1 ? t.w - 1 : c);       /* never taken for finite coordinates */
+    r = r < 0 ? 0 : (r > t.h - 1 ? t.h - 1 : r);
+    uint32_t i = texel_index(t.w, t.flags, t.mbits, c, r);
+    if (t.flags & RZ_TEX_R32F) {
+        float d = ((const float*)t.data)[i];
+        return mk4(d, d, d, 1.0f);
+    }
+    float4 v = ((const float4*)t.data)[i];
+    return mk4(v.x, v.y, v.z, v.w);
+}
+
+/* nearest texel, index = (int)((size - 1) * coordinate) (texture.c:160-176) */
+RZ_DEV f4 sample_repeat(const DevTex &t, float x, float y) {
+    float u = x - floorf(x);
+    float v = y - floorf(y);
+    int c = (int)((float)(t.w - 1) * u);
+    int r = (int)((float)(t.h - 1) * v);
+    return fetch_texel(t, c, r);
+}
+RZ_DEV f4 sample_clamp(const DevTex &t, float x, float y) {
+    float u = d_sat(x);
+    float v = d_sat(y);
+    int c = (int)((float)(t.w - 1) * u);
+    int r = (int)((float)(t.h - 1) * v);
+    return fetch_texel(t, c, r);
+}
+
+/* GL ES 2.0 3.7.5 face selection with strict comparisons (texture.c:210-255);
+ * the face index differs per lane, so the six descriptors are read per lane */
+RZ_DEV int cube_face(f3 d, float *s, float *t) {
+    float ax = fabsf(d.x), ay = fabsf(d.y), az = fabsf(d.z);
+    float ma, sc, tc;
+    int face;
+    if (ax > ay && ax > az) {
+        ma = ax;
+        if (d.x > 0) { face = 0; sc = -d.z; tc = -d.y; }
+        else         { face = 1; sc = +d.z; tc = -d.y; }
+    } else if (ay > az) {
+        ma = ay;
+        if (d.y > 0) { face = 2; sc = +d.x; tc = +d.z; }
+        else         { face = 3; sc = +d.x; tc = -d.z; }
+    } else {
+        ma = az;
+        if (d.z > 0) { face = 4; sc = +d.x; tc = -d.y; }
+        else         { face = 5; sc = -d.x; tc = -d.y; }
+    }
+    *s = (sc / ma + 1) / 2;
+    *t = (tc / ma + 1) / 2;
+    return face;
+}
+RZ_DEV f4 cube_repeat(const DevTex *faces, f3 dir) {                  /* texture.c:257 */
+    float s, t;
+    int face = cube_face(dir, &s, &t);
+    DevTex f = faces[face];
+    return sample_repeat(f, s, 1 - t);
+}
+RZ_DEV f4 cube_clamp(const DevTex *faces, f3 dir) {                   /* texture.c:264 */
+    float s, t;
+    int face = cube_face(dir, &s, &t);
+    DevTex f = faces[face];
+    return sample_clamp(f, s, 1 - t);
+}
+
+/* ---- shared by blinn and pbr --------------------------------------------- */
+
+/* blinn_shader.c:178-195 == pbr_shader.c:311-328 */
+RZ_DEV bool in_shadow(const DrawRec &D, f3 depth_position, float n_dot_l) {
+    if (D.shadow_map.data) {
+        float u = (depth_position.x + 1) * 0.5f;
+        float v = (depth_position.y + 1) * 0.5f;
+        float d = (depth_position.z + 1) * 0.5f;
+        float bias = d_max(0.05f * (1 - n_dot_l), 0.005f);
+        float current = d - bias;
+        float closest = sample_repeat(D.shadow_map, u, v).x;
+        return current > closest;
+    }
+    return false;
+}
+
+/* ---- blinn: varyings = world_position[3] depth_position[3] texcoord[2] normal[3]
+ *      (blinn_shader.h:16-21) --------------------------------------------- */
+
+RZ_DEV f4 fs_blinn(const DrawRec &D, const float *v, bool backface, bool *discard) {
+    float tu = v[6], tv = v[7];
+    if (D.flags & RZ_DRAW_SHADOW_PASS) {                        /* blinn_shader.c:101-115 */
+        if (D.alpha_cutoff > 0) {
+            float a = D.base[3];
+            if (D.maps[0].data) a *= sample_repeat(D.maps[0], tu, tv).w;
+            if (a < D.alpha_cutoff) *discard = true;
+        }
+        return mk4(0, 0, 0, 0);
+    }
+    /* material (:126-169) */
+    f3 diffuse = mk3(D.base[0], D.base[1], D.base[2]);
+    float alpha = D.base[3];
+    if (D.maps[0].data) {
+        f4 s = sample_repeat(D.maps[0], tu, tv);
+        diffuse = mul3(diffuse, xyz(s));
+        alpha *= s.w;
+    }
+    f3 specular = mk3(0, 0, 0);
+    if (D.maps[1].data) specular = xyz(sample_repeat(D.maps[1], tu, tv));
+    f3 normal = unit3(mk3(v[8], v[9], v[10]));
+    if (backface) normal = neg3(normal);
+    f3 emission = mk3(0, 0, 0);
+    if (D.maps[2].data) emission = xyz(sample_repeat(D.maps[2], tu, tv));
+
+    if (D.alpha_cutoff > 0 && alpha < D.alpha_cutoff) {         /* :220-222 */
+        *discard = true;
+        return mk4(0, 0, 0, 0);
+    }
+    f3 color = emission;                                        /* :224-245 */
+    if (D.ambient > 0) color = add3(color, scale3(diffuse, D.ambient));
+    if (D.punctual > 0) {
+        f3 light = neg3(mk3(D.light_dir[0], D.light_dir[1], D.light_dir[2]));
+        float n_dot_l = dot3(normal, light);
+        if (n_dot_l > 0 && !in_shadow(D, mk3(v[3], v[4], v[5]), n_dot_l)) {
+            f3 cam = mk3(D.camera_pos[0], D.camera_pos[1], D.camera_pos[2]);
+            f3 view = unit3(sub3(cam, mk3(v[0], v[1], v[2])));
+            f3 spec = mk3(0, 0, 0);
+            if (!(specular.x == 0 && specular.y == 0 && specular.z == 0)) {      /* :201-212 */
+                f3 half = unit3(add3(light, view));
+                float n_dot_h = dot3(normal, half);
+                if (n_dot_h > 0) spec = scale3(specular, (float)pow((double)n_dot_h, (double)D.shininess));
+            }
+            f3 lit = add3(scale3(diffuse, n_dot_l), spec);
+            color = add3(color, scale3(lit, D.punctual));
+        }
+    }
+    return mk4(color.x, color.y, color.z, alpha);
+}
+
+/* ---- pbr: varyings = world_position[3] depth_position[3] clip_position[4]
+ *      world_normal[3] world_tangent[3] world_bitangent[3] texcoord[2]
+ *      (pbr_shader.h:29-37) ----------------------------------------------- */
+
+struct Surface {
+    f3 diffuse, specular;
+    float alpha, roughness;
+    f3 normal;
+    float occlusion;
+    f3 emission;
+};
+
+RZ_DEV float largest3(f3 v) { return v.x > v.y && v.x > v.z ? v.x : (v.y > v.z ? v.y : v.z); }   /* pbr_shader.c:184 */
+
+RZ_DEV Surface pbr_surface(const DrawRec &D, const float *v, bool backface) {
+    Surface s;
+    float tu = v[19], tv = v[20];
+    if (D.workflow == 0) {                                      /* metal-rough, :148-182 */
+        f3 base = mk3(D.base[0], D.base[1], D.base[2]);
+        float metal = D.metalness, rough = D.roughness;
+        s.alpha = D.base[3];
+        if (D.maps[0].data) {
+            f4 t = sample_repeat(D.maps[0], tu, tv);
+            base = mul3(base, xyz(t));
+            s.alpha *= t.w;
+        }
+        if (D.maps[1].data) metal *= sample_repeat(D.maps[1], tu, tv).x;
+        if (D.maps[2].data) rough *= sample_repeat(D.maps[2], tu, tv).x;
+        s.diffuse = scale3(base, (1 - 0.04f) * (1 - metal));
+        s.specular = mix3(mk3(0.04f, 0.04f, 0.04f), base, metal);
+        s.roughness = rough;
+    } else {                                                    /* spec-gloss, :188-222 */
+        f3 diff = mk3(D.base[0], D.base[1], D.base[2]);
+        f3 spec = mk3(D.specular[0], D.specular[1], D.specular[2]);
+        float gloss = D.glossiness;
+        s.alpha = D.base[3];
+        if (D.maps[0].data) {
+            f4 t = sample_repeat(D.maps[0], tu, tv);
+            diff = mul3(diff, xyz(t));
+            s.alpha *= t.w;
+        }
+        if (D.maps[1].data) spec = mul3(spec, xyz(sample_repeat(D.maps[1], tu, tv)));
+        if (D.maps[2].data) gloss *= sample_repeat(D.maps[2], tu, tv).x;
+        s.diffuse = scale3(diff, 1 - largest3(spec));
+        s.specular = spec;
+        s.roughness = 1 - gloss;
+    }
+    if (D.maps[3].data) {                                       /* normal map, :224-243 */
+        f4 t = sample_repeat(D.maps[3], tu, tv);
+        f3 tn = mk3(t.x * 2 - 1, t.y * 2 - 1, t.z * 2 - 1);
+        /* TBN has tangent, bitangent, normal as COLUMNS */
+        f3 wn = mk3(v[13] * tn.x + v[16] * tn.y + v[10] * tn.z,
+                    v[14] * tn.x + v[17] * tn.y + v[11] * tn.z,
+                    v[15] * tn.x + v[18] * tn.y + v[12] * tn.z);
+        s.normal = unit3(wn);
+    } else {
+        s.normal = unit3(mk3(v[10], v[11], v[12]));
+    }
+    if (backface) s.normal = neg3(s.normal);
+    s.occlusion = D.maps[4].data ? sample_repeat(D.maps[4], tu, tv).x : 1.0f;      /* :259-264 */
+    s.emission = D.maps[5].data ? xyz(sample_repeat(D.maps[5], tu, tv)) : mk3(0, 0, 0);
+    return s;
+}
+
+/* image-based lighting (:281-309); the prefiltered level differs per lane */
+RZ_DEV f3 pbr_ambient(const Surface &s, const DevIbl *ibl, f3 n, f3 view) {
+    f3 diffuse_color = scale3(s.diffuse, s.occlusion);
+    f3 irradiance = xyz(cube_clamp(ibl->diffuse, n));
+    f3 diffuse = mul3(irradiance, diffuse_color);
+    float n_dot_v = dot3(n, view);
+    f4 lut = sample_clamp(ibl->lut, n_dot_v, s.roughness);
+    f3 spec_color = mk3(s.specular.x * lut.x + lut.y, s.specular.y * lut.x + lut.y, s.specular.z * lut.x + lut.y);
+    f3 reflected = sub3(scale3(n, 2 * n_dot_v), view);          /* :276-279 */
+    float top = (float)(ibl->mip_levels - 1);
+    int level = (int)(s.roughness * top + 0.5f);
+    level = level < 0 ? 0 : (level > ibl->mip_levels - 1 ? ibl->mip_levels - 1 : level);
+    f3 radiance = xyz(cube_clamp(ibl->specular[level], reflected));
+    return add3(diffuse, mul3(radiance, spec_color));
+}
+
+/* GGX D, height-correlated Smith V, Schlick F (:334-393) */
+RZ_DEV f3 pbr_light(const Surface &s, f3 light, f3 n, f3 view) {
+    float n_dot_l = dot3(n, light);
+    float n_dot_v = dot3(n, view);
+    if (n_dot_l > 0 && n_dot_v > 0) {
+        f3 half = unit3(add3(light, view));
+        float n_dot_h = d_max(dot3(n, half), 0);
+        float v_dot_h = d_max(dot3(view, half), 0);
+        float a1 = s.roughness * s.roughness;
+        float a2 = a1 * a1;
+        float ndh2 = n_dot_h * n_dot_h;
+        float fd = ndh2 * (a2 - 1) + 1;
+        float d_term = a2 / (RZ_PI_F * fd * fd);
+        float ndv2 = n_dot_v * n_dot_v, ndl2 = n_dot_l * n_dot_l;
+        float gv = n_dot_l * sqrtf(ndv2 * (1 - a2) + a2);
+        float gl = n_dot_v * sqrtf(ndl2 * (1 - a2) + a2);
+        float v_term = 0.5f / (gv + gl);
+        float ff = (float)pow((double)(1 - v_dot_h), 5.0);
+        float f90 = d_sat(largest3(s.specular) * 50);
+        f3 f = mk3(s.specular.x + (f90 - s.specular.x) * ff,
+                   s.specular.y + (f90 - s.specular.y) * ff,
+                   s.specular.z + (f90 - s.specular.z) * ff);
+        f3 dl = div3(s.diffuse, RZ_PI_F);
+        f3 sl = scale3(f, v_term * d_term);
+        f3 lobe = mk3((1 - f.x) * dl.x + sl.x, (1 - f.y) * dl.y + sl.y, (1 - f.z) * dl.z + sl.z);
+        return scale3(lobe, n_dot_l);
+    }
+    return mk3(0, 0, 0);
+}
+
+RZ_DEV f4 display_encode(f3 c, float alpha) {                    /* :401-406 */
+    return mk4(d_srgb(d_aces(c.x)), d_srgb(d_aces(c.y)), d_srgb(d_aces(c.z)), alpha);
+}
+
+/* layer inspector (:408-438) */
+RZ_DEV bool right_of_band_edge(int edge, float px, float py) {
+    float space = 0.15f;
+    float offset = space * (float)edge;
+    float sx = (1 - space * 0.5f) - offset, ex = (space * (5 - 0.5f)) - offset;
+    return (px - sx) * (1.0f - 0.0f) - (py - 0.0f) * (ex - sx) > 0;
+}
+RZ_DEV f4 layer_color(int layer, const Surface &s) {
+    if (layer == 1) return display_encode(s.diffuse, s.alpha);
+    if (layer == 2) return display_encode(s.specular, s.alpha);
+    if (layer == 3) return mk4(s.roughness, s.roughness, s.roughness, s.alpha);
+    if (layer == 4) return mk4(s.occlusion, s.occlusion, s.occlusion, s.alpha);
+    return mk4(s.normal.x * 0.5f + 0.5f, s.normal.y * 0.5f + 0.5f, s.normal.z * 0.5f + 0.5f, s.alpha);
+}
+
+RZ_DEV f4 fs_pbr(const DrawRec &D, const float *v, bool backface, bool *discard) {
+    if (D.flags & RZ_DRAW_SHADOW_PASS) {                        /* pbr_shader.c:113-136 */
+        if (D.alpha_cutoff > 0) {
+            float a = D.base[3];    /* basecolor_factor.w or diffuse_factor.w */
+            if (D.maps[0].data) a *= sample_repeat(D.maps[0], v[19], v[20]).w;
+            if (a < D.alpha_cutoff) *discard = true;
+        }
+        return mk4(0, 0, 0, 0);
+    }
+    Surface s = pbr_surface(D, v, backface);                    /* :446-490 */
+    float sxn = v[6] / v[9] * 0.5f + 0.5f;
+    float syn = v[7] / v[9] * 0.5f + 0.5f;
+    if (D.alpha_cutoff > 0 && s.alpha < D.alpha_cutoff) {
+        *discard = true;
+        return mk4(0, 0, 0, 0);
+    } else if (D.layer_view > 0) {
+        return layer_color(D.layer_view, s);
+    } else if (D.layer_view == 0 && !right_of_band_edge(0, sxn, syn)) {
+        int edge;
+        for (edge = 1; edge < 5; edge++) if (right_of_band_edge(edge, sxn, syn)) break;
+        return layer_color(edge, s);
+    } else {
+        f3 cam = mk3(D.camera_pos[0], D.camera_pos[1], D.camera_pos[2]);
+        f3 view = unit3(sub3(cam, mk3(v[0], v[1], v[2])));
+        f3 light = neg3(mk3(D.light_dir[0], D.light_dir[1], D.light_dir[2]));
+        float n_dot_l = dot3(s.normal, light);
+        f3 color = s.emission;
+        if (D.ambient > 0 && D.ibl) color = add3(color, scale3(pbr_ambient(s, D.ibl, s.normal, view), D.ambient));
+        if (D.punctual > 0 && n_dot_l > 0) {
+            if (!in_shadow(D, mk3(v[3], v[4], v[5]), n_dot_l))
+                color = add3(color, scale3(pbr_light(s, light, s.normal, view), D.punctual));
+        }
+        return display_encode(color, s.alpha);
+    }
+}
+
+/* ---- skybox: varyings = direction[3] (skybox_shader.c:21-29) -------------- */
+RZ_DEV f4 fs_skybox(const DrawRec &D, const float *v) {
+    return cube_repeat(D.skybox, mk3(v[0], v[1], v[2]));
+}
+
+#endif
