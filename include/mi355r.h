@@ -248,12 +248,21 @@ void mi355r_shutdown(void);
 const char *mi355r_backend(void);
 void *mi355r_stream(void);              /* hipStream_t of the pipeline */
 
-/* Counters of the last flush-to-flush interval (for measurement):
- * index 0 triangles submitted, 1 triangles after clip/cull (raster prims),
- * 2 fragments shaded, 3 tile-bin entries, 4 passes, 5 draws. */
-void mi355r_get_counters(unsigned long long out[8]);
+/* Workload counters since the last reset (measurement only; the device-side
+ * ones cost atomics and are off unless enabled): index 0 triangles submitted,
+ * 1 triangles rasterised after clip/cull, 2 fragments shaded (the reference's
+ * draw_fragment calls, graphics.c:437), 3 bin-list entries, 4 passes,
+ * 5 draws, 6 skybox fragments, 7 blended fragments, 8 fragments the device
+ * actually shaded (deferred shading skips fragments that get overdrawn). */
+void mi355r_get_counters(unsigned long long out[12]);
 void mi355r_reset_counters(void);
 void mi355r_enable_counters(int on);
+
+/* Device time per kernel, from HIP events recorded on the pipeline's stream
+ * around each launch while enabled: out_ms[0..3] = summed milliseconds of the
+ * vertex, setup, bin and raster kernels; returns the number of passes. */
+void mi355r_enable_timing(int on);
+unsigned long long mi355r_get_timing(double out_ms[4], int reset);
 
 #ifdef __cplusplus
 }

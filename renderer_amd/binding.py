@@ -74,6 +74,10 @@ class Pipeline:
             lib.mi355r_get_counters.argtypes = [C.POINTER(C.c_ulonglong)]
             lib.mi355r_enable_counters.argtypes = [C.c_int]
             lib.mi355r_stream.restype = P
+            lib.mi355r_reset_counters.argtypes = []
+            lib.mi355r_enable_timing.argtypes = [C.c_int]
+            lib.mi355r_get_timing.argtypes = [C.POINTER(C.c_double), C.c_int]
+            lib.mi355r_get_timing.restype = C.c_ulonglong
         else:
             lib.oracle_get_stats.argtypes = [C.POINTER(C.c_ulonglong)]
         lib.rzs_set_assets_dir(assets.encode())
@@ -138,8 +142,14 @@ class Pipeline:
         self.release(fb)
         return out
 
+    def kernel_times(self, reset=True):
+        """(passes, [vertex, setup, bin, raster] summed ms) since timing was enabled/reset."""
+        ms = (C.c_double * 4)()
+        n = self.lib.mi355r_get_timing(ms, 1 if reset else 0)
+        return int(n), list(ms)
+
     def counters(self):
-        out = (C.c_ulonglong * 8)()
+        out = (C.c_ulonglong * 12)()
         if self.is_gpu:
             self.lib.mi355r_get_counters(out)
         else:

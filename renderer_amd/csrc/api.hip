@@ -106,7 +106,7 @@ struct Context {
     DevBuf<float> clip, vary, fan_vary;
     DevBuf<TriRec> tri, fan_tri;
     DevBuf<uint2> bbox;
-    DevBuf<uint32_t> bin_start, bin_count, bin_list;
+    DevBuf<uint32_t> bin_start, bin_count, bin_list, clip_list;
     /* upload ring: pinned host memory mirrored 1:1 in device memory */
     char *ring_host = nullptr, *ring_dev = nullptr;
     size_t ring_size = 0, ring_at = 0;
@@ -123,6 +123,10 @@ struct Context {
     struct Registered { void *vs, *fs; int family; };
     std::vector<Registered> families;
     /* measurement */
+    bool timing = false;
+    std::vector<hipEvent_t> timing_events;  /* 5 per pass: before vertex, after vertex/setup/bin/raster */
+    double kernel_ms[4] = {0, 0, 0, 0};
+    unsigned long long kernel_launches = 0;
     bool counting = false;
     unsigned long long *d_counters = nullptr;
     unsigned long long host_counters[8] = {0};
@@ -163,8 +167,8 @@ extern "C" int mi355r_init(int device) {
     HIP_OK(hipHostMalloc((void**)&g.ring_host, RING_BYTES, hipHostMallocDefault));
     HIP_OK(hipMalloc((void**)&g.ring_dev, RING_BYTES));
     g.ring_size = RING_BYTES;
-    HIP_OK(hipMalloc((void**)&g.d_counters, 8 * sizeof(unsigned long long)));
-    HIP_OK(hipMemset(g.d_counters, 0, 8 * sizeof(unsigned long long)));
+    HIP_OK(hipMalloc((void**)&g.d_counters, 12 * sizeof(unsigned long long)));
+    HIP_OK(hipMemset(g.d_counters, 0, 12 * sizeof(unsigned long long)));
     g.ready = true;
     return g.device;
 }
@@ -750,7 +754,7 @@ extern "C" void graphics_draw_triangle(rz_framebuffer *fp, rz_program *program) 
 
 static size_t ring_alloc(size_t bytes) {
     bytes = (bytes + 255) & ~(size_t)255;
-    if (bytes > g.ring_size) fatal("a single pass needs %zu bytes of upload space (ring is %zu)", bytes, g.ring_size);
+    if (bytes > g.ring_size) fatal("one flush needs %zu bytes of upload space (ring is %zu)", bytes, g.ring_size);
     if (g.ring_at + bytes > g.ring_size) {
         sync_stream();              /* everything that used the ring has finished */
         g.ring_at = 0;
@@ -770,61 +774,74 @@ static void check_passes_in_flight() {
     g.control_slots.clear();
 }
 
-static void run_pass(size_t first, size_t last) {
-    Fb *fb = g.pending[first].fb;
-    const int D = (int)(last - first);
-    size_t T = 0;
-    for (size_t i = first; i < last; i++) T += (size_t)g.pending[i].rec.num_faces;
-    if (D > 65535) fatal("%d draws in one pass (limit 65535)", D);
-    if (T > 0x3fffffffu) fatal("%zu triangles in one pass", T);
+/* layout of one pass inside the flush's upload region */
+struct PassPlan {
+    size_t first, last;             /* range in g.pending */
+    size_t T;                       /* triangles */
+    size_t off_draws, off_first;    /* offsets from the region start */
+    std::vector<size_t> side_at, verts_at;
+};
 
-    /* blob: control | DrawRec[D] | first_tri[D+1] | joint matrices | transient vertices */
-    size_t off_control = 0;
-    size_t off_draws = 256;
-    size_t off_first = off_draws + sizeof(DrawRec) * D;
-    size_t off_side = (off_first + sizeof(uint32_t) * (D + 1) + 15) & ~(size_t)15;
-    size_t total = off_side;
-    std::vector<size_t> side_at(D, 0), verts_at(D, 0);
-    for (int i = 0; i < D; i++) {
-        Pending &pd = g.pending[first + i];
+static const size_t CONTROL_BYTES = 64;
+
+static void plan_pass(PassPlan &pl, size_t &total) {
+    const size_t D = pl.last - pl.first;
+    pl.T = 0;
+    for (size_t i = pl.first; i < pl.last; i++) pl.T += (size_t)g.pending[i].rec.num_faces;
+    if (D > 65535) fatal("%zu draws in one pass (limit 65535)", D);
+    if (pl.T > 0x3fffffffu) fatal("%zu triangles in one pass", pl.T);
+    total = (total + 255) & ~(size_t)255;
+    pl.off_draws = total;
+    total += sizeof(DrawRec) * D;
+    pl.off_first = total;
+    total += sizeof(uint32_t) * (D + 1);
+    total = (total + 15) & ~(size_t)15;
+    pl.side_at.assign(D, 0);
+    pl.verts_at.assign(D, 0);
+    for (size_t i = 0; i < D; i++) {
+        Pending &pd = g.pending[pl.first + i];
         if (pd.num_joints) {
-            side_at[i] = total;
+            pl.side_at[i] = total;
             total += (sizeof(rz_mat4) + sizeof(rz_mat3)) * pd.num_joints;
             total = (total + 15) & ~(size_t)15;
         }
         if (pd.transient) {
-            verts_at[i] = total;
+            pl.verts_at[i] = total;
             total += pd.verts.size() * sizeof(rz_vertex);
             total = (total + 15) & ~(size_t)15;
         }
     }
-    size_t at = ring_alloc(total);
-    char *hb = g.ring_host + at, *db = g.ring_dev + at;
-    uint32_t *first_tri = (uint32_t*)(hb + off_first);
+}
+
+static void fill_pass(const PassPlan &pl, char *hb, char *db) {
+    const size_t D = pl.last - pl.first;
+    uint32_t *first_tri = (uint32_t*)(hb + pl.off_first);
     uint32_t running = 0;
-    for (int i = 0; i < D; i++) {
-        Pending &pd = g.pending[first + i];
+    for (size_t i = 0; i < D; i++) {
+        Pending &pd = g.pending[pl.first + i];
         DrawRec rec = pd.rec;
         if (pd.num_joints) {
             size_t jb = sizeof(rz_mat4) * pd.num_joints;
-            memcpy(hb + side_at[i], g.side.data() + pd.joints_at, jb);
-            memcpy(hb + side_at[i] + jb, g.side.data() + pd.joint_normals_at, sizeof(rz_mat3) * pd.num_joints);
-            rec.joints = (const float*)(db + side_at[i]);
-            rec.joint_normals = (const float*)(db + side_at[i] + jb);
+            memcpy(hb + pl.side_at[i], g.side.data() + pd.joints_at, jb);
+            memcpy(hb + pl.side_at[i] + jb, g.side.data() + pd.joint_normals_at, sizeof(rz_mat3) * pd.num_joints);
+            rec.joints = (const float*)(db + pl.side_at[i]);
+            rec.joint_normals = (const float*)(db + pl.side_at[i] + jb);
             if (rec.flags & RZ_DRAW_SHADOW_PASS) rec.joint_normals = nullptr;
         }
         if (pd.transient) {
-            memcpy(hb + verts_at[i], pd.verts.data(), pd.verts.size() * sizeof(rz_vertex));
-            rec.vertices = db + verts_at[i];
+            memcpy(hb + pl.verts_at[i], pd.verts.data(), pd.verts.size() * sizeof(rz_vertex));
+            rec.vertices = db + pl.verts_at[i];
         }
-        memcpy(hb + off_draws + sizeof(DrawRec) * i, &rec, sizeof rec);
+        memcpy(hb + pl.off_draws + sizeof(DrawRec) * i, &rec, sizeof rec);
         first_tri[i] = running;
         running += (uint32_t)rec.num_faces;
     }
     first_tri[D] = running;
-    HIP_OK(hipMemcpyAsync(db + off_draws, hb + off_draws, total - off_draws, hipMemcpyHostToDevice, g.stream));
-    HIP_OK(hipMemsetAsync(db + off_control, 0, 256, g.stream));
+}
 
+static void launch_pass(const PassPlan &pl, char *db, uint32_t *control) {
+    Fb *fb = g.pending[pl.first].fb;
+    const size_t D = pl.last - pl.first, T = pl.T;
     const int W = fb->pub.width, H = fb->pub.height;
     const int bins_x = (W + RZ_BIN - 1) / RZ_BIN, bins_y = (H + RZ_BIN - 1) / RZ_BIN;
     const size_t bins = (size_t)bins_x * bins_y;
@@ -834,6 +851,7 @@ static void run_pass(size_t first, size_t last) {
     reserve(g.vary, T * 3 * RZ_VARY_STRIDE);
     reserve(g.tri, T);
     reserve(g.bbox, T);
+    reserve(g.clip_list, T);
     reserve(g.fan_tri, fan_cap * RZ_MAX_FAN);
     reserve(g.fan_vary, fan_cap * RZ_MAX_POLY * RZ_VARY_STRIDE);
     reserve(g.bin_start, bins);
@@ -850,9 +868,9 @@ static void run_pass(size_t first, size_t last) {
     P.clear_depth_pending = fb->clear_depth_pending;
     P.clear_color = fb->clear_color;
     P.clear_depth = fb->clear_depth;
-    P.draws = (const DrawRec*)(db + off_draws);
-    P.first_tri = (const uint32_t*)(db + off_first);
-    P.num_draws = D;
+    P.draws = (const DrawRec*)(db + pl.off_draws);
+    P.first_tri = (const uint32_t*)(db + pl.off_first);
+    P.num_draws = (int)D;
     P.num_tris = (int)T;
     P.clip = g.clip.ptr;
     P.vary = g.vary.ptr;
@@ -861,24 +879,36 @@ static void run_pass(size_t first, size_t last) {
     P.fan_tri = g.fan_tri.ptr;
     P.fan_vary = g.fan_vary.ptr;
     P.fan_capacity = (int)fan_cap;
+    P.clip_list = g.clip_list.ptr;
     P.bins_x = bins_x;
     P.bins_y = bins_y;
     P.bin_start = g.bin_start.ptr;
     P.bin_count = g.bin_count.ptr;
     P.bin_list = g.bin_list.ptr;
     P.bin_capacity = (uint32_t)list_cap;
-    P.control = (uint32_t*)(db + off_control);
+    P.control = control;
     P.counters = g.counting ? g.d_counters : nullptr;
 
     const unsigned vblocks = (unsigned)((T * 3 + 255) / 256), tblocks = (unsigned)((T + 255) / 256);
     const int tiles_x = (W + RZ_TILE - 1) / RZ_TILE, tiles_y = (H + RZ_TILE - 1) / RZ_TILE;
+    auto stamp = [&]() {
+        if (!g.timing) return;
+        hipEvent_t e;
+        HIP_OK(hipEventCreate(&e));
+        HIP_OK(hipEventRecord(e, g.stream));
+        g.timing_events.push_back(e);
+    };
+    stamp();
     rz_vertex_kernel<<<dim3(vblocks), dim3(256), 0, g.stream>>>(P);
+    stamp();
     rz_setup_kernel<<<dim3(tblocks), dim3(256), 0, g.stream>>>(P);
-    rz_bin_kernel<<<dim3((unsigned)bins), dim3(256), 0, g.stream>>>(P);
+    rz_clip_kernel<<<dim3(256), dim3(64), 0, g.stream>>>(P);
+    stamp();
+    rz_bin_kernel<<<dim3((unsigned)bins), dim3(RZ_BIN_WAVES * 64), 0, g.stream>>>(P);
+    stamp();
     rz_raster_kernel<<<dim3((unsigned)(tiles_x * tiles_y)), dim3(256), 0, g.stream>>>(P);
+    stamp();
     HIP_OK(hipGetLastError());
-    HIP_OK(hipMemcpyAsync(hb + off_control, db + off_control, 64, hipMemcpyDeviceToHost, g.stream));
-    g.control_slots.push_back(at + off_control);
 
     fb->clear_color_pending = fb->clear_depth_pending = false;
     g.host_counters[0] += T;
@@ -886,15 +916,32 @@ static void run_pass(size_t first, size_t last) {
     g.host_counters[5] += (unsigned long long)D;
 }
 
+/* One upload region per flush: [control block per pass][pass 0 tables][pass 1 tables]...
+ * -> one host-to-device copy in front of the kernels and one small copy of the
+ * control blocks back behind them, whatever the number of passes. */
 extern "C" void graphics_flush(void) {
     if (!g.ready || g.pending.empty()) return;
+    std::vector<PassPlan> plans;
     size_t n = g.pending.size(), first = 0;
     while (first < n) {
         size_t last = first + 1;
         while (last < n && g.pending[last].fb == g.pending[first].fb) last++;
-        run_pass(first, last);
+        PassPlan pl;
+        pl.first = first;
+        pl.last = last;
+        plans.push_back(std::move(pl));
         first = last;
     }
+    size_t total = CONTROL_BYTES * plans.size();
+    for (auto &pl : plans) plan_pass(pl, total);
+    size_t at = ring_alloc(total);
+    char *hb = g.ring_host + at, *db = g.ring_dev + at;
+    for (auto &pl : plans) fill_pass(pl, hb, db);
+    size_t head = (CONTROL_BYTES * plans.size() + 255) & ~(size_t)255;
+    HIP_OK(hipMemcpyAsync(db + head, hb + head, total - head, hipMemcpyHostToDevice, g.stream));
+    for (size_t i = 0; i < plans.size(); i++) launch_pass(plans[i], db, (uint32_t*)(db + CONTROL_BYTES * i));
+    HIP_OK(hipMemcpyAsync(hb, db, CONTROL_BYTES * plans.size(), hipMemcpyDeviceToHost, g.stream));
+    for (size_t i = 0; i < plans.size(); i++) g.control_slots.push_back(at + CONTROL_BYTES * i);
     g.pending.clear();
     g.side.clear();
 }
@@ -911,19 +958,53 @@ extern "C" void mi355r_reset_counters(void) {
     ensure_ready();
     graphics_flush();
     sync_stream();
-    HIP_OK(hipMemset(g.d_counters, 0, 8 * sizeof(unsigned long long)));
+    HIP_OK(hipMemset(g.d_counters, 0, 12 * sizeof(unsigned long long)));
     memset(g.host_counters, 0, sizeof g.host_counters);
 }
 
-extern "C" void mi355r_get_counters(unsigned long long out[8]) {
+extern "C" void mi355r_get_counters(unsigned long long out[12]) {
     ensure_ready();
     graphics_flush();
     sync_stream();
-    unsigned long long dev[8];
+    unsigned long long dev[12];
     HIP_OK(hipMemcpy(dev, g.d_counters, sizeof dev, hipMemcpyDeviceToHost));
     for (int i = 0; i < 8; i++) out[i] = g.host_counters[i];
+    for (int i = 8; i < 12; i++) out[i] = 0;
     out[1] = dev[1];
     out[2] = dev[2];
+    out[6] = dev[6];
+    out[7] = dev[7];
+    out[8] = dev[8];
+}
+
+/* Per-kernel device time, measured with HIP events on the pipeline's own
+ * stream around every launch while enabled.  out_ms: summed milliseconds of
+ * the vertex, setup, bin and raster kernels; returns the number of passes. */
+extern "C" void mi355r_enable_timing(int on) {
+    ensure_ready();
+    graphics_flush();
+    sync_stream();
+    g.timing = on != 0;
+}
+
+extern "C" unsigned long long mi355r_get_timing(double out_ms[4], int reset) {
+    ensure_ready();
+    graphics_flush();
+    sync_stream();
+    for (size_t i = 0; i + 4 < g.timing_events.size(); i += 5) {
+        for (int k = 0; k < 4; k++) {
+            float ms = 0;
+            HIP_OK(hipEventElapsedTime(&ms, g.timing_events[i + k], g.timing_events[i + k + 1]));
+            g.kernel_ms[k] += ms;
+        }
+        g.kernel_launches++;
+    }
+    for (hipEvent_t e : g.timing_events) HIP_OK(hipEventDestroy(e));
+    g.timing_events.clear();
+    for (int k = 0; k < 4; k++) out_ms[k] = g.kernel_ms[k];
+    unsigned long long n = g.kernel_launches;
+    if (reset) { for (int k = 0; k < 4; k++) g.kernel_ms[k] = 0; g.kernel_launches = 0; }
+    return n;
 }
 
 extern "C" void mi355r_shutdown(void) {

@@ -3,7 +3,8 @@
  * framebuffer) per launch sequence:
  *
  *   rz_vertex_kernel   vertex shaders incl. skeletal skinning, 1 thread / vertex
- *   rz_setup_kernel    clip -> fan -> cull -> viewport -> bbox, 1 thread / triangle
+ *   rz_setup_kernel    cull -> viewport -> bbox for unclipped triangles, 1 thread / triangle
+ *   rz_clip_kernel     homogeneous clipping -> fan for the rest, 1 wave / triangle
  *   rz_bin_kernel      ordered 64x64-pixel bin lists, 1 workgroup / bin
  *   rz_raster_kernel   coverage, early-Z, varyings, fragment shaders, blend;
  *                      1 wave / 8x8 pixels, depth + colour held in registers
@@ -59,6 +60,7 @@ RZ_DEV void mat_mul(const float *a, const float *b, float *c) {
 
 __global__ void __launch_bounds__(256) rz_vertex_kernel(PassParams P) {
     uint32_t gv = blockIdx.x * 256u + threadIdx.x;
+    if (gv < 8u) P.control[gv] = 0;             /* the pass's device-written scalars start at zero */
     if (gv >= 3u * (uint32_t)P.num_tris) return;
     int d = find_draw(P.first_tri, P.num_draws, gv / 3u);
     const DrawRec &D = P.draws[d];
@@ -201,7 +203,7 @@ RZ_DEV bool make_tri(const f4 c[3], int width, int height, bool double_sided, ui
         x1 = (int)d_min(ceilf(maxx), (float)(width - 1));
         y1 = (int)d_min(ceilf(maxy), (float)(height - 1));
     }
-    rec.meta = draw | (backface ? 1u << 16 : 0u);
+    rec.meta = draw | (backface ? 1u << 16 : 0u);       /* class bits are or-ed in by the caller */
     if (x0 > x1 || y0 > y1) { rec.bx = RZ_BBOX_EMPTY_X; rec.by = RZ_BBOX_EMPTY_X; }
     else { rec.bx = (uint32_t)x0 | ((uint32_t)x1 << 16); rec.by = (uint32_t)y0 | ((uint32_t)y1 << 16); }
     return true;
@@ -221,94 +223,140 @@ __global__ void __launch_bounds__(256) rz_setup_kernel(PassParams P) {
     int d = find_draw(P.first_tri, P.num_draws, t);
     const DrawRec &D = P.draws[d];
     bool double_sided = (D.flags & RZ_DRAW_DOUBLE_SIDED) != 0;
+    /* what the rasteriser needs to know about the draw without loading it */
+    const uint32_t class_bits = ((D.flags & RZ_DRAW_BLEND) ? 1u << 22 : 0u) | (D.alpha_cutoff > 0 ? 1u << 23 : 0u);
     f4 c[3];
     for (int i = 0; i < 3; i++) {
         float4 q = ((const float4*)P.clip)[3u * t + i];
         c[i] = mk4(q.x, q.y, q.z, q.w);
     }
-    TriRec rec;
-    int x0, x1, y0, y1;
     uint2 empty = make_uint2(RZ_BBOX_EMPTY_X, RZ_BBOX_EMPTY_X);
-
-    if (fully_visible(c[0]) && fully_visible(c[1]) && fully_visible(c[2])) {
+    if (fully_visible(c[0]) && fully_visible(c[1]) && fully_visible(c[2])) {        /* graphics.c:290-300 */
+        TriRec rec;
+        int x0, x1, y0, y1;
         if (make_tri(c, P.width, P.height, double_sided, (uint32_t)d, rec, x0, x1, y0, y1)) {
+            rec.meta |= class_bits;
             store_tri(&P.tri[t], rec);
             P.bbox[t] = make_uint2(rec.bx, rec.by);
             if (P.counters) atomicAdd(&P.counters[1], 1ull);
         } else {
             P.bbox[t] = empty;
         }
-        return;
-    }
-
-    /* Sutherland-Hodgman against W, +X, -X, +Y, -Y, +Z, -Z (graphics.c:304-310),
-     * positions and every varying float lerped with the same ratio */
-    const int nv = D.num_varyings;
-    f4 pos[2][RZ_MAX_POLY];
-    float var[2][RZ_MAX_POLY][21];
-    for (int i = 0; i < 3; i++) {
-        pos[0][i] = c[i];
-        const float *src = P.vary + (size_t)(3u * t + i) * RZ_VARY_STRIDE;
-        for (int k = 0; k < nv; k++) var[0][i][k] = src[k];
-    }
-    int n = 3, cur = 0;
-    for (int plane = PLANE_W; plane <= PLANE_NZ && n >= 3; plane++) {
-        int dst = cur ^ 1, out = 0;
-        for (int i = 0; i < n; i++) {
-            int j = (i - 1 + n) % n;
-            f4 a = pos[cur][j], b = pos[cur][i];
-            bool a_in = plane_inside(a, plane), b_in = plane_inside(b, plane);
-            if (a_in != b_in && out < RZ_MAX_POLY) {
-                float r = plane_crossing(a, b, plane);
-                pos[dst][out] = mk4(d_mix(a.x, b.x, r), d_mix(a.y, b.y, r), d_mix(a.z, b.z, r), d_mix(a.w, b.w, r));
-                for (int k = 0; k < nv; k++) var[dst][out][k] = d_mix(var[cur][j][k], var[cur][i][k], r);
-                out++;
-            }
-            if (b_in && out < RZ_MAX_POLY) {
-                pos[dst][out] = b;
-                for (int k = 0; k < nv; k++) var[dst][out][k] = var[cur][i][k];
-                out++;
-            }
-        }
-        n = out;
-        cur = dst;
-    }
-    if (n < 3) { P.bbox[t] = empty; return; }
-
-    uint32_t block = atomicAdd(&P.control[0], 1u);
-    if (block >= (uint32_t)P.fan_capacity) {
-        atomicOr(&P.control[2], (uint32_t)RZ_ERR_FAN_OVERFLOW);
+    } else {
+        /* needs the clipper: queued for rz_clip_kernel, which fills tri/bbox */
         P.bbox[t] = empty;
-        return;
+        P.clip_list[atomicAdd(&P.control[3], 1u)] = t;
     }
-    for (int i = 0; i < n; i++) {
-        float *dstv = P.fan_vary + ((size_t)block * RZ_MAX_POLY + i) * RZ_VARY_STRIDE;
-        for (int k = 0; k < nv; k++) dstv[k] = var[cur][i][k];
-    }
-    int fan = 0;
-    int ux0 = 65535, ux1 = -1, uy0 = 65535, uy1 = -1;
-    for (int k = 0; k + 2 < n; k++) {
-        f4 fc[3] = {pos[cur][0], pos[cur][k + 1], pos[cur][k + 2]};
-        /* a culled fan triangle ends the whole fan (graphics.c:604-606) */
-        if (!make_tri(fc, P.width, P.height, double_sided, (uint32_t)d, rec, x0, x1, y0, y1)) break;
-        store_tri(&P.fan_tri[(size_t)block * RZ_MAX_FAN + k], rec);
-        if (x0 <= x1 && y0 <= y1) {
-            ux0 = x0 < ux0 ? x0 : ux0; ux1 = x1 > ux1 ? x1 : ux1;
-            uy0 = y0 < uy0 ? y0 : uy0; uy1 = y1 > uy1 ? y1 : uy1;
+}
+
+/* K2b  clipping, one WAVE per queued triangle.  Lane c carries one float
+ * "channel" of every polygon corner through the seven Sutherland-Hodgman
+ * passes: channels 0-3 are the clip-space position, 4.. the varyings.  Inside
+ * tests and crossing ratios depend on positions only, so every lane computes
+ * them identically from LDS broadcasts and then lerps its own channel with
+ * the same ratio -- exactly what clip_against_plane does per float
+ * (graphics.c:205-253).  Planes in the reference order W +X -X +Y -Y +Z -Z
+ * (:304-310); the fan and its early end on a culled triangle as in :584-607. */
+__global__ void __launch_bounds__(64) rz_clip_kernel(PassParams P) {
+    __shared__ float poly[2][RZ_MAX_POLY][32];
+    __shared__ int s_box[4][RZ_MAX_FAN];
+    const int lane = threadIdx.x;
+    const uint32_t queued = P.control[3];
+    for (uint32_t item = blockIdx.x; item < queued; item += gridDim.x) {
+        const uint32_t t = P.clip_list[item];
+        const int d = find_draw(P.first_tri, P.num_draws, t);
+        const DrawRec &D = P.draws[d];
+        const int nv = D.num_varyings;
+        const bool double_sided = (D.flags & RZ_DRAW_DOUBLE_SIDED) != 0;
+        const uint32_t class_bits = ((D.flags & RZ_DRAW_BLEND) ? 1u << 22 : 0u) | (D.alpha_cutoff > 0 ? 1u << 23 : 0u);
+        __syncthreads();
+        if (lane < 32) {
+            for (int i = 0; i < 3; i++) {
+                float v = 0;
+                if (lane < 4) v = P.clip[(size_t)(3u * t + i) * 4 + lane];
+                else if (lane < 4 + nv) v = P.vary[(size_t)(3u * t + i) * RZ_VARY_STRIDE + (lane - 4)];
+                poly[0][i][lane] = v;
+            }
         }
-        fan++;
+        __syncthreads();
+        int n = 3, cur = 0;
+        for (int plane = PLANE_W; plane <= PLANE_NZ && n >= 3; plane++) {
+            const int dst = cur ^ 1;
+            int out = 0;
+            for (int i = 0; i < n; i++) {
+                const int j = (i - 1 + n) % n;
+                f4 a = mk4(poly[cur][j][0], poly[cur][j][1], poly[cur][j][2], poly[cur][j][3]);
+                f4 b = mk4(poly[cur][i][0], poly[cur][i][1], poly[cur][i][2], poly[cur][i][3]);
+                bool a_in = plane_inside(a, plane), b_in = plane_inside(b, plane);
+                if (a_in != b_in && out < RZ_MAX_POLY) {
+                    float r = plane_crossing(a, b, plane);
+                    if (lane < 32) poly[dst][out][lane] = d_mix(poly[cur][j][lane & 31], poly[cur][i][lane & 31], r);
+                    out++;
+                }
+                if (b_in && out < RZ_MAX_POLY) {
+                    if (lane < 32) poly[dst][out][lane] = poly[cur][i][lane & 31];
+                    out++;
+                }
+            }
+            n = out;
+            cur = dst;
+            __syncthreads();
+        }
+        if (n < 3) continue;                    /* bbox stays empty */
+
+        uint32_t block = 0;
+        if (lane == 0) block = atomicAdd(&P.control[0], 1u);
+        block = (uint32_t)__builtin_amdgcn_readfirstlane((int)block);
+        if (block >= (uint32_t)P.fan_capacity) {
+            if (lane == 0) atomicOr(&P.control[2], (uint32_t)RZ_ERR_FAN_OVERFLOW);
+            continue;
+        }
+        if (lane >= 4 && lane < 4 + nv) {
+            for (int i = 0; i < n; i++)
+                P.fan_vary[((size_t)block * RZ_MAX_POLY + i) * RZ_VARY_STRIDE + (lane - 4)] = poly[cur][i][lane];
+        }
+        /* lane k builds fan triangle (0, k+1, k+2) */
+        const int k = lane;
+        TriRec rec;
+        int x0 = 1, x1 = 0, y0 = 1, y1 = 0;
+        bool alive = false;
+        if (k + 2 < n) {
+            f4 fc[3];
+            fc[0] = mk4(poly[cur][0][0], poly[cur][0][1], poly[cur][0][2], poly[cur][0][3]);
+            fc[1] = mk4(poly[cur][k + 1][0], poly[cur][k + 1][1], poly[cur][k + 1][2], poly[cur][k + 1][3]);
+            fc[2] = mk4(poly[cur][k + 2][0], poly[cur][k + 2][1], poly[cur][k + 2][2], poly[cur][k + 2][3]);
+            alive = make_tri(fc, P.width, P.height, double_sided, (uint32_t)d, rec, x0, x1, y0, y1);
+        }
+        unsigned long long culled = __ballot(k + 2 < n && !alive);
+        const int fan = culled ? (__ffsll((long long)culled) - 1) : (n - 2);
+        if (k < fan) {
+            rec.meta |= class_bits;
+            store_tri(&P.fan_tri[(size_t)block * RZ_MAX_FAN + k], rec);
+            bool any_px = x0 <= x1 && y0 <= y1;
+            s_box[0][k] = any_px ? x0 : 65535; s_box[1][k] = any_px ? x1 : -1;
+            s_box[2][k] = any_px ? y0 : 65535; s_box[3][k] = any_px ? y1 : -1;
+        }
+        __syncthreads();
+        if (lane == 0) {
+            int ux0 = 65535, ux1 = -1, uy0 = 65535, uy1 = -1;
+            for (int q = 0; q < fan; q++) {
+                ux0 = min(ux0, s_box[0][q]); ux1 = max(ux1, s_box[1][q]);
+                uy0 = min(uy0, s_box[2][q]); uy1 = max(uy1, s_box[3][q]);
+            }
+            if (P.counters) atomicAdd(&P.counters[1], (unsigned long long)fan);
+            if (fan > 0 && ux0 <= ux1 && uy0 <= uy1) {
+                TriRec head;
+                head.ax = __uint_as_float(block);
+                head.ay = head.abx = head.aby = head.acx = head.acy = head.factor = 0;
+                head.z[0] = head.z[1] = head.z[2] = head.rw[0] = head.rw[1] = head.rw[2] = 0;
+                head.meta = (uint32_t)d | (1u << 17) | ((uint32_t)fan << 18);
+                head.bx = (uint32_t)ux0 | ((uint32_t)ux1 << 16);
+                head.by = (uint32_t)uy0 | ((uint32_t)uy1 << 16);
+                store_tri(&P.tri[t], head);
+                P.bbox[t] = make_uint2(head.bx, head.by);
+            }
+        }
     }
-    if (P.counters) atomicAdd(&P.counters[1], (unsigned long long)fan);
-    if (fan == 0 || ux0 > ux1) { P.bbox[t] = empty; return; }
-    TriRec head;
-    head.ax = __uint_as_float(block);
-    head.ay = head.abx = head.aby = head.acx = head.acy = head.factor = 0;
-    head.z[0] = head.z[1] = head.z[2] = head.rw[0] = head.rw[1] = head.rw[2] = 0;
-    head.meta = (uint32_t)d | (1u << 17) | ((uint32_t)fan << 18);
-    head.bx = (uint32_t)ux0 | ((uint32_t)ux1 << 16);
-    head.by = (uint32_t)uy0 | ((uint32_t)uy1 << 16);
-    store_tri(&P.tri[t], head);
-    P.bbox[t] = make_uint2(head.bx, head.by);
 }
 
 /* ========================================================================
@@ -324,22 +372,36 @@ RZ_DEV bool box_overlaps(uint2 bb, int rx0, int ry0, int rx1, int ry1) {
     return x0 <= rx1 && x1 >= rx0 && y0 <= ry1 && y1 >= ry0;
 }
 
-__global__ void __launch_bounds__(256) rz_bin_kernel(PassParams P) {
-    __shared__ uint32_t s_wave[4];
-    __shared__ uint32_t s_base;
+#define RZ_BIN_WAVES 16
+
+/* Wave w owns the w-th contiguous slice of the triangle range, so the list is
+ * the concatenation of the waves' hits: one barrier in the whole kernel. */
+__global__ void __launch_bounds__(RZ_BIN_WAVES * 64) rz_bin_kernel(PassParams P) {
+    __shared__ uint32_t s_count[RZ_BIN_WAVES];
+    __shared__ uint32_t s_start;
     const int bin = blockIdx.x;
     const int rx0 = (bin % P.bins_x) * RZ_BIN, ry0 = (bin / P.bins_x) * RZ_BIN;
     const int rx1 = rx0 + RZ_BIN - 1, ry1 = ry0 + RZ_BIN - 1;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t T = (uint32_t)P.num_tris;
+    const uint32_t chunks = (T + 63u) / 64u;
+    const uint32_t per_wave = (chunks + RZ_BIN_WAVES - 1) / RZ_BIN_WAVES;
+    const uint32_t c0 = min((uint32_t)wave * per_wave, chunks), c1 = min(c0 + per_wave, chunks);
 
     uint32_t mine = 0;
-    for (uint32_t t = threadIdx.x; t < T; t += 256u) mine += box_overlaps(P.bbox[t], rx0, ry0, rx1, ry1) ? 1u : 0u;
-    for (int off = 32; off > 0; off >>= 1) mine += __shfl_down(mine, off);
-    if (lane == 0) s_wave[wave] = mine;
+    for (uint32_t c = c0; c < c1; c += 4u) {
+        bool hit[4];
+        for (int u = 0; u < 4; u++) {           /* four independent loads in flight */
+            uint32_t t = (c + u) * 64u + lane;
+            hit[u] = (c + u) < c1 && t < T && box_overlaps(P.bbox[t], rx0, ry0, rx1, ry1);
+        }
+        for (int u = 0; u < 4; u++) mine += (uint32_t)__popcll(__ballot(hit[u]));
+    }
+    if (lane == 0) s_count[wave] = mine;
     __syncthreads();
     if (threadIdx.x == 0) {
-        uint32_t total = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+        uint32_t total = 0;
+        for (int w = 0; w < RZ_BIN_WAVES; w++) total += s_count[w];
         uint32_t start = total ? atomicAdd(&P.control[1], total) : 0u;
         if (start + total > P.bin_capacity) {
             atomicOr(&P.control[2], (uint32_t)RZ_ERR_BIN_OVERFLOW);
@@ -347,28 +409,24 @@ __global__ void __launch_bounds__(256) rz_bin_kernel(PassParams P) {
         }
         P.bin_start[bin] = start;
         P.bin_count[bin] = total;
-        s_base = total ? start : 0xffffffffu;
+        s_start = total ? start : 0xffffffffu;
     }
     __syncthreads();
-    uint32_t cursor = s_base;
-    if (cursor == 0xffffffffu) return;
-    __syncthreads();
+    uint32_t cursor = s_start;
+    if (cursor == 0xffffffffu || mine == 0) return;
+    for (int w = 0; w < wave; w++) cursor += s_count[w];
 
-    for (uint32_t base = 0; base < T; base += 256u) {
-        uint32_t t = base + threadIdx.x;
-        bool hit = t < T && box_overlaps(P.bbox[t], rx0, ry0, rx1, ry1);
-        unsigned long long m = __ballot(hit);
-        if (lane == 0) s_wave[wave] = (uint32_t)__popcll(m);
-        __syncthreads();
-        uint32_t before = 0;
-        for (int w = 0; w < wave; w++) before += s_wave[w];
-        uint32_t chunk = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
-        if (hit) {
-            uint32_t rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-            P.bin_list[cursor + before + rank] = t;
+    for (uint32_t c = c0; c < c1; c += 4u) {
+        bool hit[4];
+        for (int u = 0; u < 4; u++) {
+            uint32_t t = (c + u) * 64u + lane;
+            hit[u] = (c + u) < c1 && t < T && box_overlaps(P.bbox[t], rx0, ry0, rx1, ry1);
         }
-        cursor += chunk;
-        __syncthreads();
+        for (int u = 0; u < 4; u++) {
+            unsigned long long m = __ballot(hit[u]);
+            if (hit[u]) P.bin_list[cursor + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (c + u) * 64u + lane;
+            cursor += (uint32_t)__popcll(m);
+        }
     }
 }
 
@@ -397,67 +455,50 @@ RZ_DEV uint32_t pack_rgb(f4 c, uint32_t keep) {                 /* float_to_ucha
     return r | (g << 8) | (b << 16) | (keep & 0xff000000u);
 }
 
+/* ---- deferred, order-exact shading ---------------------------------------
+ *
+ * The reference runs the fragment shader for every fragment that passes the
+ * depth test, in submission order (graphics.c:523-529).  Its result only
+ * matters for the fragments that are still visible at the end, so each lane
+ * (= pixel) keeps a short stack of REFERENCES to the triangles whose fragments
+ * make up its colour and shades them when the list ends:
+ *   - an opaque fragment replaces the stack (everything below it is dead);
+ *   - a blended fragment is pushed on top (it reads the colour below it);
+ *   - fragments the shader would discard (alpha cutoff) never enter: the
+ *     cutoff test is evaluated at once, it needs only alpha;
+ *   - depth is updated at once in both cases (draw_fragment writes depth for
+ *     blended fragments too, graphics.c:469).
+ * When a blended fragment meets a full stack the wave resolves all stacks and
+ * goes on.  Resolving shades level by level, all lanes of one draw together
+ * whatever triangle each lane refers to, so the shader runs on full waves and
+ * at exactly one place in the kernel.
+ */
+
+#define RZ_REF_NONE 0xffffffffu
+#define RZ_REF_FAN 0x80000000u      /* index into fan_tri instead of tri */
+#define RZ_META_BLEND(m) (((m) >> 22) & 1u)
+#define RZ_META_CUTOFF(m) (((m) >> 23) & 1u)
+
+/* (s0*q0 + s1*q1 + s2*q2) * norm per float (graphics.c:431-434), per lane */
 template <int NV>
-RZ_DEV void interpolate(const float *v0, const float *v1, const float *v2,
-                        float q0, float q1, float q2, float norm, float *out) {
-    /* (s0*q0 + s1*q1 + s2*q2) * norm per float (graphics.c:431-434) */
-    for (int k = 0; k < NV; k++) out[k] = (v0[k] * q0 + v1[k] * q1 + v2[k] * q2) * norm;
+RZ_DEV void interpolate_lane(const float *v0, const float *v1, const float *v2,
+                             float q0, float q1, float q2, float norm, float *out) {
+    constexpr int N4 = (NV + 3) / 4;            /* the 96-byte stride makes whole float4 reads safe */
+    for (int i = 0; i < N4; i++) {
+        float4 a = ((const float4*)v0)[i], b = ((const float4*)v1)[i], c = ((const float4*)v2)[i];
+        if (4 * i + 0 < NV) out[4 * i + 0] = (a.x * q0 + b.x * q1 + c.x * q2) * norm;
+        if (4 * i + 1 < NV) out[4 * i + 1] = (a.y * q0 + b.y * q1 + c.y * q2) * norm;
+        if (4 * i + 2 < NV) out[4 * i + 2] = (a.z * q0 + b.z * q1 + c.z * q2) * norm;
+        if (4 * i + 3 < NV) out[4 * i + 3] = (a.w * q0 + b.w * q1 + c.w * q2) * norm;
+    }
 }
 
-/* one triangle against this wave's 8x8 block */
-RZ_DEV void raster_one(const PassParams &P, const TriRec &r, const float *v0, const float *v1, const float *v2,
-                       int px, int py, bool valid, float &zcur, uint32_t &ccur, unsigned long long *shaded) {
-    int x0 = (int)(r.bx & 0xffffu), x1 = (int)(r.bx >> 16);
-    int y0 = (int)(r.by & 0xffffu), y1 = (int)(r.by >> 16);
-    /* barycentrics at the pixel centre (graphics.c:385-397, 514-519) */
+/* barycentric weights of the pixel centre (graphics.c:385-397, 514) */
+RZ_DEV void pixel_weights(const TriRec &r, int px, int py, float &w0, float &w1, float &w2) {
     float apx = ((float)px + 0.5f) - r.ax, apy = ((float)py + 0.5f) - r.ay;
     float s = (r.acy * apx - r.acx * apy) * r.factor;
     float t = (r.abx * apy - r.aby * apx) * r.factor;
-    float w0 = 1 - s - t, w1 = s, w2 = t;
-    bool inside = valid && px >= x0 && px <= x1 && py >= y0 && py <= y1 &&
-                  w0 > -RZ_EPS && w1 > -RZ_EPS && w2 > -RZ_EPS;
-    float depth = r.z[0] * w0 + r.z[1] * w1 + r.z[2] * w2;      /* :403-408 */
-    bool pass = inside && depth <= zcur;                        /* :523 */
-    if (!__any(pass)) return;
-
-    const DrawRec &D = P.draws[RZ_META_DRAW(r.meta)];
-    bool backface = RZ_META_BACKFACE(r.meta) != 0;
-    if (pass) {
-        float q0 = r.rw[0] * w0, q1 = r.rw[1] * w1, q2 = r.rw[2] * w2;      /* :426-429 */
-        float norm = 1 / (q0 + q1 + q2);
-        bool discard = false;
-        f4 color;
-        if (D.family == 2) {
-            float v[3];
-            interpolate<3>(v0, v1, v2, q0, q1, q2, norm, v);
-            color = fs_skybox(D, v);
-        } else if (D.family == 0) {
-            float v[11];
-            interpolate<11>(v0, v1, v2, q0, q1, q2, norm, v);
-            color = fs_blinn(D, v, backface, &discard);
-        } else {
-            float v[21];
-            interpolate<21>(v0, v1, v2, q0, q1, q2, norm, v);
-            color = fs_pbr(D, v, backface, &discard);
-        }
-        if (!discard) {                                         /* draw_fragment, :449-469 */
-            color = mk4(d_sat(color.x), d_sat(color.y), d_sat(color.z), d_sat(color.w));
-            if (D.flags & RZ_DRAW_BLEND) {
-                float dr = (float)(ccur & 0xffu) / 255.0f;
-                float dg = (float)((ccur >> 8) & 0xffu) / 255.0f;
-                float db = (float)((ccur >> 16) & 0xffu) / 255.0f;
-                color.x = color.x * color.w + dr * (1 - color.w);
-                color.y = color.y * color.w + dg * (1 - color.w);
-                color.z = color.z * color.w + db * (1 - color.w);
-            }
-            ccur = pack_rgb(color, ccur);
-            zcur = depth;
-        }
-    }
-    if (shaded) {
-        unsigned long long m = __ballot(pass);
-        if ((threadIdx.x & 63) == 0) atomicAdd(shaded, (unsigned long long)__popcll(m));
-    }
+    w0 = 1 - s - t; w1 = s; w2 = t;
 }
 
 __global__ void __launch_bounds__(256) rz_raster_kernel(PassParams P) {
@@ -481,36 +522,177 @@ __global__ void __launch_bounds__(256) rz_raster_kernel(PassParams P) {
     }
     const uint32_t *list = P.bin_list + P.bin_start[bin];
     const int bx1 = bx0 + 7, by1 = by0 + 7;
-    unsigned long long *shaded = P.counters ? P.counters + 2 : nullptr;
 
-    for (uint32_t base = 0; base < count; base += 64u) {
-        uint32_t mine = 0xffffffffu;
-        bool hit = false;
-        if (base + lane < count) {
-            mine = list[base + lane];
-            hit = box_overlaps(P.bbox[mine], bx0, by0, bx1, by1);
+    /* per-lane stack of unshaded fragments (see above) */
+    uint32_t ref0 = RZ_REF_NONE, ref1 = RZ_REF_NONE;
+    int depth_of_stack = 0;
+
+    /* iterator over this block's triangles, in list order */
+    uint32_t base = 0;
+    unsigned long long todo = 0;
+    uint32_t mine = 0;
+    uint32_t fan_block = 0;
+    int fan_k = 0, fan_n = 0;
+    bool have = false, exhausted = false;
+    TriRec r;
+    uint32_t ref = 0;
+    const float *v0 = nullptr, *v1 = nullptr, *v2 = nullptr;
+
+    while (true) {
+        /* ---- phase A: coverage + depth, until the list ends or a stack is full */
+        bool stack_full = false;
+        while (true) {
+            if (!have) {
+                if (fan_k < fan_n) {
+                    uint32_t idx = fan_block * RZ_MAX_FAN + (uint32_t)fan_k;
+                    r = load_tri(&P.fan_tri[idx]);
+                    ref = RZ_REF_FAN | idx;
+                    const float *fv = P.fan_vary + (size_t)fan_block * RZ_MAX_POLY * RZ_VARY_STRIDE;
+                    v0 = fv; v1 = fv + (fan_k + 1) * RZ_VARY_STRIDE; v2 = fv + (fan_k + 2) * RZ_VARY_STRIDE;
+                    fan_k++;
+                    have = true;
+                } else if (todo) {
+                    int j = __ffsll((long long)todo) - 1;
+                    todo &= todo - 1;
+                    uint32_t t = (uint32_t)__builtin_amdgcn_readlane((int)mine, j);
+                    r = load_tri(&P.tri[t]);
+                    if (RZ_META_CLIPPED(r.meta)) {
+                        fan_block = __float_as_uint(r.ax);
+                        fan_n = (int)RZ_META_FAN(r.meta);
+                        fan_k = 0;
+                        continue;
+                    }
+                    ref = t;
+                    v0 = P.vary + (size_t)(3u * t) * RZ_VARY_STRIDE; v1 = v0 + RZ_VARY_STRIDE; v2 = v1 + RZ_VARY_STRIDE;
+                    have = true;
+                } else {
+                    if (base >= count) { exhausted = true; break; }
+                    bool hit = false;
+                    mine = 0;
+                    if (base + lane < count) {
+                        mine = list[base + lane];
+                        hit = box_overlaps(P.bbox[mine], bx0, by0, bx1, by1);
+                    }
+                    todo = __ballot(hit);
+                    base += 64u;
+                    continue;
+                }
+            }
+            /* the triangle in r against this block */
+            int x0 = (int)(r.bx & 0xffffu), x1 = (int)(r.bx >> 16);
+            int y0 = (int)(r.by & 0xffffu), y1 = (int)(r.by >> 16);
+            float w0, w1, w2;
+            pixel_weights(r, px, py, w0, w1, w2);
+            bool inside = valid && px >= x0 && px <= x1 && py >= y0 && py <= y1 &&
+                          w0 > -RZ_EPS && w1 > -RZ_EPS && w2 > -RZ_EPS;                  /* :516-519 */
+            float depth = r.z[0] * w0 + r.z[1] * w1 + r.z[2] * w2;                        /* :403-408 */
+            bool pass = inside && depth <= zcur;                                          /* :523 */
+            if (!__any(pass)) { have = false; continue; }
+            const bool blend = RZ_META_BLEND(r.meta) != 0;
+            if (blend && __any(pass && depth_of_stack == 2)) { stack_full = true; break; }
+            if (P.counters) {       /* fragments the reference would shade: [2] all, [6] skybox, [7] blended */
+                unsigned long long n = (unsigned long long)__popcll(__ballot(pass));
+                if (lane == 0) {
+                    atomicAdd(P.counters + 2, n);
+                    if (P.draws[RZ_META_DRAW(r.meta)].family == 2) atomicAdd(P.counters + 6, n);
+                    if (blend) atomicAdd(P.counters + 7, n);
+                }
+            }
+            if (RZ_META_CUTOFF(r.meta)) {
+                /* the shaders' discard test (blinn_shader.c:104-113, 220; pbr_shader.c:116-134, 452):
+                 * alpha = base alpha * first map's alpha, from the interpolated texcoord */
+                const DrawRec &D = P.draws[RZ_META_DRAW(r.meta)];
+                const int tc = D.family == 0 ? 6 : 19;
+                float q0 = r.rw[0] * w0, q1 = r.rw[1] * w1, q2 = r.rw[2] * w2;
+                float norm = 1 / (q0 + q1 + q2);
+                float tu = (v0[tc] * q0 + v1[tc] * q1 + v2[tc] * q2) * norm;
+                float tv = (v0[tc + 1] * q0 + v1[tc + 1] * q1 + v2[tc + 1] * q2) * norm;
+                if (pass) {
+                    float a = D.base[3];
+                    if (D.maps[0].data) a *= sample_repeat(D.maps[0], tu, tv).w;
+                    if (a < D.alpha_cutoff) pass = false;
+                }
+            }
+            if (pass) {
+                zcur = depth;
+                if (blend && depth_of_stack == 1) { ref1 = ref; depth_of_stack = 2; }
+                else if (blend && depth_of_stack == 0) { ref0 = ref; depth_of_stack = 1; }
+                else if (!blend) { ref0 = ref; depth_of_stack = 1; }
+            }
+            have = false;
         }
-        unsigned long long todo = __ballot(hit);
-        while (todo) {
-            int j = __ffsll((long long)todo) - 1;
-            todo &= todo - 1;
-            uint32_t t = (uint32_t)__builtin_amdgcn_readlane((int)mine, j);
-            TriRec r = load_tri(&P.tri[t]);
-            if (!RZ_META_CLIPPED(r.meta)) {
-                const float *v = P.vary + (size_t)(3u * t) * RZ_VARY_STRIDE;
-                raster_one(P, r, v, v + RZ_VARY_STRIDE, v + 2 * RZ_VARY_STRIDE, px, py, valid, zcur, ccur, shaded);
-            } else {
-                uint32_t block = __float_as_uint(r.ax);
-                int fan = (int)RZ_META_FAN(r.meta);
-                const float *v = P.fan_vary + (size_t)block * RZ_MAX_POLY * RZ_VARY_STRIDE;
-                for (int k = 0; k < fan; k++) {
-                    TriRec f = load_tri(&P.fan_tri[(size_t)block * RZ_MAX_FAN + k]);
-                    raster_one(P, f, v, v + (k + 1) * RZ_VARY_STRIDE, v + (k + 2) * RZ_VARY_STRIDE,
-                               px, py, valid, zcur, ccur, shaded);
+
+        /* ---- phase B: resolve the stacks, bottom level first */
+        for (int level = 0; level < 2; level++) {
+            bool want = depth_of_stack > level;
+            if (!__any(want)) break;
+            uint32_t myref = level == 0 ? ref0 : ref1;
+            TriRec m;
+            const float *m0 = P.vary, *m1 = P.vary, *m2 = P.vary;
+            uint32_t mydraw = 0xffffffffu;
+            if (want) {
+                if (myref & RZ_REF_FAN) {
+                    uint32_t idx = myref & ~RZ_REF_FAN, blk = idx / RZ_MAX_FAN, k = idx % RZ_MAX_FAN;
+                    m = load_tri(&P.fan_tri[idx]);
+                    const float *fv = P.fan_vary + (size_t)blk * RZ_MAX_POLY * RZ_VARY_STRIDE;
+                    m0 = fv; m1 = fv + (k + 1) * RZ_VARY_STRIDE; m2 = fv + (k + 2) * RZ_VARY_STRIDE;
+                } else {
+                    m = load_tri(&P.tri[myref]);
+                    m0 = P.vary + (size_t)(3u * myref) * RZ_VARY_STRIDE; m1 = m0 + RZ_VARY_STRIDE; m2 = m1 + RZ_VARY_STRIDE;
+                }
+                mydraw = RZ_META_DRAW(m.meta);
+            }
+            unsigned long long rest = __ballot(want);
+            while (rest) {
+                int leader = __ffsll((long long)rest) - 1;
+                uint32_t d = (uint32_t)__builtin_amdgcn_readlane((int)mydraw, leader);
+                bool sel = want && mydraw == d;
+                rest &= ~__ballot(sel);
+                const DrawRec &D = P.draws[d];
+                if (sel) {
+                    float w0, w1, w2;
+                    pixel_weights(m, px, py, w0, w1, w2);
+                    float q0 = m.rw[0] * w0, q1 = m.rw[1] * w1, q2 = m.rw[2] * w2;      /* :426-429 */
+                    float norm = 1 / (q0 + q1 + q2);
+                    bool backface = RZ_META_BACKFACE(m.meta) != 0;
+                    bool discard = false;
+                    f4 color;
+                    if (D.family == 2) {
+                        float v[4];
+                        interpolate_lane<3>(m0, m1, m2, q0, q1, q2, norm, v);
+                        color = fs_skybox(D, v);
+                    } else if (D.family == 0) {
+                        float v[12];
+                        interpolate_lane<11>(m0, m1, m2, q0, q1, q2, norm, v);
+                        color = fs_blinn(D, v, backface, &discard);
+                    } else {
+                        float v[24];
+                        interpolate_lane<21>(m0, m1, m2, q0, q1, q2, norm, v);
+                        color = fs_pbr(D, v, backface, &discard);
+                    }
+                    /* draw_fragment (graphics.c:452-468); discard was settled in phase A */
+                    color = mk4(d_sat(color.x), d_sat(color.y), d_sat(color.z), d_sat(color.w));
+                    if (D.flags & RZ_DRAW_BLEND) {
+                        float dr = (float)(ccur & 0xffu) / 255.0f;
+                        float dg = (float)((ccur >> 8) & 0xffu) / 255.0f;
+                        float db = (float)((ccur >> 16) & 0xffu) / 255.0f;
+                        color.x = color.x * color.w + dr * (1 - color.w);
+                        color.y = color.y * color.w + dg * (1 - color.w);
+                        color.z = color.z * color.w + db * (1 - color.w);
+                    }
+                    ccur = pack_rgb(color, ccur);
+                }
+                if (P.counters) {   /* [8] fragments actually shaded on the device */
+                    unsigned long long n = (unsigned long long)__popcll(__ballot(sel));
+                    if (lane == 0) atomicAdd(P.counters + 8, n);
                 }
             }
         }
+        ref0 = ref1 = RZ_REF_NONE;
+        depth_of_stack = 0;
+        if (exhausted || !stack_full) break;
     }
+
     if (valid) {
         P.depth[pixel] = zcur;
         P.color[pixel] = ccur;

@@ -100,7 +100,8 @@ struct TriRec {
     float factor;                   /* 1 / (ab x ac) */
     float z[3];                     /* screen depth per corner */
     float rw[3];                    /* 1 / clip.w per corner */
-    uint32_t meta;                  /* draw | backface << 16 | clipped << 17 | fan_count << 18 */
+    uint32_t meta;                  /* draw | backface << 16 | clipped << 17 | fan_count << 18
+                                     * | blend << 22 | alpha-cutoff << 23 */
     uint32_t bx, by;                /* own bounding box: min | max << 16 */
 };
 
@@ -129,13 +130,14 @@ struct PassParams {
     TriRec *fan_tri;                /* fan_capacity * RZ_MAX_FAN */
     float *fan_vary;                /* fan_capacity * RZ_MAX_POLY * RZ_VARY_STRIDE */
     int32_t fan_capacity;
+    uint32_t *clip_list;            /* triangles queued for the clipper (count in control[3]) */
     /* binning */
     int32_t bins_x, bins_y;
     uint32_t *bin_start, *bin_count;
     uint32_t *bin_list;
     uint32_t bin_capacity;
     /* scalars written by the device: [0] fan blocks used, [1] bin entries
-     * used, [2] error bits, [3..] counters */
+     * used, [2] error bits, [3] triangles queued for clipping */
     uint32_t *control;
     unsigned long long *counters;   /* nullptr unless counting is enabled */
 };
