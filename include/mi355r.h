@@ -259,10 +259,11 @@ void mi355r_reset_counters(void);
 void mi355r_enable_counters(int on);
 
 /* Device time per kernel, from HIP events recorded on the pipeline's stream
- * around each launch while enabled: out_ms[0..3] = summed milliseconds of the
- * vertex, setup, bin and raster kernels; returns the number of passes. */
+ * around each launch while enabled: out_ms[0..4] = summed milliseconds of the
+ * vertex, setup+clip, bin, raster and per-family shade kernels; returns the
+ * number of passes. */
 void mi355r_enable_timing(int on);
-unsigned long long mi355r_get_timing(double out_ms[4], int reset);
+unsigned long long mi355r_get_timing(double out_ms[5], int reset);
 
 #ifdef __cplusplus
 }

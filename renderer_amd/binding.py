@@ -143,8 +143,8 @@ class Pipeline:
         return out
 
     def kernel_times(self, reset=True):
-        """(passes, [vertex, setup, bin, raster] summed ms) since timing was enabled/reset."""
-        ms = (C.c_double * 4)()
+        """(passes, [vertex, setup, bin, raster, shade] summed ms) since timing was enabled/reset."""
+        ms = (C.c_double * 5)()
         n = self.lib.mi355r_get_timing(ms, 1 if reset else 0)
         return int(n), list(ms)
 

@@ -106,7 +106,8 @@ struct Context {
     DevBuf<float> clip, vary, fan_vary;
     DevBuf<TriRec> tri, fan_tri;
     DevBuf<uint2> bbox;
-    DevBuf<uint32_t> bin_start, bin_count, bin_list, clip_list;
+    DevBuf<uint32_t> bin_start, bin_count, clip_list, ref;
+    DevBuf<uint4> bin_list;
     /* upload ring: pinned host memory mirrored 1:1 in device memory */
     char *ring_host = nullptr, *ring_dev = nullptr;
     size_t ring_size = 0, ring_at = 0;
@@ -124,8 +125,8 @@ struct Context {
     std::vector<Registered> families;
     /* measurement */
     bool timing = false;
-    std::vector<hipEvent_t> timing_events;  /* 5 per pass: before vertex, after vertex/setup/bin/raster */
-    double kernel_ms[4] = {0, 0, 0, 0};
+    std::vector<hipEvent_t> timing_events;  /* 6 per pass: before vertex, after vertex/setup/bin/raster/shade */
+    double kernel_ms[5] = {0, 0, 0, 0, 0};
     unsigned long long kernel_launches = 0;
     bool counting = false;
     unsigned long long *d_counters = nullptr;
@@ -857,6 +858,14 @@ static void launch_pass(const PassPlan &pl, char *db, uint32_t *control) {
     reserve(g.bin_start, bins);
     reserve(g.bin_count, bins);
     reserve(g.bin_list, list_cap);
+    bool has_blend = false;
+    int families = 0;
+    for (size_t i = pl.first; i < pl.last; i++) {
+        has_blend |= (g.pending[i].rec.flags & RZ_DRAW_BLEND) != 0;
+        families |= 1 << g.pending[i].rec.family;
+    }
+    if (getenv("MI355R_MONOLITHIC")) has_blend = true;
+    if (!has_blend) reserve(g.ref, (size_t)W * H);
 
     PassParams P;
     memset(&P, 0, sizeof P);
@@ -886,8 +895,10 @@ static void launch_pass(const PassPlan &pl, char *db, uint32_t *control) {
     P.bin_count = g.bin_count.ptr;
     P.bin_list = g.bin_list.ptr;
     P.bin_capacity = (uint32_t)list_cap;
+    P.ref = g.ref.ptr;
     P.control = control;
     P.counters = g.counting ? g.d_counters : nullptr;
+    { const char *dbg = getenv("MI355R_DEBUG_SKIP"); P.debug_skip = dbg ? atoi(dbg) : 0; }
 
     const unsigned vblocks = (unsigned)((T * 3 + 255) / 256), tblocks = (unsigned)((T + 255) / 256);
     const int tiles_x = (W + RZ_TILE - 1) / RZ_TILE, tiles_y = (H + RZ_TILE - 1) / RZ_TILE;
@@ -906,7 +917,23 @@ static void launch_pass(const PassPlan &pl, char *db, uint32_t *control) {
     stamp();
     rz_bin_kernel<<<dim3((unsigned)bins), dim3(RZ_BIN_WAVES * 64), 0, g.stream>>>(P);
     stamp();
-    rz_raster_kernel<<<dim3((unsigned)(tiles_x * tiles_y)), dim3(256), 0, g.stream>>>(P);
+    const dim3 tiles((unsigned)(tiles_x * tiles_y));
+    if (has_blend) {
+        /* blended fragments read the colour below them: visibility and shading stay in one kernel */
+        rz_raster_kernel<false><<<tiles, dim3(256), 0, g.stream>>>(
+            P, P.tri, P.fan_tri, P.bin_list, P.vary, P.fan_vary, P.draws, P.bin_start, P.bin_count);
+        stamp();
+    } else {
+        rz_raster_kernel<true><<<tiles, dim3(256), 0, g.stream>>>(
+            P, P.tri, P.fan_tri, P.bin_list, P.vary, P.fan_vary, P.draws, P.bin_start, P.bin_count);
+        stamp();
+        if (families & (1 << RZ_FAMILY_SKYBOX))
+            rz_shade_kernel<2><<<tiles, dim3(256), 0, g.stream>>>(P, P.tri, P.fan_tri, P.vary, P.fan_vary, P.draws, P.ref);
+        if (families & (1 << RZ_FAMILY_BLINN))
+            rz_shade_kernel<0><<<tiles, dim3(256), 0, g.stream>>>(P, P.tri, P.fan_tri, P.vary, P.fan_vary, P.draws, P.ref);
+        if (families & (1 << RZ_FAMILY_PBR))
+            rz_shade_kernel<1><<<tiles, dim3(256), 0, g.stream>>>(P, P.tri, P.fan_tri, P.vary, P.fan_vary, P.draws, P.ref);
+    }
     stamp();
     HIP_OK(hipGetLastError());
 
@@ -979,7 +1006,9 @@ extern "C" void mi355r_get_counters(unsigned long long out[12]) {
 
 /* Per-kernel device time, measured with HIP events on the pipeline's own
  * stream around every launch while enabled.  out_ms: summed milliseconds of
- * the vertex, setup, bin and raster kernels; returns the number of passes. */
+ * the vertex, setup+clip, bin, raster and shade kernels (shade is zero for
+ * passes whose shading runs inside the raster kernel); returns the number of
+ * passes. */
 extern "C" void mi355r_enable_timing(int on) {
     ensure_ready();
     graphics_flush();
@@ -987,12 +1016,12 @@ extern "C" void mi355r_enable_timing(int on) {
     g.timing = on != 0;
 }
 
-extern "C" unsigned long long mi355r_get_timing(double out_ms[4], int reset) {
+extern "C" unsigned long long mi355r_get_timing(double out_ms[5], int reset) {
     ensure_ready();
     graphics_flush();
     sync_stream();
-    for (size_t i = 0; i + 4 < g.timing_events.size(); i += 5) {
-        for (int k = 0; k < 4; k++) {
+    for (size_t i = 0; i + 5 < g.timing_events.size(); i += 6) {
+        for (int k = 0; k < 5; k++) {
             float ms = 0;
             HIP_OK(hipEventElapsedTime(&ms, g.timing_events[i + k], g.timing_events[i + k + 1]));
             g.kernel_ms[k] += ms;
@@ -1001,9 +1030,9 @@ extern "C" unsigned long long mi355r_get_timing(double out_ms[4], int reset) {
     }
     for (hipEvent_t e : g.timing_events) HIP_OK(hipEventDestroy(e));
     g.timing_events.clear();
-    for (int k = 0; k < 4; k++) out_ms[k] = g.kernel_ms[k];
+    for (int k = 0; k < 5; k++) out_ms[k] = g.kernel_ms[k];
     unsigned long long n = g.kernel_launches;
-    if (reset) { for (int k = 0; k < 4; k++) g.kernel_ms[k] = 0; g.kernel_launches = 0; }
+    if (reset) { for (int k = 0; k < 5; k++) g.kernel_ms[k] = 0; g.kernel_launches = 0; }
     return n;
 }
 

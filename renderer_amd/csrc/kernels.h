@@ -224,7 +224,8 @@ __global__ void __launch_bounds__(256) rz_setup_kernel(PassParams P) {
     const DrawRec &D = P.draws[d];
     bool double_sided = (D.flags & RZ_DRAW_DOUBLE_SIDED) != 0;
     /* what the rasteriser needs to know about the draw without loading it */
-    const uint32_t class_bits = ((D.flags & RZ_DRAW_BLEND) ? 1u << 22 : 0u) | (D.alpha_cutoff > 0 ? 1u << 23 : 0u);
+    const uint32_t class_bits = ((D.flags & RZ_DRAW_BLEND) ? 1u << 22 : 0u) | (D.alpha_cutoff > 0 ? 1u << 23 : 0u) |
+                                ((uint32_t)D.family << 24);
     f4 c[3];
     for (int i = 0; i < 3; i++) {
         float4 q = ((const float4*)P.clip)[3u * t + i];
@@ -268,7 +269,8 @@ __global__ void __launch_bounds__(64) rz_clip_kernel(PassParams P) {
         const DrawRec &D = P.draws[d];
         const int nv = D.num_varyings;
         const bool double_sided = (D.flags & RZ_DRAW_DOUBLE_SIDED) != 0;
-        const uint32_t class_bits = ((D.flags & RZ_DRAW_BLEND) ? 1u << 22 : 0u) | (D.alpha_cutoff > 0 ? 1u << 23 : 0u);
+        const uint32_t class_bits = ((D.flags & RZ_DRAW_BLEND) ? 1u << 22 : 0u) | (D.alpha_cutoff > 0 ? 1u << 23 : 0u) |
+                                    ((uint32_t)D.family << 24);
         __syncthreads();
         if (lane < 32) {
             for (int i = 0; i < 3; i++) {
@@ -424,7 +426,11 @@ __global__ void __launch_bounds__(RZ_BIN_WAVES * 64) rz_bin_kernel(PassParams P)
         }
         for (int u = 0; u < 4; u++) {
             unsigned long long m = __ballot(hit[u]);
-            if (hit[u]) P.bin_list[cursor + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (c + u) * 64u + lane;
+            if (hit[u]) {
+                uint32_t t = (c + u) * 64u + lane;
+                uint2 bb = P.bbox[t];           /* cached from the test above */
+                P.bin_list[cursor + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = make_uint4(t, bb.x, bb.y, 0u);
+            }
             cursor += (uint32_t)__popcll(m);
         }
     }
@@ -478,6 +484,7 @@ RZ_DEV uint32_t pack_rgb(f4 c, uint32_t keep) {                 /* float_to_ucha
 #define RZ_REF_FAN 0x80000000u      /* index into fan_tri instead of tri */
 #define RZ_META_BLEND(m) (((m) >> 22) & 1u)
 #define RZ_META_CUTOFF(m) (((m) >> 23) & 1u)
+#define RZ_META_FAMILY(m) (((m) >> 24) & 3u)
 
 /* (s0*q0 + s1*q1 + s2*q2) * norm per float (graphics.c:431-434), per lane */
 template <int NV>
@@ -501,7 +508,97 @@ RZ_DEV void pixel_weights(const TriRec &r, int px, int py, float &w0, float &w1,
     w0 = 1 - s - t; w1 = s; w2 = t;
 }
 
-__global__ void __launch_bounds__(256) rz_raster_kernel(PassParams P) {
+/* Shades the fragments referenced by `want` lanes and merges them into ccur.
+ * Each lane carries its own triangle record and varying pointers; lanes of one
+ * draw are shaded together under that draw's (wave-uniform) record.
+ * FAMILY >= 0 compiles only that family's shader (per-family kernels),
+ * FAMILY < 0 all three. */
+template <int FAMILY>
+RZ_DEV void shade_lanes(const PassParams &P, const DrawRec *__restrict__ draw_table, bool want,
+                        const TriRec &m, const float *m0, const float *m1, const float *m2,
+                        int px, int py, uint32_t &ccur) {
+    const int lane = threadIdx.x & 63;
+    uint32_t mydraw = want ? RZ_META_DRAW(m.meta) : 0xffffffffu;
+    unsigned long long rest = __ballot(want);
+    while (rest) {
+        int leader = __ffsll((long long)rest) - 1;
+        uint32_t d = (uint32_t)__builtin_amdgcn_readlane((int)mydraw, leader);
+        bool sel = want && mydraw == d;
+        rest &= ~__ballot(sel);
+        const DrawRec &D = draw_table[d];
+        if (sel) {
+            float w0, w1, w2;
+            pixel_weights(m, px, py, w0, w1, w2);
+            float q0 = m.rw[0] * w0, q1 = m.rw[1] * w1, q2 = m.rw[2] * w2;          /* graphics.c:426-429 */
+            float norm = 1 / (q0 + q1 + q2);
+            bool backface = RZ_META_BACKFACE(m.meta) != 0;
+            bool discard = false;
+            f4 color = mk4(0, 0, 0, 0);
+            if ((FAMILY < 0 || FAMILY == 2) && D.family == 2) {
+                float v[4];
+                interpolate_lane<3>(m0, m1, m2, q0, q1, q2, norm, v);
+                color = fs_skybox(D, v);
+            } else if ((FAMILY < 0 || FAMILY == 0) && D.family == 0) {
+                float v[12];
+                interpolate_lane<11>(m0, m1, m2, q0, q1, q2, norm, v);
+                color = fs_blinn(D, v, backface, &discard);
+            } else if ((FAMILY < 0 || FAMILY == 1) && D.family == 1) {
+                float v[24];
+                interpolate_lane<21>(m0, m1, m2, q0, q1, q2, norm, v);
+                color = fs_pbr(D, v, backface, &discard);
+            }
+            /* draw_fragment (graphics.c:452-468); a discard was settled during rasterisation */
+            color = mk4(d_sat(color.x), d_sat(color.y), d_sat(color.z), d_sat(color.w));
+            if (D.flags & RZ_DRAW_BLEND) {
+                float dr = (float)(ccur & 0xffu) / 255.0f;
+                float dg = (float)((ccur >> 8) & 0xffu) / 255.0f;
+                float db = (float)((ccur >> 16) & 0xffu) / 255.0f;
+                color.x = color.x * color.w + dr * (1 - color.w);
+                color.y = color.y * color.w + dg * (1 - color.w);
+                color.z = color.z * color.w + db * (1 - color.w);
+            }
+            ccur = pack_rgb(color, ccur);
+        }
+        if (P.counters) {       /* [8] fragments actually shaded on the device */
+            unsigned long long n = (unsigned long long)__popcll(__ballot(sel));
+            if (lane == 0) atomicAdd(P.counters + 8, n);
+        }
+    }
+}
+
+/* loads the record and varying pointers a fragment reference stands for */
+RZ_DEV void fetch_ref(uint32_t ref, const TriRec *__restrict__ tri_table, const TriRec *__restrict__ fan_table,
+                      const float *__restrict__ vary_table, const float *__restrict__ fan_vary_table,
+                      TriRec &m, const float *&m0, const float *&m1, const float *&m2) {
+    if (ref & RZ_REF_FAN) {
+        uint32_t idx = ref & ~RZ_REF_FAN, blk = idx / RZ_MAX_FAN, k = idx % RZ_MAX_FAN;
+        m = load_tri(&fan_table[idx]);
+        const float *fv = fan_vary_table + (size_t)blk * RZ_MAX_POLY * RZ_VARY_STRIDE;
+        m0 = fv; m1 = fv + (k + 1) * RZ_VARY_STRIDE; m2 = fv + (k + 2) * RZ_VARY_STRIDE;
+    } else {
+        m = load_tri(&tri_table[ref]);
+        m0 = vary_table + (size_t)(3u * ref) * RZ_VARY_STRIDE; m1 = m0 + RZ_VARY_STRIDE; m2 = m1 + RZ_VARY_STRIDE;
+    }
+}
+
+#define RZ_BCAST_F(v, j) __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), (j)))
+
+/* Rasteriser.  SPLIT = true: the pass has no blended draw, so one reference per
+ * pixel is enough; the kernel resolves visibility only and leaves depth plus the
+ * reference of the visible fragment for the per-family shade kernels.
+ * SPLIT = false: general form with the two-level stack, shading in-kernel.
+ *
+ * The read-only tables come in as separate const __restrict__ arguments so
+ * that wave-uniform reads of them are issued as scalar loads.  Per 64 list
+ * entries the candidates' records are fetched lane-parallel (one memory round
+ * trip for all of them) and then broadcast one at a time in list order. */
+template <bool SPLIT>
+__global__ void __launch_bounds__(256) rz_raster_kernel(PassParams P,
+        const TriRec *__restrict__ tri_table, const TriRec *__restrict__ fan_table,
+        const uint4 *__restrict__ list_table,
+        const float *__restrict__ vary_table, const float *__restrict__ fan_vary_table,
+        const DrawRec *__restrict__ draw_table,
+        const uint32_t *__restrict__ bin_start_table, const uint32_t *__restrict__ bin_count_table) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int tiles_x = (P.width + RZ_TILE - 1) / RZ_TILE;
     const int tile_x = blockIdx.x % tiles_x, tile_y = blockIdx.x / tiles_x;
@@ -511,16 +608,19 @@ __global__ void __launch_bounds__(256) rz_raster_kernel(PassParams P) {
     if (bx0 >= P.width || by0 >= P.height) return;             /* whole wave off-screen */
     const size_t pixel = (size_t)py * P.width + px;
     const int bin = (by0 / RZ_BIN) * P.bins_x + bx0 / RZ_BIN;
-    const uint32_t count = P.bin_count[bin];
-    if (count == 0 && !P.clear_color_pending && !P.clear_depth_pending) return;
+    const uint32_t count = bin_count_table[bin];
+    if (count == 0 && !P.clear_color_pending && !P.clear_depth_pending) {
+        if (SPLIT && valid) P.ref[pixel] = RZ_REF_NONE;
+        return;
+    }
 
     float zcur = 1.0f;
     uint32_t ccur = 0;
     if (valid) {
         zcur = P.clear_depth_pending ? P.clear_depth : P.depth[pixel];
-        ccur = P.clear_color_pending ? P.clear_color : P.color[pixel];
+        if (!SPLIT || P.clear_color_pending) ccur = P.clear_color_pending ? P.clear_color : P.color[pixel];
     }
-    const uint32_t *list = P.bin_list + P.bin_start[bin];
+    const uint4 *list = list_table + bin_start_table[bin];
     const int bx1 = bx0 + 7, by1 = by0 + 7;
 
     /* per-lane stack of unshaded fragments (see above) */
@@ -531,6 +631,7 @@ __global__ void __launch_bounds__(256) rz_raster_kernel(PassParams P) {
     uint32_t base = 0;
     unsigned long long todo = 0;
     uint32_t mine = 0;
+    float4 c0 = make_float4(0, 0, 0, 0), c1 = c0, c2 = c0, c3 = c0;    /* this lane's candidate record */
     uint32_t fan_block = 0;
     int fan_k = 0, fan_n = 0;
     bool have = false, exhausted = false;
@@ -545,9 +646,9 @@ __global__ void __launch_bounds__(256) rz_raster_kernel(PassParams P) {
             if (!have) {
                 if (fan_k < fan_n) {
                     uint32_t idx = fan_block * RZ_MAX_FAN + (uint32_t)fan_k;
-                    r = load_tri(&P.fan_tri[idx]);
+                    r = load_tri(&fan_table[idx]);
                     ref = RZ_REF_FAN | idx;
-                    const float *fv = P.fan_vary + (size_t)fan_block * RZ_MAX_POLY * RZ_VARY_STRIDE;
+                    const float *fv = fan_vary_table + (size_t)fan_block * RZ_MAX_POLY * RZ_VARY_STRIDE;
                     v0 = fv; v1 = fv + (fan_k + 1) * RZ_VARY_STRIDE; v2 = fv + (fan_k + 2) * RZ_VARY_STRIDE;
                     fan_k++;
                     have = true;
@@ -555,7 +656,13 @@ __global__ void __launch_bounds__(256) rz_raster_kernel(PassParams P) {
                     int j = __ffsll((long long)todo) - 1;
                     todo &= todo - 1;
                     uint32_t t = (uint32_t)__builtin_amdgcn_readlane((int)mine, j);
-                    r = load_tri(&P.tri[t]);
+                    r.ax = RZ_BCAST_F(c0.x, j); r.ay = RZ_BCAST_F(c0.y, j); r.abx = RZ_BCAST_F(c0.z, j); r.aby = RZ_BCAST_F(c0.w, j);
+                    r.acx = RZ_BCAST_F(c1.x, j); r.acy = RZ_BCAST_F(c1.y, j); r.factor = RZ_BCAST_F(c1.z, j); r.z[0] = RZ_BCAST_F(c1.w, j);
+                    r.z[1] = RZ_BCAST_F(c2.x, j); r.z[2] = RZ_BCAST_F(c2.y, j); r.rw[0] = RZ_BCAST_F(c2.z, j); r.rw[1] = RZ_BCAST_F(c2.w, j);
+                    r.rw[2] = RZ_BCAST_F(c3.x, j);
+                    r.meta = (uint32_t)__builtin_amdgcn_readlane(__float_as_int(c3.y), j);
+                    r.bx = (uint32_t)__builtin_amdgcn_readlane(__float_as_int(c3.z), j);
+                    r.by = (uint32_t)__builtin_amdgcn_readlane(__float_as_int(c3.w), j);
                     if (RZ_META_CLIPPED(r.meta)) {
                         fan_block = __float_as_uint(r.ax);
                         fan_n = (int)RZ_META_FAN(r.meta);
@@ -563,21 +670,27 @@ __global__ void __launch_bounds__(256) rz_raster_kernel(PassParams P) {
                         continue;
                     }
                     ref = t;
-                    v0 = P.vary + (size_t)(3u * t) * RZ_VARY_STRIDE; v1 = v0 + RZ_VARY_STRIDE; v2 = v1 + RZ_VARY_STRIDE;
+                    v0 = vary_table + (size_t)(3u * t) * RZ_VARY_STRIDE; v1 = v0 + RZ_VARY_STRIDE; v2 = v1 + RZ_VARY_STRIDE;
                     have = true;
                 } else {
                     if (base >= count) { exhausted = true; break; }
                     bool hit = false;
                     mine = 0;
                     if (base + lane < count) {
-                        mine = list[base + lane];
-                        hit = box_overlaps(P.bbox[mine], bx0, by0, bx1, by1);
+                        uint4 e = list[base + lane];            /* triangle index and its bounding box */
+                        mine = e.x;
+                        hit = box_overlaps(make_uint2(e.y, e.z), bx0, by0, bx1, by1);
+                    }
+                    if (hit) {
+                        const float4 *src = (const float4*)&tri_table[mine];
+                        c0 = src[0]; c1 = src[1]; c2 = src[2]; c3 = src[3];
                     }
                     todo = __ballot(hit);
                     base += 64u;
                     continue;
                 }
             }
+            if (P.debug_skip >= 2) { have = false; continue; }
             /* the triangle in r against this block */
             int x0 = (int)(r.bx & 0xffffu), x1 = (int)(r.bx >> 16);
             int y0 = (int)(r.by & 0xffffu), y1 = (int)(r.by >> 16);
@@ -588,20 +701,20 @@ __global__ void __launch_bounds__(256) rz_raster_kernel(PassParams P) {
             float depth = r.z[0] * w0 + r.z[1] * w1 + r.z[2] * w2;                        /* :403-408 */
             bool pass = inside && depth <= zcur;                                          /* :523 */
             if (!__any(pass)) { have = false; continue; }
-            const bool blend = RZ_META_BLEND(r.meta) != 0;
+            const bool blend = !SPLIT && RZ_META_BLEND(r.meta) != 0;
             if (blend && __any(pass && depth_of_stack == 2)) { stack_full = true; break; }
             if (P.counters) {       /* fragments the reference would shade: [2] all, [6] skybox, [7] blended */
                 unsigned long long n = (unsigned long long)__popcll(__ballot(pass));
                 if (lane == 0) {
                     atomicAdd(P.counters + 2, n);
-                    if (P.draws[RZ_META_DRAW(r.meta)].family == 2) atomicAdd(P.counters + 6, n);
+                    if (RZ_META_FAMILY(r.meta) == 2) atomicAdd(P.counters + 6, n);
                     if (blend) atomicAdd(P.counters + 7, n);
                 }
             }
             if (RZ_META_CUTOFF(r.meta)) {
                 /* the shaders' discard test (blinn_shader.c:104-113, 220; pbr_shader.c:116-134, 452):
                  * alpha = base alpha * first map's alpha, from the interpolated texcoord */
-                const DrawRec &D = P.draws[RZ_META_DRAW(r.meta)];
+                const DrawRec &D = draw_table[RZ_META_DRAW(r.meta)];
                 const int tc = D.family == 0 ? 6 : 19;
                 float q0 = r.rw[0] * w0, q1 = r.rw[1] * w1, q2 = r.rw[2] * w2;
                 float norm = 1 / (q0 + q1 + q2);
@@ -621,72 +734,16 @@ __global__ void __launch_bounds__(256) rz_raster_kernel(PassParams P) {
             }
             have = false;
         }
+        if (SPLIT) break;
 
         /* ---- phase B: resolve the stacks, bottom level first */
         for (int level = 0; level < 2; level++) {
-            bool want = depth_of_stack > level;
+            bool want = depth_of_stack > level && P.debug_skip == 0;
             if (!__any(want)) break;
-            uint32_t myref = level == 0 ? ref0 : ref1;
             TriRec m;
-            const float *m0 = P.vary, *m1 = P.vary, *m2 = P.vary;
-            uint32_t mydraw = 0xffffffffu;
-            if (want) {
-                if (myref & RZ_REF_FAN) {
-                    uint32_t idx = myref & ~RZ_REF_FAN, blk = idx / RZ_MAX_FAN, k = idx % RZ_MAX_FAN;
-                    m = load_tri(&P.fan_tri[idx]);
-                    const float *fv = P.fan_vary + (size_t)blk * RZ_MAX_POLY * RZ_VARY_STRIDE;
-                    m0 = fv; m1 = fv + (k + 1) * RZ_VARY_STRIDE; m2 = fv + (k + 2) * RZ_VARY_STRIDE;
-                } else {
-                    m = load_tri(&P.tri[myref]);
-                    m0 = P.vary + (size_t)(3u * myref) * RZ_VARY_STRIDE; m1 = m0 + RZ_VARY_STRIDE; m2 = m1 + RZ_VARY_STRIDE;
-                }
-                mydraw = RZ_META_DRAW(m.meta);
-            }
-            unsigned long long rest = __ballot(want);
-            while (rest) {
-                int leader = __ffsll((long long)rest) - 1;
-                uint32_t d = (uint32_t)__builtin_amdgcn_readlane((int)mydraw, leader);
-                bool sel = want && mydraw == d;
-                rest &= ~__ballot(sel);
-                const DrawRec &D = P.draws[d];
-                if (sel) {
-                    float w0, w1, w2;
-                    pixel_weights(m, px, py, w0, w1, w2);
-                    float q0 = m.rw[0] * w0, q1 = m.rw[1] * w1, q2 = m.rw[2] * w2;      /* :426-429 */
-                    float norm = 1 / (q0 + q1 + q2);
-                    bool backface = RZ_META_BACKFACE(m.meta) != 0;
-                    bool discard = false;
-                    f4 color;
-                    if (D.family == 2) {
-                        float v[4];
-                        interpolate_lane<3>(m0, m1, m2, q0, q1, q2, norm, v);
-                        color = fs_skybox(D, v);
-                    } else if (D.family == 0) {
-                        float v[12];
-                        interpolate_lane<11>(m0, m1, m2, q0, q1, q2, norm, v);
-                        color = fs_blinn(D, v, backface, &discard);
-                    } else {
-                        float v[24];
-                        interpolate_lane<21>(m0, m1, m2, q0, q1, q2, norm, v);
-                        color = fs_pbr(D, v, backface, &discard);
-                    }
-                    /* draw_fragment (graphics.c:452-468); discard was settled in phase A */
-                    color = mk4(d_sat(color.x), d_sat(color.y), d_sat(color.z), d_sat(color.w));
-                    if (D.flags & RZ_DRAW_BLEND) {
-                        float dr = (float)(ccur & 0xffu) / 255.0f;
-                        float dg = (float)((ccur >> 8) & 0xffu) / 255.0f;
-                        float db = (float)((ccur >> 16) & 0xffu) / 255.0f;
-                        color.x = color.x * color.w + dr * (1 - color.w);
-                        color.y = color.y * color.w + dg * (1 - color.w);
-                        color.z = color.z * color.w + db * (1 - color.w);
-                    }
-                    ccur = pack_rgb(color, ccur);
-                }
-                if (P.counters) {   /* [8] fragments actually shaded on the device */
-                    unsigned long long n = (unsigned long long)__popcll(__ballot(sel));
-                    if (lane == 0) atomicAdd(P.counters + 8, n);
-                }
-            }
+            const float *m0 = vary_table, *m1 = vary_table, *m2 = vary_table;
+            if (want) fetch_ref(level == 0 ? ref0 : ref1, tri_table, fan_table, vary_table, fan_vary_table, m, m0, m1, m2);
+            shade_lanes<-1>(P, draw_table, want, m, m0, m1, m2, px, py, ccur);
         }
         ref0 = ref1 = RZ_REF_NONE;
         depth_of_stack = 0;
@@ -695,8 +752,43 @@ __global__ void __launch_bounds__(256) rz_raster_kernel(PassParams P) {
 
     if (valid) {
         P.depth[pixel] = zcur;
-        P.color[pixel] = ccur;
+        if (SPLIT) {
+            P.ref[pixel] = depth_of_stack ? ref0 : RZ_REF_NONE;
+            if (P.clear_color_pending) P.color[pixel] = ccur;
+        } else {
+            P.color[pixel] = ccur;
+        }
     }
+}
+
+/* K5  per-family fragment kernels for passes rasterised with SPLIT = true:
+ * every lane shades the one fragment its pixel refers to. */
+template <int FAMILY>
+__global__ void __launch_bounds__(256) rz_shade_kernel(PassParams P,
+        const TriRec *__restrict__ tri_table, const TriRec *__restrict__ fan_table,
+        const float *__restrict__ vary_table, const float *__restrict__ fan_vary_table,
+        const DrawRec *__restrict__ draw_table, const uint32_t *__restrict__ ref_table) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int tiles_x = (P.width + RZ_TILE - 1) / RZ_TILE;
+    const int tile_x = blockIdx.x % tiles_x, tile_y = blockIdx.x / tiles_x;
+    const int bx0 = tile_x * RZ_TILE + (wave & 1) * 8, by0 = tile_y * RZ_TILE + (wave >> 1) * 8;
+    const int px = bx0 + (lane & 7), py = by0 + (lane >> 3);
+    const bool valid = px < P.width && py < P.height;
+    if (bx0 >= P.width || by0 >= P.height) return;
+    const size_t pixel = (size_t)py * P.width + px;
+    uint32_t myref = valid ? ref_table[pixel] : RZ_REF_NONE;
+    bool want = myref != RZ_REF_NONE && P.debug_skip == 0;
+    if (!__any(want)) return;
+    TriRec m;
+    const float *m0 = vary_table, *m1 = vary_table, *m2 = vary_table;
+    if (want) {
+        fetch_ref(myref, tri_table, fan_table, vary_table, fan_vary_table, m, m0, m1, m2);
+        want = RZ_META_FAMILY(m.meta) == (uint32_t)FAMILY;
+    }
+    if (!__any(want)) return;
+    uint32_t ccur = want ? P.color[pixel] : 0u;
+    shade_lanes<FAMILY>(P, draw_table, want, m, m0, m1, m2, px, py, ccur);
+    if (want) P.color[pixel] = ccur;
 }
 
 /* ========================================================================

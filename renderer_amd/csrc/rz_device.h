@@ -101,7 +101,7 @@ struct TriRec {
     float z[3];                     /* screen depth per corner */
     float rw[3];                    /* 1 / clip.w per corner */
     uint32_t meta;                  /* draw | backface << 16 | clipped << 17 | fan_count << 18
-                                     * | blend << 22 | alpha-cutoff << 23 */
+                                     * | blend << 22 | alpha-cutoff << 23 | family << 24 */
     uint32_t bx, by;                /* own bounding box: min | max << 16 */
 };
 
@@ -134,12 +134,14 @@ struct PassParams {
     /* binning */
     int32_t bins_x, bins_y;
     uint32_t *bin_start, *bin_count;
-    uint32_t *bin_list;
+    uint4 *bin_list;                /* {triangle, bbox x, bbox y, 0} per entry */
     uint32_t bin_capacity;
+    uint32_t *ref;                  /* per pixel: reference of the visible fragment (split passes) */
     /* scalars written by the device: [0] fan blocks used, [1] bin entries
      * used, [2] error bits, [3] triangles queued for clipping */
     uint32_t *control;
     unsigned long long *counters;   /* nullptr unless counting is enabled */
+    int32_t debug_skip;             /* measurement only: 1 skip shading, 2 skip coverage too */
 };
 
 enum { RZ_ERR_FAN_OVERFLOW = 1, RZ_ERR_BIN_OVERFLOW = 2 };

@@ -28,7 +28,68 @@ RZ_DEV float d_max(float a, float b) { return a > b ? a : b; }                 /
 RZ_DEV float d_min(float a, float b) { return a < b ? a : b; }                 /* maths.c:9 */
 RZ_DEV float d_mix(float a, float b, float t) { return a + (b - a) * t; }      /* maths.c:17 */
 RZ_DEV float d_sat(float f) { return f < 0 ? 0 : (f > 1 ? 1 : f); }            /* maths.c:25 */
-RZ_DEV float d_srgb(float v) { return (float)pow((double)v, 1 / 2.2); }        /* maths.c:41 */
+
+/* ---- pow ------------------------------------------------------------------
+ * The reference calls the C library's double pow and narrows the result
+ * (maths.c:37-43, pbr_shader.c:357, blinn_shader.c:207).  The device library's
+ * general double pow costs ~600 instructions per call; here the base is a
+ * positive float, so log2 by the atanh series and exp2 by a Taylor polynomial,
+ * both in double with explicit fma, give a relative error below 1e-14 --
+ * thirty bits beyond float, which makes a different float after narrowing a
+ * once-in-10^7 event -- in about a tenth of the instructions. */
+RZ_DEV double d_log2_pos(double x) {
+    int e;
+    double m = frexp(x, &e);                        /* [0.5, 1) */
+    if (m < 0.70710678118654752440) { m *= 2.0; e -= 1; }
+    double s = (m - 1.0) / (m + 1.0);               /* |s| <= 0.1716 */
+    double z = s * s;
+    double p = 1.0 / 19.0;
+    p = fma(p, z, 1.0 / 17.0);
+    p = fma(p, z, 1.0 / 15.0);
+    p = fma(p, z, 1.0 / 13.0);
+    p = fma(p, z, 1.0 / 11.0);
+    p = fma(p, z, 1.0 / 9.0);
+    p = fma(p, z, 1.0 / 7.0);
+    p = fma(p, z, 1.0 / 5.0);
+    p = fma(p, z, 1.0 / 3.0);
+    p = fma(p, z, 1.0);
+    /* log2(m) = 2 atanh(s) / ln 2 */
+    return fma(s * p, 2.8853900817779268147, (double)e);
+}
+RZ_DEV double d_exp2(double y) {
+    double k = rint(y);
+    double t = (y - k) * 0.69314718055994530942;    /* |t| <= 0.3466 */
+    double p = 1.0 / 6227020800.0;                  /* 1/13! */
+    p = fma(p, t, 1.0 / 479001600.0);
+    p = fma(p, t, 1.0 / 39916800.0);
+    p = fma(p, t, 1.0 / 3628800.0);
+    p = fma(p, t, 1.0 / 362880.0);
+    p = fma(p, t, 1.0 / 40320.0);
+    p = fma(p, t, 1.0 / 5040.0);
+    p = fma(p, t, 1.0 / 720.0);
+    p = fma(p, t, 1.0 / 120.0);
+    p = fma(p, t, 1.0 / 24.0);
+    p = fma(p, t, 1.0 / 6.0);
+    p = fma(p, t, 0.5);
+    p = fma(p, t, 1.0);
+    p = fma(p, t, 1.0);
+    return ldexp(p, (int)k);
+}
+/* pow(base, exponent) narrowed to float, for base >= 0 (or NaN): the only
+ * cases the shaders produce (a saturated colour, a positive cosine) */
+RZ_DEV float d_powf(float base, double exponent) {
+    const float inf = __builtin_inff(), nan = __builtin_nanf("");
+    if (base > 0.0f) {
+        if (base == inf) return exponent > 0 ? inf : (exponent == 0 ? 1.0f : 0.0f);
+        double y = exponent * d_log2_pos((double)base);
+        if (!(y > -1070.0)) return y != y ? nan : 0.0f;        /* underflows float long before */
+        if (y > 1020.0) return inf;
+        return (float)d_exp2(y);
+    }
+    if (base == 0.0f) return exponent > 0 ? 0.0f : (exponent == 0 ? 1.0f : inf);
+    return nan;                                                 /* NaN in, or a negative base */
+}
+RZ_DEV float d_srgb(float v) { return d_powf(v, 1 / 2.2); }                      /* maths.c:41 */
 RZ_DEV float d_aces(float v) {                                                 /* maths.c:49 */
     float a = 2.51f, b = 0.03f, c = 2.43f, d = 0.59f, e = 0.14f;
     v = (v * (a * v + b)) / (v * (c * v + d) + e);
@@ -212,7 +273,7 @@ RZ_DEV f4 fs_blinn(const DrawRec &D, const float *v, bool backface, bool *discar
             if (!(specular.x == 0 && specular.y == 0 && specular.z == 0)) {      /* :201-212 */
                 f3 half = unit3(add3(light, view));
                 float n_dot_h = dot3(normal, half);
-                if (n_dot_h > 0) spec = scale3(specular, (float)pow((double)n_dot_h, (double)D.shininess));
+                if (n_dot_h > 0) spec = scale3(specular, d_powf(n_dot_h, (double)D.shininess));
             }
             f3 lit = add3(scale3(diffuse, n_dot_l), spec);
             color = add3(color, scale3(lit, D.punctual));
@@ -318,7 +379,9 @@ RZ_DEV f3 pbr_light(const Surface &s, f3 light, f3 n, f3 view) {
         float gv = n_dot_l * sqrtf(ndv2 * (1 - a2) + a2);
         float gl = n_dot_v * sqrtf(ndl2 * (1 - a2) + a2);
         float v_term = 0.5f / (gv + gl);
-        float ff = (float)pow((double)(1 - v_dot_h), 5.0);
+        /* pow(x, 5) in double: x*x and (x*x)*(x*x) are exact or rounded once at 2^-53 */
+        double fb = (double)(1 - v_dot_h), fb2 = fb * fb;
+        float ff = (float)((fb2 * fb2) * fb);
         float f90 = d_sat(largest3(s.specular) * 50);
         f3 f = mk3(s.specular.x + (f90 - s.specular.x) * ff,
                    s.specular.y + (f90 - s.specular.y) * ff,

@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""Condenses the rocprofv3 CSVs written by tools/profile.sh into one table:
+per kernel the launch count, average duration and the PMC counters averaged
+per launch.  FETCH_SIZE / WRITE_SIZE are reported in bytes with the gfx950
+correction for wide coalesced reads (FETCH_SIZE counts 64 B per 128-B request:
+doubled here, flagged as an upper bound for narrow access patterns)."""
+import csv
+import glob
+import os
+import sys
+from collections import defaultdict
+
+out = sys.argv[1]
+
+
+def short(name):
+    return name.split("(")[0].replace("void ", "")
+
+
+stats = {}
+for f in glob.glob(os.path.join(out, "trace", "**", "*kernel_stats.csv"), recursive=True):
+    for row in csv.DictReader(open(f)):
+        stats[short(row["Name"])] = (int(row["Calls"]), float(row["AverageNs"]) / 1e3, float(row["Percentage"]))
+
+pmc = defaultdict(lambda: defaultdict(list))
+for f in glob.glob(os.path.join(out, "*", "**", "*counter_collection.csv"), recursive=True):
+    for row in csv.DictReader(open(f)):
+        pmc[short(row["Kernel_Name"])][row["Counter_Name"]].append(float(row["Counter_Value"]))
+
+print(f"{'kernel':34s} {'calls':>6s} {'avg us':>9s} {'%':>6s}")
+for k, (calls, avg, pct) in sorted(stats.items(), key=lambda kv: -kv[1][2]):
+    print(f"{k:34s} {calls:6d} {avg:9.2f} {pct:6.2f}")
+    for c, vals in sorted(pmc.get(k, {}).items()):
+        mean = sum(vals) / len(vals)
+        note = ""
+        if c == "FETCH_SIZE":
+            note = f"  KiB -> {mean * 1024 * 2 / 1e6:.2f} MB/launch (x2 gfx950 correction)"
+        if c == "WRITE_SIZE":
+            note = f"  KiB -> {mean * 1024 / 1e6:.2f} MB/launch"
+        print(f"    {c:28s} {mean:16.1f}{note}")
