@@ -54,6 +54,7 @@ struct Fb {
     rz_framebuffer pub;             /* must stay first: handed out as rz_framebuffer* */
     uint32_t *d_color;
     float *d_depth;
+    int lane;                       /* execution lane of the last pass into it, -1 = none yet */
     bool clear_color_pending, clear_depth_pending;
     uint32_t clear_color;
     float clear_depth;
@@ -66,6 +67,11 @@ struct Tex {
     int flags, mbits;               /* RZ_TEX_* of the device image */
     bool device_stale;              /* host buffer is newer */
     bool host_stale;                /* device image is newer */
+    /* a texture written on the GPU (texture_from_*buffer) orders the passes
+     * around it: readers wait for the write, the next write for the readers */
+    int write_lane;
+    hipEvent_t write_event;
+    std::vector<hipEvent_t> read_events;
 };
 
 struct rz_program {
@@ -88,6 +94,7 @@ struct Pending {
     DrawRec rec;                    /* joints / vertices patched at flush */
     int num_joints;
     size_t joints_at, joint_normals_at;     /* offsets into Context::side */
+    std::vector<Tex*> gpu_textures; /* sampled textures that a GPU pass wrote */
     bool transient;                 /* vertices recorded by graphics_draw_triangle */
     std::vector<rz_vertex> verts;
     std::vector<char> uniform_bytes;        /* for merging per-triangle calls */
@@ -98,16 +105,30 @@ template <typename T> struct DevBuf {
     size_t cap = 0;
 };
 
-struct Context {
-    bool ready = false;
-    int device = 0;
+/* An execution lane: a HIP stream with its own per-pass scratch.  Passes that
+ * do not depend on each other (different framebuffers, no texture hand-over)
+ * run on different lanes and overlap on the GPU; passes on one lane are
+ * serialised by the stream, which is what lets them share the scratch. */
+struct Lane {
     hipStream_t stream = nullptr;
-    /* per-pass scratch, grow-only; passes are serialised on the stream */
     DevBuf<float> clip, vary, fan_vary;
     DevBuf<TriRec> tri, fan_tri;
     DevBuf<uint2> bbox;
     DevBuf<uint32_t> bin_start, bin_count, clip_list, ref;
     DevBuf<uint4> bin_list;
+};
+
+static const int MAX_LANES = 8;
+
+struct Context {
+    bool ready = false;
+    int device = 0;
+    hipStream_t stream = nullptr;       /* lane 0's stream: uploads and utilities */
+    hipStream_t copy_stream = nullptr;  /* table uploads / control read-back of a flush */
+    Lane lanes[MAX_LANES];
+    int num_lanes = 1, next_lane = 0;
+    std::vector<hipEvent_t> events;     /* recorded since the last full sync */
+    std::vector<Tex*> current_gpu_textures;
     /* upload ring: pinned host memory mirrored 1:1 in device memory */
     char *ring_host = nullptr, *ring_dev = nullptr;
     size_t ring_size = 0, ring_at = 0;
@@ -141,9 +162,9 @@ static void ensure_ready() {
     if (!g.ready) mi355r_init(-1);
 }
 
-template <typename T> static void reserve(DevBuf<T> &b, size_t n) {
+template <typename T> static void reserve(DevBuf<T> &b, size_t n, hipStream_t user) {
     if (n <= b.cap) return;
-    if (b.ptr) { HIP_OK(hipStreamSynchronize(g.stream)); HIP_OK(hipFree(b.ptr)); }
+    if (b.ptr) { HIP_OK(hipStreamSynchronize(user)); HIP_OK(hipFree(b.ptr)); }
     size_t cap = std::max(n, b.cap + b.cap / 2);
     HIP_OK(hipMalloc((void**)&b.ptr, cap * sizeof(T)));
     b.cap = cap;
@@ -151,9 +172,25 @@ template <typename T> static void reserve(DevBuf<T> &b, size_t n) {
 
 static void check_passes_in_flight();
 
+static void sync_stream();
+
+static hipEvent_t new_event(hipStream_t on) {
+    if (g.events.size() > 8192) sync_stream();      /* bound the number of live events */
+    hipEvent_t e;
+    HIP_OK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    HIP_OK(hipEventRecord(e, on));
+    g.events.push_back(e);
+    return e;
+}
+
+/* full synchronisation: every lane and the copy stream */
 static void sync_stream() {
-    HIP_OK(hipStreamSynchronize(g.stream));
+    for (int i = 0; i < g.num_lanes; i++) HIP_OK(hipStreamSynchronize(g.lanes[i].stream));
+    HIP_OK(hipStreamSynchronize(g.copy_stream));
     check_passes_in_flight();
+    for (hipEvent_t e : g.events) HIP_OK(hipEventDestroy(e));
+    g.events.clear();
+    for (Tex *t : g.texs) { t->write_event = nullptr; t->read_events.clear(); }
 }
 
 extern "C" int mi355r_init(int device) {
@@ -164,12 +201,21 @@ extern "C" int mi355r_init(int device) {
     HIP_OK(hipGetDeviceProperties(&prop, g.device));
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         fprintf(stderr, "mi355r: warning: built for gfx950, running on %s\n", prop.gcnArchName);
-    HIP_OK(hipStreamCreate(&g.stream));
+    {
+        const char *env = getenv("MI355R_LANES");
+        g.num_lanes = env ? atoi(env) : 4;
+        if (g.num_lanes < 1) g.num_lanes = 1;
+        if (g.num_lanes > MAX_LANES) g.num_lanes = MAX_LANES;
+    }
+    for (int i = 0; i < g.num_lanes; i++) HIP_OK(hipStreamCreateWithFlags(&g.lanes[i].stream, hipStreamNonBlocking));
+    HIP_OK(hipStreamCreateWithFlags(&g.copy_stream, hipStreamNonBlocking));
+    g.stream = g.lanes[0].stream;
     HIP_OK(hipHostMalloc((void**)&g.ring_host, RING_BYTES, hipHostMallocDefault));
     HIP_OK(hipMalloc((void**)&g.ring_dev, RING_BYTES));
     g.ring_size = RING_BYTES;
     HIP_OK(hipMalloc((void**)&g.d_counters, 12 * sizeof(unsigned long long)));
     HIP_OK(hipMemset(g.d_counters, 0, 12 * sizeof(unsigned long long)));
+    HIP_OK(hipDeviceSynchronize());
     g.ready = true;
     return g.device;
 }
@@ -206,6 +252,7 @@ extern "C" rz_framebuffer *framebuffer_create(int width, int height) {
     fb->pub.depth_buffer = (float*)malloc(n * sizeof(float));
     HIP_OK(hipMalloc((void**)&fb->d_color, n * 4));
     HIP_OK(hipMalloc((void**)&fb->d_depth, n * sizeof(float)));
+    fb->lane = -1;
     g.fbs.insert(fb);
     rz_vec4 black = {0, 0, 0, 1};
     framebuffer_clear_color(&fb->pub, black);           /* graphics.c:26-27 */
@@ -243,7 +290,8 @@ extern "C" void framebuffer_clear_depth(rz_framebuffer *p, float depth) {
 static void apply_pending_clear(Fb *fb) {
     if (!fb->clear_color_pending && !fb->clear_depth_pending) return;
     size_t n = (size_t)fb->pub.width * fb->pub.height;
-    rz_clear_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, g.stream>>>(
+    if (fb->lane < 0) fb->lane = 0;
+    rz_clear_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, g.lanes[fb->lane].stream>>>(
         fb->d_color, fb->d_depth, n, fb->clear_color_pending, fb->clear_color,
         fb->clear_depth_pending, fb->clear_depth);
     HIP_OK(hipGetLastError());
@@ -260,8 +308,9 @@ extern "C" void framebuffer_read(rz_framebuffer *p, void *color, void *depth) {
     graphics_flush();
     apply_pending_clear(fb);
     size_t n = (size_t)fb->pub.width * fb->pub.height;
-    if (color) HIP_OK(hipMemcpyAsync(color, fb->d_color, n * 4, hipMemcpyDeviceToHost, g.stream));
-    if (depth) HIP_OK(hipMemcpyAsync(depth, fb->d_depth, n * sizeof(float), hipMemcpyDeviceToHost, g.stream));
+    hipStream_t st = g.lanes[fb->lane < 0 ? 0 : fb->lane].stream;
+    if (color) HIP_OK(hipMemcpyAsync(color, fb->d_color, n * 4, hipMemcpyDeviceToHost, st));
+    if (depth) HIP_OK(hipMemcpyAsync(depth, fb->d_depth, n * sizeof(float), hipMemcpyDeviceToHost, st));
     sync_stream();
 }
 
@@ -270,9 +319,11 @@ extern "C" void framebuffer_read_device(rz_framebuffer *p, void *color, void *de
     graphics_flush();
     apply_pending_clear(fb);
     size_t n = (size_t)fb->pub.width * fb->pub.height;
-    if (color) HIP_OK(hipMemcpyAsync(color, fb->d_color, n * 4, hipMemcpyDeviceToDevice, g.stream));
-    if (depth) HIP_OK(hipMemcpyAsync(depth, fb->d_depth, n * sizeof(float), hipMemcpyDeviceToDevice, g.stream));
-    sync_stream();
+    /* only this framebuffer's lane has to drain: other frames keep rendering */
+    hipStream_t st = g.lanes[fb->lane < 0 ? 0 : fb->lane].stream;
+    if (color) HIP_OK(hipMemcpyAsync(color, fb->d_color, n * 4, hipMemcpyDeviceToDevice, st));
+    if (depth) HIP_OK(hipMemcpyAsync(depth, fb->d_depth, n * sizeof(float), hipMemcpyDeviceToDevice, st));
+    HIP_OK(hipStreamSynchronize(st));
 }
 
 /* ---------------------------------------------------------------- textures -- */
@@ -311,6 +362,8 @@ extern "C" rz_texture *texture_create(int width, int height) {      /* texture.c
     t->mbits = 0;
     t->device_stale = true;
     t->host_stale = false;
+    t->write_lane = -1;
+    t->write_event = nullptr;
     g.texs.insert(t);
     return &t->pub;
 }
@@ -351,6 +404,8 @@ static void upload_texture(Tex *t) {
     int w = t->pub.width, h = t->pub.height;
     size_t bytes = (size_t)w * h * sizeof(float4);
     graphics_flush();               /* recorded draws may still sample the old image */
+    if (t->write_lane >= 0 || !t->read_events.empty()) sync_stream();
+    t->write_lane = -1;
     device_image(t, 0, sizeof(float4));
     float4 *staging;
     HIP_OK(hipMalloc((void**)&staging, bytes));
@@ -370,6 +425,7 @@ static DevTex dev_tex(rz_texture *p) {
     if (!p) return d;
     Tex *t = as_tex(p);
     if (t->device_stale) upload_texture(t);
+    if (t->write_lane >= 0) g.current_gpu_textures.push_back(t);
     d.data = t->d_data;
     d.w = t->pub.width;
     d.h = t->pub.height;
@@ -384,6 +440,7 @@ extern "C" void texture_sync(rz_texture *p) {
     int w = t->pub.width, h = t->pub.height;
     size_t bytes = (size_t)w * h * sizeof(float4);
     graphics_flush();
+    sync_stream();
     float4 *staging;
     HIP_OK(hipMalloc((void**)&staging, bytes));
     rz_texture_untile_kernel<<<dim3((w + 15) / 16, (h + 15) / 16), dim3(256), 0, g.stream>>>(
@@ -395,6 +452,23 @@ extern "C" void texture_sync(rz_texture *p) {
     t->host_stale = false;
 }
 
+/* The framebuffer's lane writes the texture: it first waits for every pass
+ * that still samples the previous contents; later readers wait for the write. */
+static hipStream_t begin_texture_write(Tex *t, Fb *fb) {
+    if (fb->lane < 0) fb->lane = 0;
+    hipStream_t st = g.lanes[fb->lane].stream;
+    for (hipEvent_t e : t->read_events) HIP_OK(hipStreamWaitEvent(st, e, 0));
+    t->read_events.clear();
+    if (t->write_event && t->write_lane != fb->lane) HIP_OK(hipStreamWaitEvent(st, t->write_event, 0));
+    return st;
+}
+static void end_texture_write(Tex *t, Fb *fb) {
+    t->write_lane = fb->lane;
+    t->write_event = new_event(g.lanes[fb->lane].stream);
+    t->device_stale = false;
+    t->host_stale = true;
+}
+
 extern "C" void texture_from_depthbuffer(rz_texture *tp, rz_framebuffer *fp) {   /* texture.c:147 */
     Tex *t = as_tex(tp);
     Fb *fb = as_fb(fp);
@@ -403,11 +477,11 @@ extern "C" void texture_from_depthbuffer(rz_texture *tp, rz_framebuffer *fp) {  
     apply_pending_clear(fb);
     device_image(t, RZ_TEX_R32F, sizeof(float));
     int w = t->pub.width, h = t->pub.height;
-    rz_depth_to_texture_kernel<<<dim3((w + 15) / 16, (h + 15) / 16), dim3(256), 0, g.stream>>>(
+    hipStream_t st = begin_texture_write(t, fb);
+    rz_depth_to_texture_kernel<<<dim3((w + 15) / 16, (h + 15) / 16), dim3(256), 0, st>>>(
         fb->d_depth, (float*)t->d_data, w, h, t->flags, t->mbits);
     HIP_OK(hipGetLastError());
-    t->device_stale = false;
-    t->host_stale = true;
+    end_texture_write(t, fb);
 }
 
 extern "C" void texture_from_colorbuffer(rz_texture *tp, rz_framebuffer *fp) {   /* texture.c:130 */
@@ -418,11 +492,11 @@ extern "C" void texture_from_colorbuffer(rz_texture *tp, rz_framebuffer *fp) {  
     apply_pending_clear(fb);
     device_image(t, 0, sizeof(float4));
     int w = t->pub.width, h = t->pub.height;
-    rz_color_to_texture_kernel<<<dim3((w + 15) / 16, (h + 15) / 16), dim3(256), 0, g.stream>>>(
+    hipStream_t st = begin_texture_write(t, fb);
+    rz_color_to_texture_kernel<<<dim3((w + 15) / 16, (h + 15) / 16), dim3(256), 0, st>>>(
         fb->d_color, (float4*)t->d_data, w, h, t->flags, t->mbits);
     HIP_OK(hipGetLastError());
-    t->device_stale = false;
-    t->host_stale = true;
+    end_texture_write(t, fb);
 }
 
 /* Host-side accessors with the reference's addressing (texture.c:160-273).
@@ -610,6 +684,7 @@ static void copy_floats(float *dst, const void *src, int n) { memcpy(dst, src, s
 static void snapshot_uniforms(rz_program *p, Pending &pd, int num_joints) {
     DrawRec &r = pd.rec;
     memset(&r, 0, sizeof r);
+    g.current_gpu_textures.clear();
     r.family = p->family;
     r.flags = (p->double_sided ? RZ_DRAW_DOUBLE_SIDED : 0) | (p->blend ? RZ_DRAW_BLEND : 0);
     const rz_mat4 *joints = nullptr;
@@ -679,6 +754,7 @@ static void snapshot_uniforms(rz_program *p, Pending &pd, int num_joints) {
         r.layer_view = u->layer_view;
         if (u->shadow_pass) r.flags |= RZ_DRAW_SHADOW_PASS;
     }
+    pd.gpu_textures = g.current_gpu_textures;
     /* joint matrices are rewritten in place by the skeleton every frame
      * (skeleton.c:336-337): copy them now */
     pd.num_joints = 0;
@@ -840,24 +916,25 @@ static void fill_pass(const PassPlan &pl, char *hb, char *db) {
     first_tri[D] = running;
 }
 
-static void launch_pass(const PassPlan &pl, char *db, uint32_t *control) {
+static void launch_pass(const PassPlan &pl, char *db, uint32_t *control, Lane &L) {
     Fb *fb = g.pending[pl.first].fb;
+    hipStream_t st = L.stream;
     const size_t D = pl.last - pl.first, T = pl.T;
     const int W = fb->pub.width, H = fb->pub.height;
     const int bins_x = (W + RZ_BIN - 1) / RZ_BIN, bins_y = (H + RZ_BIN - 1) / RZ_BIN;
     const size_t bins = (size_t)bins_x * bins_y;
     const size_t fan_cap = std::min<size_t>(T, 1u << 18);
     const size_t list_cap = std::min<size_t>(T * bins, std::max<size_t>(T * 16, 1u << 20));
-    reserve(g.clip, T * 3 * 4);
-    reserve(g.vary, T * 3 * RZ_VARY_STRIDE);
-    reserve(g.tri, T);
-    reserve(g.bbox, T);
-    reserve(g.clip_list, T);
-    reserve(g.fan_tri, fan_cap * RZ_MAX_FAN);
-    reserve(g.fan_vary, fan_cap * RZ_MAX_POLY * RZ_VARY_STRIDE);
-    reserve(g.bin_start, bins);
-    reserve(g.bin_count, bins);
-    reserve(g.bin_list, list_cap);
+    reserve(L.clip, T * 3 * 4, st);
+    reserve(L.vary, T * 3 * RZ_VARY_STRIDE, st);
+    reserve(L.tri, T, st);
+    reserve(L.bbox, T, st);
+    reserve(L.clip_list, T, st);
+    reserve(L.fan_tri, fan_cap * RZ_MAX_FAN, st);
+    reserve(L.fan_vary, fan_cap * RZ_MAX_POLY * RZ_VARY_STRIDE, st);
+    reserve(L.bin_start, bins, st);
+    reserve(L.bin_count, bins, st);
+    reserve(L.bin_list, list_cap, st);
     bool has_blend = false;
     int families = 0;
     for (size_t i = pl.first; i < pl.last; i++) {
@@ -865,7 +942,7 @@ static void launch_pass(const PassPlan &pl, char *db, uint32_t *control) {
         families |= 1 << g.pending[i].rec.family;
     }
     if (getenv("MI355R_MONOLITHIC")) has_blend = true;
-    if (!has_blend) reserve(g.ref, (size_t)W * H);
+    if (!has_blend) reserve(L.ref, (size_t)W * H, st);
 
     PassParams P;
     memset(&P, 0, sizeof P);
@@ -881,21 +958,21 @@ static void launch_pass(const PassPlan &pl, char *db, uint32_t *control) {
     P.first_tri = (const uint32_t*)(db + pl.off_first);
     P.num_draws = (int)D;
     P.num_tris = (int)T;
-    P.clip = g.clip.ptr;
-    P.vary = g.vary.ptr;
-    P.tri = g.tri.ptr;
-    P.bbox = g.bbox.ptr;
-    P.fan_tri = g.fan_tri.ptr;
-    P.fan_vary = g.fan_vary.ptr;
+    P.clip = L.clip.ptr;
+    P.vary = L.vary.ptr;
+    P.tri = L.tri.ptr;
+    P.bbox = L.bbox.ptr;
+    P.fan_tri = L.fan_tri.ptr;
+    P.fan_vary = L.fan_vary.ptr;
     P.fan_capacity = (int)fan_cap;
-    P.clip_list = g.clip_list.ptr;
+    P.clip_list = L.clip_list.ptr;
     P.bins_x = bins_x;
     P.bins_y = bins_y;
-    P.bin_start = g.bin_start.ptr;
-    P.bin_count = g.bin_count.ptr;
-    P.bin_list = g.bin_list.ptr;
+    P.bin_start = L.bin_start.ptr;
+    P.bin_count = L.bin_count.ptr;
+    P.bin_list = L.bin_list.ptr;
     P.bin_capacity = (uint32_t)list_cap;
-    P.ref = g.ref.ptr;
+    P.ref = L.ref.ptr;
     P.control = control;
     P.counters = g.counting ? g.d_counters : nullptr;
     { const char *dbg = getenv("MI355R_DEBUG_SKIP"); P.debug_skip = dbg ? atoi(dbg) : 0; }
@@ -906,33 +983,33 @@ static void launch_pass(const PassPlan &pl, char *db, uint32_t *control) {
         if (!g.timing) return;
         hipEvent_t e;
         HIP_OK(hipEventCreate(&e));
-        HIP_OK(hipEventRecord(e, g.stream));
+        HIP_OK(hipEventRecord(e, st));
         g.timing_events.push_back(e);
     };
     stamp();
-    rz_vertex_kernel<<<dim3(vblocks), dim3(256), 0, g.stream>>>(P);
+    rz_vertex_kernel<<<dim3(vblocks), dim3(256), 0, st>>>(P);
     stamp();
-    rz_setup_kernel<<<dim3(tblocks), dim3(256), 0, g.stream>>>(P);
-    rz_clip_kernel<<<dim3(256), dim3(64), 0, g.stream>>>(P);
+    rz_setup_kernel<<<dim3(tblocks), dim3(256), 0, st>>>(P);
+    rz_clip_kernel<<<dim3(256), dim3(64), 0, st>>>(P);
     stamp();
-    rz_bin_kernel<<<dim3((unsigned)bins), dim3(RZ_BIN_WAVES * 64), 0, g.stream>>>(P);
+    rz_bin_kernel<<<dim3((unsigned)bins), dim3(RZ_BIN_WAVES * 64), 0, st>>>(P);
     stamp();
     const dim3 tiles((unsigned)(tiles_x * tiles_y));
     if (has_blend) {
         /* blended fragments read the colour below them: visibility and shading stay in one kernel */
-        rz_raster_kernel<false><<<tiles, dim3(256), 0, g.stream>>>(
+        rz_raster_kernel<false><<<tiles, dim3(256), 0, st>>>(
             P, P.tri, P.fan_tri, P.bin_list, P.vary, P.fan_vary, P.draws, P.bin_start, P.bin_count);
         stamp();
     } else {
-        rz_raster_kernel<true><<<tiles, dim3(256), 0, g.stream>>>(
+        rz_raster_kernel<true><<<tiles, dim3(256), 0, st>>>(
             P, P.tri, P.fan_tri, P.bin_list, P.vary, P.fan_vary, P.draws, P.bin_start, P.bin_count);
         stamp();
         if (families & (1 << RZ_FAMILY_SKYBOX))
-            rz_shade_kernel<2><<<tiles, dim3(256), 0, g.stream>>>(P, P.tri, P.fan_tri, P.vary, P.fan_vary, P.draws, P.ref);
+            rz_shade_kernel<2><<<tiles, dim3(256), 0, st>>>(P, P.tri, P.fan_tri, P.vary, P.fan_vary, P.draws, P.ref);
         if (families & (1 << RZ_FAMILY_BLINN))
-            rz_shade_kernel<0><<<tiles, dim3(256), 0, g.stream>>>(P, P.tri, P.fan_tri, P.vary, P.fan_vary, P.draws, P.ref);
+            rz_shade_kernel<0><<<tiles, dim3(256), 0, st>>>(P, P.tri, P.fan_tri, P.vary, P.fan_vary, P.draws, P.ref);
         if (families & (1 << RZ_FAMILY_PBR))
-            rz_shade_kernel<1><<<tiles, dim3(256), 0, g.stream>>>(P, P.tri, P.fan_tri, P.vary, P.fan_vary, P.draws, P.ref);
+            rz_shade_kernel<1><<<tiles, dim3(256), 0, st>>>(P, P.tri, P.fan_tri, P.vary, P.fan_vary, P.draws, P.ref);
     }
     stamp();
     HIP_OK(hipGetLastError());
@@ -945,7 +1022,12 @@ static void launch_pass(const PassPlan &pl, char *db, uint32_t *control) {
 
 /* One upload region per flush: [control block per pass][pass 0 tables][pass 1 tables]...
  * -> one host-to-device copy in front of the kernels and one small copy of the
- * control blocks back behind them, whatever the number of passes. */
+ * control blocks back behind them, whatever the number of passes.
+ *
+ * Scheduling: a pass runs on the lane its framebuffer last ran on (passes into
+ * one framebuffer must stay ordered), a framebuffer without history takes the
+ * next lane in turn.  Textures written on the GPU order passes across lanes
+ * through events. */
 extern "C" void graphics_flush(void) {
     if (!g.ready || g.pending.empty()) return;
     std::vector<PassPlan> plans;
@@ -965,9 +1047,38 @@ extern "C" void graphics_flush(void) {
     char *hb = g.ring_host + at, *db = g.ring_dev + at;
     for (auto &pl : plans) fill_pass(pl, hb, db);
     size_t head = (CONTROL_BYTES * plans.size() + 255) & ~(size_t)255;
-    HIP_OK(hipMemcpyAsync(db + head, hb + head, total - head, hipMemcpyHostToDevice, g.stream));
-    for (size_t i = 0; i < plans.size(); i++) launch_pass(plans[i], db, (uint32_t*)(db + CONTROL_BYTES * i));
-    HIP_OK(hipMemcpyAsync(hb, db, CONTROL_BYTES * plans.size(), hipMemcpyDeviceToHost, g.stream));
+    HIP_OK(hipMemcpyAsync(db + head, hb + head, total - head, hipMemcpyHostToDevice, g.copy_stream));
+    hipEvent_t uploaded = new_event(g.copy_stream);
+
+    const int lanes = g.timing ? 1 : g.num_lanes;      /* per-kernel timing wants kernels alone on the GPU */
+    bool used[MAX_LANES] = {false};
+    for (size_t i = 0; i < plans.size(); i++) {
+        const PassPlan &pl = plans[i];
+        Fb *fb = g.pending[pl.first].fb;
+        int lane = fb->lane;
+        if (lane < 0 || lane >= lanes) { lane = g.next_lane % lanes; g.next_lane = (g.next_lane + 1) % lanes; }
+        Lane &L = g.lanes[lane];
+        if (fb->lane >= 0 && fb->lane != lane) {        /* lane count changed (timing mode): order by hand */
+            HIP_OK(hipStreamWaitEvent(L.stream, new_event(g.lanes[fb->lane].stream), 0));
+        }
+        if (!used[lane]) { HIP_OK(hipStreamWaitEvent(L.stream, uploaded, 0)); used[lane] = true; }
+        std::vector<Tex*> sampled;
+        for (size_t d = pl.first; d < pl.last; d++)
+            for (Tex *t : g.pending[d].gpu_textures)
+                if (std::find(sampled.begin(), sampled.end(), t) == sampled.end()) sampled.push_back(t);
+        for (Tex *t : sampled)
+            if (t->write_event && t->write_lane != lane) HIP_OK(hipStreamWaitEvent(L.stream, t->write_event, 0));
+        fb->lane = lane;
+        launch_pass(pl, db, (uint32_t*)(db + CONTROL_BYTES * i), L);
+        if (!sampled.empty()) {
+            hipEvent_t done = new_event(L.stream);
+            for (Tex *t : sampled) t->read_events.push_back(done);
+        }
+    }
+    /* control blocks come back once every lane of this flush has finished */
+    for (int l = 0; l < MAX_LANES; l++)
+        if (used[l]) HIP_OK(hipStreamWaitEvent(g.copy_stream, new_event(g.lanes[l].stream), 0));
+    HIP_OK(hipMemcpyAsync(hb, db, CONTROL_BYTES * plans.size(), hipMemcpyDeviceToHost, g.copy_stream));
     for (size_t i = 0; i < plans.size(); i++) g.control_slots.push_back(at + CONTROL_BYTES * i);
     g.pending.clear();
     g.side.clear();
@@ -986,6 +1097,7 @@ extern "C" void mi355r_reset_counters(void) {
     graphics_flush();
     sync_stream();
     HIP_OK(hipMemset(g.d_counters, 0, 12 * sizeof(unsigned long long)));
+    HIP_OK(hipDeviceSynchronize());
     memset(g.host_counters, 0, sizeof g.host_counters);
 }
 
