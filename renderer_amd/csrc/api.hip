@@ -33,6 +33,7 @@ static_assert(sizeof(rz_pbr_uniforms) == 440, "pbr uniform block (pbr_shader.h:3
 static_assert(sizeof(rz_skybox_uniforms) == 72, "skybox uniform block (skybox_shader.h:16-19)");
 static_assert(sizeof(rz_blinn_attribs) == 64, "blinn attribs");
 static_assert(sizeof(TriRec) == 64, "TriRec is four float4");
+static_assert(sizeof(BinEntry) == 80, "BinEntry is five float4");
 static_assert(sizeof(DevTex) == 24, "DevTex");
 
 [[noreturn]] static void fatal(const char *fmt, ...) {
@@ -114,8 +115,9 @@ struct Lane {
     DevBuf<float> clip, vary, fan_vary;
     DevBuf<TriRec> tri, fan_tri;
     DevBuf<uint2> bbox;
-    DevBuf<uint32_t> bin_start, bin_count, clip_list, ref;
-    DevBuf<uint4> bin_list;
+    DevBuf<uint32_t> clip_list, ref;
+    DevBuf<uint2> bin_range;
+    DevBuf<BinEntry> bin_list;
 };
 
 static const int MAX_LANES = 8;
@@ -932,8 +934,7 @@ static void launch_pass(const PassPlan &pl, char *db, uint32_t *control, Lane &L
     reserve(L.clip_list, T, st);
     reserve(L.fan_tri, fan_cap * RZ_MAX_FAN, st);
     reserve(L.fan_vary, fan_cap * RZ_MAX_POLY * RZ_VARY_STRIDE, st);
-    reserve(L.bin_start, bins, st);
-    reserve(L.bin_count, bins, st);
+    reserve(L.bin_range, bins, st);
     reserve(L.bin_list, list_cap, st);
     bool has_blend = false;
     int families = 0;
@@ -968,8 +969,7 @@ static void launch_pass(const PassPlan &pl, char *db, uint32_t *control, Lane &L
     P.clip_list = L.clip_list.ptr;
     P.bins_x = bins_x;
     P.bins_y = bins_y;
-    P.bin_start = L.bin_start.ptr;
-    P.bin_count = L.bin_count.ptr;
+    P.bin_range = L.bin_range.ptr;
     P.bin_list = L.bin_list.ptr;
     P.bin_capacity = (uint32_t)list_cap;
     P.ref = L.ref.ptr;
@@ -978,7 +978,7 @@ static void launch_pass(const PassPlan &pl, char *db, uint32_t *control, Lane &L
     { const char *dbg = getenv("MI355R_DEBUG_SKIP"); P.debug_skip = dbg ? atoi(dbg) : 0; }
 
     const unsigned vblocks = (unsigned)((T * 3 + 255) / 256), tblocks = (unsigned)((T + 255) / 256);
-    const int tiles_x = (W + RZ_TILE - 1) / RZ_TILE, tiles_y = (H + RZ_TILE - 1) / RZ_TILE;
+    const int tiles_x = (W + RZ_TILE_W - 1) / RZ_TILE_W, tiles_y = (H + RZ_TILE_H - 1) / RZ_TILE_H;
     auto stamp = [&]() {
         if (!g.timing) return;
         hipEvent_t e;
@@ -998,11 +998,11 @@ static void launch_pass(const PassPlan &pl, char *db, uint32_t *control, Lane &L
     if (has_blend) {
         /* blended fragments read the colour below them: visibility and shading stay in one kernel */
         rz_raster_kernel<false><<<tiles, dim3(256), 0, st>>>(
-            P, P.tri, P.fan_tri, P.bin_list, P.vary, P.fan_vary, P.draws, P.bin_start, P.bin_count);
+            P, P.tri, P.fan_tri, P.bin_list, P.vary, P.fan_vary, P.draws, P.bin_range);
         stamp();
     } else {
         rz_raster_kernel<true><<<tiles, dim3(256), 0, st>>>(
-            P, P.tri, P.fan_tri, P.bin_list, P.vary, P.fan_vary, P.draws, P.bin_start, P.bin_count);
+            P, P.tri, P.fan_tri, P.bin_list, P.vary, P.fan_vary, P.draws, P.bin_range);
         stamp();
         if (families & (1 << RZ_FAMILY_SKYBOX))
             rz_shade_kernel<2><<<tiles, dim3(256), 0, st>>>(P, P.tri, P.fan_tri, P.vary, P.fan_vary, P.draws, P.ref);

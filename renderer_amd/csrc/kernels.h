@@ -368,6 +368,10 @@ __global__ void __launch_bounds__(64) rz_clip_kernel(PassParams P) {
  *     count, reserve a contiguous range with one atomic, then fill in order.
  * ======================================================================== */
 
+/* a fragment / list reference: a triangle index, or RZ_REF_FAN | index into fan_tri */
+#define RZ_REF_NONE 0xffffffffu
+#define RZ_REF_FAN 0x80000000u
+
 RZ_DEV bool box_overlaps(uint2 bb, int rx0, int ry0, int rx1, int ry1) {
     int x0 = (int)(bb.x & 0xffffu), x1 = (int)(bb.x >> 16);
     int y0 = (int)(bb.y & 0xffffu), y1 = (int)(bb.y >> 16);
@@ -376,8 +380,28 @@ RZ_DEV bool box_overlaps(uint2 bb, int rx0, int ry0, int rx1, int ry1) {
 
 #define RZ_BIN_WAVES 16
 
+/* entries a triangle contributes to a bin it touches: one, or one per fan
+ * triangle when it was clipped (the fan keeps its order inside the list) */
+RZ_DEV uint32_t bin_entries_of(const PassParams &P, uint32_t t, bool hit) {
+    if (!hit) return 0u;
+    uint32_t meta = P.tri[t].meta;
+    return RZ_META_CLIPPED(meta) ? RZ_META_FAN(meta) : 1u;
+}
+
+RZ_DEV uint32_t wave_exclusive_scan(uint32_t v, uint32_t *total) {
+    const int lane = threadIdx.x & 63;
+    uint32_t inc = v;
+    for (int off = 1; off < 64; off <<= 1) {
+        uint32_t up = __shfl_up(inc, off);
+        if (lane >= off) inc += up;
+    }
+    *total = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+    return inc - v;
+}
+
 /* Wave w owns the w-th contiguous slice of the triangle range, so the list is
- * the concatenation of the waves' hits: one barrier in the whole kernel. */
+ * the concatenation of the waves' hits: one barrier in the whole kernel.
+ * Every entry carries a copy of the triangle's record (BinEntry). */
 __global__ void __launch_bounds__(RZ_BIN_WAVES * 64) rz_bin_kernel(PassParams P) {
     __shared__ uint32_t s_count[RZ_BIN_WAVES];
     __shared__ uint32_t s_start;
@@ -397,8 +421,10 @@ __global__ void __launch_bounds__(RZ_BIN_WAVES * 64) rz_bin_kernel(PassParams P)
             uint32_t t = (c + u) * 64u + lane;
             hit[u] = (c + u) < c1 && t < T && box_overlaps(P.bbox[t], rx0, ry0, rx1, ry1);
         }
-        for (int u = 0; u < 4; u++) mine += (uint32_t)__popcll(__ballot(hit[u]));
+        for (int u = 0; u < 4; u++) mine += bin_entries_of(P, (c + u) * 64u + lane, hit[u]);
     }
+    for (int off = 32; off > 0; off >>= 1) mine += __shfl_down(mine, off);
+    mine = (uint32_t)__builtin_amdgcn_readfirstlane((int)mine);
     if (lane == 0) s_count[wave] = mine;
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -409,8 +435,7 @@ __global__ void __launch_bounds__(RZ_BIN_WAVES * 64) rz_bin_kernel(PassParams P)
             atomicOr(&P.control[2], (uint32_t)RZ_ERR_BIN_OVERFLOW);
             total = 0;
         }
-        P.bin_start[bin] = start;
-        P.bin_count[bin] = total;
+        P.bin_range[bin] = make_uint2(start, total);
         s_start = total ? start : 0xffffffffu;
     }
     __syncthreads();
@@ -425,13 +450,26 @@ __global__ void __launch_bounds__(RZ_BIN_WAVES * 64) rz_bin_kernel(PassParams P)
             hit[u] = (c + u) < c1 && t < T && box_overlaps(P.bbox[t], rx0, ry0, rx1, ry1);
         }
         for (int u = 0; u < 4; u++) {
-            unsigned long long m = __ballot(hit[u]);
-            if (hit[u]) {
-                uint32_t t = (c + u) * 64u + lane;
-                uint2 bb = P.bbox[t];           /* cached from the test above */
-                P.bin_list[cursor + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = make_uint4(t, bb.x, bb.y, 0u);
+            if (!__any(hit[u])) continue;
+            const uint32_t t = (c + u) * 64u + lane;
+            uint32_t n = bin_entries_of(P, t, hit[u]), total;
+            uint32_t at = cursor + wave_exclusive_scan(n, &total);
+            cursor += total;
+            if (n) {
+                const float4 *src = (const float4*)&P.tri[t];
+                float4 r0 = src[0], r1 = src[1], r2 = src[2], r3 = src[3];
+                uint32_t ref = t;
+                if (RZ_META_CLIPPED(__float_as_uint(r3.y))) {
+                    ref = RZ_REF_FAN | (__float_as_uint(r0.x) * RZ_MAX_FAN);     /* first fan record */
+                    src = (const float4*)&P.fan_tri[ref & ~RZ_REF_FAN];
+                }
+                for (uint32_t k = 0; k < n; k++) {
+                    if (k || (ref & RZ_REF_FAN)) { r0 = src[4 * k]; r1 = src[4 * k + 1]; r2 = src[4 * k + 2]; r3 = src[4 * k + 3]; }
+                    float4 *dst = (float4*)&P.bin_list[at + k];
+                    dst[0] = make_float4(__uint_as_float(ref + k), 0.0f, 0.0f, 0.0f);
+                    dst[1] = r0; dst[2] = r1; dst[3] = r2; dst[4] = r3;
+                }
             }
-            cursor += (uint32_t)__popcll(m);
         }
     }
 }
@@ -480,8 +518,6 @@ RZ_DEV uint32_t pack_rgb(f4 c, uint32_t keep) {                 /* float_to_ucha
  * at exactly one place in the kernel.
  */
 
-#define RZ_REF_NONE 0xffffffffu
-#define RZ_REF_FAN 0x80000000u      /* index into fan_tri instead of tri */
 #define RZ_META_BLEND(m) (((m) >> 22) & 1u)
 #define RZ_META_CUTOFF(m) (((m) >> 23) & 1u)
 #define RZ_META_FAMILY(m) (((m) >> 24) & 3u)
@@ -566,19 +602,54 @@ RZ_DEV void shade_lanes(const PassParams &P, const DrawRec *__restrict__ draw_ta
     }
 }
 
+/* the three corner varying blocks a reference stands for */
+RZ_DEV void ref_varyings(uint32_t ref, const float *__restrict__ vary_table, const float *__restrict__ fan_vary_table,
+                         const float *&m0, const float *&m1, const float *&m2) {
+    if (ref & RZ_REF_FAN) {
+        uint32_t idx = ref & ~RZ_REF_FAN, blk = idx / RZ_MAX_FAN, k = idx % RZ_MAX_FAN;
+        const float *fv = fan_vary_table + (size_t)blk * RZ_MAX_POLY * RZ_VARY_STRIDE;
+        m0 = fv; m1 = fv + (k + 1) * RZ_VARY_STRIDE; m2 = fv + (k + 2) * RZ_VARY_STRIDE;
+    } else {
+        m0 = vary_table + (size_t)(3u * ref) * RZ_VARY_STRIDE; m1 = m0 + RZ_VARY_STRIDE; m2 = m1 + RZ_VARY_STRIDE;
+    }
+}
+
 /* loads the record and varying pointers a fragment reference stands for */
 RZ_DEV void fetch_ref(uint32_t ref, const TriRec *__restrict__ tri_table, const TriRec *__restrict__ fan_table,
                       const float *__restrict__ vary_table, const float *__restrict__ fan_vary_table,
                       TriRec &m, const float *&m0, const float *&m1, const float *&m2) {
-    if (ref & RZ_REF_FAN) {
-        uint32_t idx = ref & ~RZ_REF_FAN, blk = idx / RZ_MAX_FAN, k = idx % RZ_MAX_FAN;
-        m = load_tri(&fan_table[idx]);
-        const float *fv = fan_vary_table + (size_t)blk * RZ_MAX_POLY * RZ_VARY_STRIDE;
-        m0 = fv; m1 = fv + (k + 1) * RZ_VARY_STRIDE; m2 = fv + (k + 2) * RZ_VARY_STRIDE;
-    } else {
-        m = load_tri(&tri_table[ref]);
-        m0 = vary_table + (size_t)(3u * ref) * RZ_VARY_STRIDE; m1 = m0 + RZ_VARY_STRIDE; m2 = m1 + RZ_VARY_STRIDE;
-    }
+    m = load_tri((ref & RZ_REF_FAN) ? &fan_table[ref & ~RZ_REF_FAN] : &tri_table[ref]);
+    ref_varyings(ref, vary_table, fan_vary_table, m0, m1, m2);
+}
+
+/* Conservative "this triangle cannot cover any pixel centre of the block":
+ * each barycentric weight is an affine function of the pixel, so its maximum
+ * over the block sits at a corner; the corner values are computed with the
+ * rasteriser's own expressions, and a weight is taken to be below the
+ * -epsilon threshold everywhere only if it is so at all four corners by more
+ * than a bound on the rounding error of those expressions (16 ulp of the
+ * magnitudes involved, twice: corner and pixel).  NaN compares false, so
+ * degenerate triangles are never rejected here -- the pixel test drops them. */
+RZ_DEV bool block_outside(float4 c0, float4 c1, float x0, float x1, float y0, float y1) {
+    const float ax = c0.x, ay = c0.y, abx = c0.z, aby = c0.w, acx = c1.x, acy = c1.y, factor = c1.z;
+    const float u = 1.9073486e-06f;             /* 2^-19 */
+    float dx0 = x0 - ax, dx1 = x1 - ax, dy0 = y0 - ay, dy1 = y1 - ay;
+    float s00 = (acy * dx0 - acx * dy0) * factor, s10 = (acy * dx1 - acx * dy0) * factor;
+    float s01 = (acy * dx0 - acx * dy1) * factor, s11 = (acy * dx1 - acx * dy1) * factor;
+    float t00 = (abx * dy0 - aby * dx0) * factor, t10 = (abx * dy0 - aby * dx1) * factor;
+    float t01 = (abx * dy1 - aby * dx0) * factor, t11 = (abx * dy1 - aby * dx1) * factor;
+    float mx = fmaxf(fabsf(dx0), fabsf(dx1)), my = fmaxf(fabsf(dy0), fabsf(dy1)), f = fabsf(factor);
+    float es = u * (fabsf(acy) * mx + fabsf(acx) * my) * f;
+    float et = u * (fabsf(abx) * my + fabsf(aby) * mx) * f;
+    float smax = fmaxf(fmaxf(s00, s10), fmaxf(s01, s11)), tmax = fmaxf(fmaxf(t00, t10), fmaxf(t01, t11));
+    float w00 = 1 - s00 - t00, w10 = 1 - s10 - t10, w01 = 1 - s01 - t01, w11 = 1 - s11 - t11;
+    float wmax = fmaxf(fmaxf(w00, w10), fmaxf(w01, w11));
+    float sabs = fmaxf(fmaxf(fabsf(s00), fabsf(s10)), fmaxf(fabsf(s01), fabsf(s11)));
+    float tabs = fmaxf(fmaxf(fabsf(t00), fabsf(t10)), fmaxf(fabsf(t01), fabsf(t11)));
+    float ew = es + et + u * (1 + sabs + tabs);
+    /* all of smax, es, ... finite is required for a rejection */
+    bool finite = (smax - smax == 0) && (tmax - tmax == 0) && (wmax - wmax == 0) && (es - es == 0) && (et - et == 0) && (ew - ew == 0);
+    return finite && (smax + es < -RZ_EPS || tmax + et < -RZ_EPS || wmax + ew < -RZ_EPS);
 }
 
 #define RZ_BCAST_F(v, j) __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), (j)))
@@ -595,32 +666,52 @@ RZ_DEV void fetch_ref(uint32_t ref, const TriRec *__restrict__ tri_table, const 
 template <bool SPLIT>
 __global__ void __launch_bounds__(256) rz_raster_kernel(PassParams P,
         const TriRec *__restrict__ tri_table, const TriRec *__restrict__ fan_table,
-        const uint4 *__restrict__ list_table,
+        const BinEntry *__restrict__ list_table,
         const float *__restrict__ vary_table, const float *__restrict__ fan_vary_table,
-        const DrawRec *__restrict__ draw_table,
-        const uint32_t *__restrict__ bin_start_table, const uint32_t *__restrict__ bin_count_table) {
+        const DrawRec *__restrict__ draw_table, const uint2 *__restrict__ bin_range_table) {
+    /* A workgroup owns a 32x8-pixel tile, wave w its w-th 8x8 block.  Planes
+     * are read and written through LDS so that every global access is a whole
+     * 128-byte row of the tile instead of eight 32-byte pieces. */
+    __shared__ uint32_t s_plane[3][RZ_TILE_H][RZ_TILE_W];
+    if (P.debug_skip == 3) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int tiles_x = (P.width + RZ_TILE - 1) / RZ_TILE;
+    const int tiles_x = (P.width + RZ_TILE_W - 1) / RZ_TILE_W;
     const int tile_x = blockIdx.x % tiles_x, tile_y = blockIdx.x / tiles_x;
-    const int bx0 = tile_x * RZ_TILE + (wave & 1) * 8, by0 = tile_y * RZ_TILE + (wave >> 1) * 8;
-    const int px = bx0 + (lane & 7), py = by0 + (lane >> 3);
+    const int tx0 = tile_x * RZ_TILE_W, ty0 = tile_y * RZ_TILE_H;
+    const int bx0 = tx0 + wave * 8, by0 = ty0;
+    const int lx = wave * 8 + (lane & 7), ly = lane >> 3;      /* position inside the tile */
+    const int px = tx0 + lx, py = ty0 + ly;
     const bool valid = px < P.width && py < P.height;
-    if (bx0 >= P.width || by0 >= P.height) return;             /* whole wave off-screen */
-    const size_t pixel = (size_t)py * P.width + px;
-    const int bin = (by0 / RZ_BIN) * P.bins_x + bx0 / RZ_BIN;
-    const uint32_t count = bin_count_table[bin];
-    if (count == 0 && !P.clear_color_pending && !P.clear_depth_pending) {
-        if (SPLIT && valid) P.ref[pixel] = RZ_REF_NONE;
+    /* row-wise view for global access: this lane moves pixel (rx, ry) of the tile */
+    const int rx = lane & 31, ry = wave * 2 + (lane >> 5);
+    const bool row_valid = tx0 + rx < P.width && ty0 + ry < P.height;
+    const size_t row_pixel = (size_t)(ty0 + ry) * P.width + (tx0 + rx);
+    const int bin = (ty0 / RZ_BIN) * P.bins_x + tx0 / RZ_BIN;
+    const uint2 range = bin_range_table[bin];          /* {first entry, entries} */
+    const uint32_t count = range.y;
+    if (count == 0 && !P.clear_color_pending && !P.clear_depth_pending) {   /* uniform over the workgroup */
+        if (SPLIT && row_valid) P.ref[row_pixel] = RZ_REF_NONE;
         return;
     }
 
     float zcur = 1.0f;
     uint32_t ccur = 0;
-    if (valid) {
-        zcur = P.clear_depth_pending ? P.clear_depth : P.depth[pixel];
-        if (!SPLIT || P.clear_color_pending) ccur = P.clear_color_pending ? P.clear_color : P.color[pixel];
+    {
+        const bool need_color = !SPLIT || P.clear_color_pending;
+        float zrow = P.clear_depth;
+        uint32_t crow = P.clear_color;
+        if (row_valid) {
+            if (!P.clear_depth_pending) zrow = P.depth[row_pixel];
+            if (need_color && !P.clear_color_pending) crow = P.color[row_pixel];
+        }
+        s_plane[0][ry][rx] = __float_as_uint(zrow);
+        s_plane[1][ry][rx] = crow;
+        __syncthreads();
+        zcur = __uint_as_float(s_plane[0][ly][lx]);
+        ccur = s_plane[1][ly][lx];
+        __syncthreads();
     }
-    const uint4 *list = list_table + bin_start_table[bin];
+    const BinEntry *list = list_table + range.x;
     const int bx1 = bx0 + 7, by1 = by0 + 7;
 
     /* per-lane stack of unshaded fragments (see above) */
@@ -632,30 +723,21 @@ __global__ void __launch_bounds__(256) rz_raster_kernel(PassParams P,
     unsigned long long todo = 0;
     uint32_t mine = 0;
     float4 c0 = make_float4(0, 0, 0, 0), c1 = c0, c2 = c0, c3 = c0;    /* this lane's candidate record */
-    uint32_t fan_block = 0;
-    int fan_k = 0, fan_n = 0;
     bool have = false, exhausted = false;
     TriRec r;
     uint32_t ref = 0;
-    const float *v0 = nullptr, *v1 = nullptr, *v2 = nullptr;
+    /* block corners at pixel centres, for the conservative triangle/block test */
+    const float cx0 = (float)bx0 + 0.5f, cx1 = (float)bx0 + 7.5f, cy0 = (float)by0 + 0.5f, cy1 = (float)by0 + 7.5f;
 
     while (true) {
         /* ---- phase A: coverage + depth, until the list ends or a stack is full */
         bool stack_full = false;
         while (true) {
             if (!have) {
-                if (fan_k < fan_n) {
-                    uint32_t idx = fan_block * RZ_MAX_FAN + (uint32_t)fan_k;
-                    r = load_tri(&fan_table[idx]);
-                    ref = RZ_REF_FAN | idx;
-                    const float *fv = fan_vary_table + (size_t)fan_block * RZ_MAX_POLY * RZ_VARY_STRIDE;
-                    v0 = fv; v1 = fv + (fan_k + 1) * RZ_VARY_STRIDE; v2 = fv + (fan_k + 2) * RZ_VARY_STRIDE;
-                    fan_k++;
-                    have = true;
-                } else if (todo) {
+                if (todo) {
                     int j = __ffsll((long long)todo) - 1;
                     todo &= todo - 1;
-                    uint32_t t = (uint32_t)__builtin_amdgcn_readlane((int)mine, j);
+                    ref = (uint32_t)__builtin_amdgcn_readlane((int)mine, j);
                     r.ax = RZ_BCAST_F(c0.x, j); r.ay = RZ_BCAST_F(c0.y, j); r.abx = RZ_BCAST_F(c0.z, j); r.aby = RZ_BCAST_F(c0.w, j);
                     r.acx = RZ_BCAST_F(c1.x, j); r.acy = RZ_BCAST_F(c1.y, j); r.factor = RZ_BCAST_F(c1.z, j); r.z[0] = RZ_BCAST_F(c1.w, j);
                     r.z[1] = RZ_BCAST_F(c2.x, j); r.z[2] = RZ_BCAST_F(c2.y, j); r.rw[0] = RZ_BCAST_F(c2.z, j); r.rw[1] = RZ_BCAST_F(c2.w, j);
@@ -663,27 +745,18 @@ __global__ void __launch_bounds__(256) rz_raster_kernel(PassParams P,
                     r.meta = (uint32_t)__builtin_amdgcn_readlane(__float_as_int(c3.y), j);
                     r.bx = (uint32_t)__builtin_amdgcn_readlane(__float_as_int(c3.z), j);
                     r.by = (uint32_t)__builtin_amdgcn_readlane(__float_as_int(c3.w), j);
-                    if (RZ_META_CLIPPED(r.meta)) {
-                        fan_block = __float_as_uint(r.ax);
-                        fan_n = (int)RZ_META_FAN(r.meta);
-                        fan_k = 0;
-                        continue;
-                    }
-                    ref = t;
-                    v0 = vary_table + (size_t)(3u * t) * RZ_VARY_STRIDE; v1 = v0 + RZ_VARY_STRIDE; v2 = v1 + RZ_VARY_STRIDE;
                     have = true;
                 } else {
-                    if (base >= count) { exhausted = true; break; }
+                    if (base >= count || P.debug_skip == 4) { exhausted = true; break; }
                     bool hit = false;
                     mine = 0;
                     if (base + lane < count) {
-                        uint4 e = list[base + lane];            /* triangle index and its bounding box */
-                        mine = e.x;
-                        hit = box_overlaps(make_uint2(e.y, e.z), bx0, by0, bx1, by1);
-                    }
-                    if (hit) {
-                        const float4 *src = (const float4*)&tri_table[mine];
-                        c0 = src[0]; c1 = src[1]; c2 = src[2]; c3 = src[3];
+                        const float4 *e = (const float4*)&list[base + lane];    /* reference + record, 80 bytes */
+                        float4 head = e[0];
+                        c0 = e[1]; c1 = e[2]; c2 = e[3]; c3 = e[4];
+                        mine = __float_as_uint(head.x);
+                        hit = box_overlaps(make_uint2(__float_as_uint(c3.z), __float_as_uint(c3.w)), bx0, by0, bx1, by1);
+                        if (hit) hit = !block_outside(c0, c1, cx0, cx1, cy0, cy1);
                     }
                     todo = __ballot(hit);
                     base += 64u;
@@ -716,6 +789,8 @@ __global__ void __launch_bounds__(256) rz_raster_kernel(PassParams P,
                  * alpha = base alpha * first map's alpha, from the interpolated texcoord */
                 const DrawRec &D = draw_table[RZ_META_DRAW(r.meta)];
                 const int tc = D.family == 0 ? 6 : 19;
+                const float *v0, *v1, *v2;
+                ref_varyings(ref, vary_table, fan_vary_table, v0, v1, v2);
                 float q0 = r.rw[0] * w0, q1 = r.rw[1] * w1, q2 = r.rw[2] * w2;
                 float norm = 1 / (q0 + q1 + q2);
                 float tu = (v0[tc] * q0 + v1[tc] * q1 + v2[tc] * q2) * norm;
@@ -750,13 +825,17 @@ __global__ void __launch_bounds__(256) rz_raster_kernel(PassParams P,
         if (exhausted || !stack_full) break;
     }
 
-    if (valid) {
-        P.depth[pixel] = zcur;
+    s_plane[0][ly][lx] = __float_as_uint(zcur);
+    s_plane[1][ly][lx] = ccur;
+    s_plane[2][ly][lx] = depth_of_stack ? ref0 : RZ_REF_NONE;
+    __syncthreads();
+    if (row_valid) {
+        P.depth[row_pixel] = __uint_as_float(s_plane[0][ry][rx]);
         if (SPLIT) {
-            P.ref[pixel] = depth_of_stack ? ref0 : RZ_REF_NONE;
-            if (P.clear_color_pending) P.color[pixel] = ccur;
+            P.ref[row_pixel] = s_plane[2][ry][rx];
+            if (P.clear_color_pending) P.color[row_pixel] = s_plane[1][ry][rx];
         } else {
-            P.color[pixel] = ccur;
+            P.color[row_pixel] = s_plane[1][ry][rx];
         }
     }
 }
@@ -768,27 +847,41 @@ __global__ void __launch_bounds__(256) rz_shade_kernel(PassParams P,
         const TriRec *__restrict__ tri_table, const TriRec *__restrict__ fan_table,
         const float *__restrict__ vary_table, const float *__restrict__ fan_vary_table,
         const DrawRec *__restrict__ draw_table, const uint32_t *__restrict__ ref_table) {
+    __shared__ uint32_t s_plane[2][RZ_TILE_H][RZ_TILE_W];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int tiles_x = (P.width + RZ_TILE - 1) / RZ_TILE;
+    const int tiles_x = (P.width + RZ_TILE_W - 1) / RZ_TILE_W;
     const int tile_x = blockIdx.x % tiles_x, tile_y = blockIdx.x / tiles_x;
-    const int bx0 = tile_x * RZ_TILE + (wave & 1) * 8, by0 = tile_y * RZ_TILE + (wave >> 1) * 8;
-    const int px = bx0 + (lane & 7), py = by0 + (lane >> 3);
-    const bool valid = px < P.width && py < P.height;
-    if (bx0 >= P.width || by0 >= P.height) return;
-    const size_t pixel = (size_t)py * P.width + px;
-    uint32_t myref = valid ? ref_table[pixel] : RZ_REF_NONE;
-    bool want = myref != RZ_REF_NONE && P.debug_skip == 0;
-    if (!__any(want)) return;
+    const int tx0 = tile_x * RZ_TILE_W, ty0 = tile_y * RZ_TILE_H;
+    const int lx = wave * 8 + (lane & 7), ly = lane >> 3;
+    const int px = tx0 + lx, py = ty0 + ly;
+    const int rx = lane & 31, ry = wave * 2 + (lane >> 5);
+    const bool row_valid = tx0 + rx < P.width && ty0 + ry < P.height;
+    const size_t row_pixel = (size_t)(ty0 + ry) * P.width + (tx0 + rx);
+    /* whole rows of the tile in, 8x8 blocks out of LDS */
+    uint32_t ref_row = row_valid ? ref_table[row_pixel] : RZ_REF_NONE;
+    if (P.debug_skip) ref_row = RZ_REF_NONE;
+    s_plane[0][ry][rx] = ref_row;
+    const bool tile_has_work = __syncthreads_or(ref_row != RZ_REF_NONE) != 0;
+    if (!tile_has_work) return;
+    const uint32_t myref = s_plane[0][ly][lx];
+    bool want = myref != RZ_REF_NONE;
     TriRec m;
     const float *m0 = vary_table, *m1 = vary_table, *m2 = vary_table;
     if (want) {
         fetch_ref(myref, tri_table, fan_table, vary_table, fan_vary_table, m, m0, m1, m2);
         want = RZ_META_FAMILY(m.meta) == (uint32_t)FAMILY;
     }
-    if (!__any(want)) return;
-    uint32_t ccur = want ? P.color[pixel] : 0u;
-    shade_lanes<FAMILY>(P, draw_table, want, m, m0, m1, m2, px, py, ccur);
-    if (want) P.color[pixel] = ccur;
+    const bool tile_has_family = __syncthreads_or(want) != 0;
+    if (!tile_has_family) return;
+    s_plane[1][ry][rx] = row_valid ? P.color[row_pixel] : 0u;
+    __syncthreads();
+    uint32_t ccur = s_plane[1][ly][lx];
+    if (__any(want)) shade_lanes<FAMILY>(P, draw_table, want, m, m0, m1, m2, px, py, ccur);
+    __syncthreads();
+    s_plane[1][ly][lx] = ccur;
+    s_plane[0][ly][lx] = want ? 1u : 0u;
+    __syncthreads();
+    if (row_valid && s_plane[0][ry][rx]) P.color[row_pixel] = s_plane[1][ry][rx];
 }
 
 /* ========================================================================

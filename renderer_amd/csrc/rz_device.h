@@ -27,7 +27,8 @@
 #define RZ_MAX_POLY 10              /* corners of a triangle clipped by 7 planes */
 #define RZ_MAX_FAN 8                /* RZ_MAX_POLY - 2 */
 #define RZ_BIN 64                   /* bin edge in pixels */
-#define RZ_TILE 16                  /* raster workgroup tile edge (4 waves of 8x8) */
+#define RZ_TILE_W 32                /* raster / shade workgroup tile: 4 waves of 8x8 side by side, */
+#define RZ_TILE_H 8                 /* so a tile row is one 128-byte line of a 4-byte plane */
 
 enum { RZ_FMT_RGBA32F = 0, RZ_FMT_R32F = 1 };
 enum { RZ_TEX_MORTON = 1, RZ_TEX_R32F = 2 };
@@ -105,6 +106,14 @@ struct TriRec {
     uint32_t bx, by;                /* own bounding box: min | max << 16 */
 };
 
+/* One bin-list entry: the triangle's index and a copy of its record, so the
+ * rasteriser needs a single memory round trip per 64 candidates. */
+struct BinEntry {
+    uint32_t tri;
+    uint32_t pad[3];
+    TriRec rec;
+};
+
 #define RZ_META_DRAW(m) ((m) & 0xffffu)
 #define RZ_META_BACKFACE(m) (((m) >> 16) & 1u)
 #define RZ_META_CLIPPED(m) (((m) >> 17) & 1u)
@@ -133,8 +142,8 @@ struct PassParams {
     uint32_t *clip_list;            /* triangles queued for the clipper (count in control[3]) */
     /* binning */
     int32_t bins_x, bins_y;
-    uint32_t *bin_start, *bin_count;
-    uint4 *bin_list;                /* {triangle, bbox x, bbox y, 0} per entry */
+    uint2 *bin_range;               /* per bin: {first entry, entries} */
+    BinEntry *bin_list;
     uint32_t bin_capacity;
     uint32_t *ref;                  /* per pixel: reference of the visible fragment (split passes) */
     /* scalars written by the device: [0] fan blocks used, [1] bin entries
