@@ -120,6 +120,7 @@ struct Lane {
     DevBuf<BinEntry> bin_list;
 };
 
+static const size_t MAX_BATCH = 64;     /* passes per launch sequence, upper bound */
 static const int MAX_LANES = 8;
 
 struct Context {
@@ -129,6 +130,7 @@ struct Context {
     hipStream_t copy_stream = nullptr;  /* table uploads / control read-back of a flush */
     Lane lanes[MAX_LANES];
     int num_lanes = 1, next_lane = 0;
+    size_t max_batch = 16;                  /* passes per launch sequence */
     std::vector<hipEvent_t> events;     /* recorded since the last full sync */
     std::vector<Tex*> current_gpu_textures;
     /* upload ring: pinned host memory mirrored 1:1 in device memory */
@@ -149,6 +151,7 @@ struct Context {
     /* measurement */
     bool timing = false;
     std::vector<hipEvent_t> timing_events;  /* 6 per pass: before vertex, after vertex/setup/bin/raster/shade */
+    std::vector<unsigned> timing_passes;    /* passes per timed launch sequence */
     double kernel_ms[5] = {0, 0, 0, 0, 0};
     unsigned long long kernel_launches = 0;
     bool counting = false;
@@ -208,6 +211,8 @@ extern "C" int mi355r_init(int device) {
         g.num_lanes = env ? atoi(env) : 4;
         if (g.num_lanes < 1) g.num_lanes = 1;
         if (g.num_lanes > MAX_LANES) g.num_lanes = MAX_LANES;
+        env = getenv("MI355R_BATCH");
+        if (env && atoi(env) >= 1) g.max_batch = std::min<size_t>((size_t)atoi(env), MAX_BATCH);
     }
     for (int i = 0; i < g.num_lanes; i++) HIP_OK(hipStreamCreateWithFlags(&g.lanes[i].stream, hipStreamNonBlocking));
     HIP_OK(hipStreamCreateWithFlags(&g.copy_stream, hipStreamNonBlocking));
@@ -859,6 +864,9 @@ struct PassPlan {
     size_t T;                       /* triangles */
     size_t off_draws, off_first;    /* offsets from the region start */
     std::vector<size_t> side_at, verts_at;
+    bool has_blend, samples_gpu_texture;
+    int families;
+    Fb *fb;
 };
 
 static const size_t CONTROL_BYTES = 64;
@@ -866,9 +874,19 @@ static const size_t CONTROL_BYTES = 64;
 static void plan_pass(PassPlan &pl, size_t &total) {
     const size_t D = pl.last - pl.first;
     pl.T = 0;
-    for (size_t i = pl.first; i < pl.last; i++) pl.T += (size_t)g.pending[i].rec.num_faces;
+    pl.has_blend = pl.samples_gpu_texture = false;
+    pl.families = 0;
+    pl.fb = g.pending[pl.first].fb;
+    for (size_t i = pl.first; i < pl.last; i++) {
+        const Pending &pd = g.pending[i];
+        pl.T += (size_t)pd.rec.num_faces;
+        pl.has_blend |= (pd.rec.flags & RZ_DRAW_BLEND) != 0;
+        pl.samples_gpu_texture |= !pd.gpu_textures.empty();
+        pl.families |= 1 << pd.rec.family;
+    }
+    if (getenv("MI355R_MONOLITHIC")) pl.has_blend = true;
     if (D > 65535) fatal("%zu draws in one pass (limit 65535)", D);
-    if (pl.T > 0x3fffffffu) fatal("%zu triangles in one pass", pl.T);
+    if (pl.T > 0x0fffffffu) fatal("%zu triangles in one pass", pl.T);
     total = (total + 255) & ~(size_t)255;
     pl.off_draws = total;
     total += sizeof(DrawRec) * D;
@@ -918,116 +936,169 @@ static void fill_pass(const PassPlan &pl, char *hb, char *db) {
     first_tri[D] = running;
 }
 
-static void launch_pass(const PassPlan &pl, char *db, uint32_t *control, Lane &L) {
-    Fb *fb = g.pending[pl.first].fb;
+/* A batch: passes that do not depend on each other and run in ONE launch
+ * sequence (grid y = pass), on one lane. */
+struct Batch {
+    size_t first, last;             /* range in the flush's plan list */
+    int lane;
+    size_t off_params;              /* PassParams[] in the upload region */
+    bool has_blend;
+    int families;
+};
+
+/* sizes the lane's scratch for the batch and (second call) writes the PassParams array */
+static void prepare_batch(const Batch &b, const std::vector<PassPlan> &plans, char *hb, char *db, size_t controls_at,
+                          bool reserve_only) {
+    Lane &L = g.lanes[b.lane];
     hipStream_t st = L.stream;
-    const size_t D = pl.last - pl.first, T = pl.T;
-    const int W = fb->pub.width, H = fb->pub.height;
-    const int bins_x = (W + RZ_BIN - 1) / RZ_BIN, bins_y = (H + RZ_BIN - 1) / RZ_BIN;
-    const size_t bins = (size_t)bins_x * bins_y;
-    const size_t fan_cap = std::min<size_t>(T, 1u << 18);
-    const size_t list_cap = std::min<size_t>(T * bins, std::max<size_t>(T * 16, 1u << 20));
-    reserve(L.clip, T * 3 * 4, st);
-    reserve(L.vary, T * 3 * RZ_VARY_STRIDE, st);
-    reserve(L.tri, T, st);
-    reserve(L.bbox, T, st);
-    reserve(L.clip_list, T, st);
-    reserve(L.fan_tri, fan_cap * RZ_MAX_FAN, st);
-    reserve(L.fan_vary, fan_cap * RZ_MAX_POLY * RZ_VARY_STRIDE, st);
-    reserve(L.bin_range, bins, st);
-    reserve(L.bin_list, list_cap, st);
-    bool has_blend = false;
-    int families = 0;
-    for (size_t i = pl.first; i < pl.last; i++) {
-        has_blend |= (g.pending[i].rec.flags & RZ_DRAW_BLEND) != 0;
-        families |= 1 << g.pending[i].rec.family;
+    size_t tris = 0, fans = 0, lists = 0, bins = 0, pixels = 0;
+    std::vector<size_t> fan_cap, list_cap;
+    for (size_t i = b.first; i < b.last; i++) {
+        const PassPlan &pl = plans[i];
+        const size_t nb = (size_t)((pl.fb->pub.width + RZ_BIN - 1) / RZ_BIN) * ((pl.fb->pub.height + RZ_BIN - 1) / RZ_BIN);
+        fan_cap.push_back(std::min<size_t>(pl.T, 1u << 18));
+        list_cap.push_back(std::min<size_t>(pl.T * 8 * nb, std::max<size_t>(pl.T * 16, 1u << 18)));
+        tris += pl.T; fans += fan_cap.back(); lists += list_cap.back(); bins += nb;
+        pixels += (size_t)pl.fb->pub.width * pl.fb->pub.height;
     }
-    if (getenv("MI355R_MONOLITHIC")) has_blend = true;
-    if (!has_blend) reserve(L.ref, (size_t)W * H, st);
+    reserve(L.clip, tris * 3 * 4, st);
+    reserve(L.vary, tris * 3 * RZ_VARY_STRIDE, st);
+    reserve(L.tri, tris, st);
+    reserve(L.bbox, tris, st);
+    reserve(L.clip_list, tris, st);
+    reserve(L.fan_tri, fans * RZ_MAX_FAN, st);
+    reserve(L.fan_vary, fans * RZ_MAX_POLY * RZ_VARY_STRIDE, st);
+    reserve(L.bin_range, bins, st);
+    reserve(L.bin_list, lists, st);
+    if (!b.has_blend) reserve(L.ref, pixels, st);
+    if (reserve_only) return;
 
-    PassParams P;
-    memset(&P, 0, sizeof P);
-    P.color = fb->d_color;
-    P.depth = fb->d_depth;
-    P.width = W;
-    P.height = H;
-    P.clear_color_pending = fb->clear_color_pending;
-    P.clear_depth_pending = fb->clear_depth_pending;
-    P.clear_color = fb->clear_color;
-    P.clear_depth = fb->clear_depth;
-    P.draws = (const DrawRec*)(db + pl.off_draws);
-    P.first_tri = (const uint32_t*)(db + pl.off_first);
-    P.num_draws = (int)D;
-    P.num_tris = (int)T;
-    P.clip = L.clip.ptr;
-    P.vary = L.vary.ptr;
-    P.tri = L.tri.ptr;
-    P.bbox = L.bbox.ptr;
-    P.fan_tri = L.fan_tri.ptr;
-    P.fan_vary = L.fan_vary.ptr;
-    P.fan_capacity = (int)fan_cap;
-    P.clip_list = L.clip_list.ptr;
-    P.bins_x = bins_x;
-    P.bins_y = bins_y;
-    P.bin_range = L.bin_range.ptr;
-    P.bin_list = L.bin_list.ptr;
-    P.bin_capacity = (uint32_t)list_cap;
-    P.ref = L.ref.ptr;
-    P.control = control;
-    P.counters = g.counting ? g.d_counters : nullptr;
-    { const char *dbg = getenv("MI355R_DEBUG_SKIP"); P.debug_skip = dbg ? atoi(dbg) : 0; }
+    size_t tri_off = 0, fan_off = 0, list_off = 0, bin_off = 0, ref_off = 0;
+    const char *dbg = getenv("MI355R_DEBUG_SKIP");
+    for (size_t i = b.first; i < b.last; i++) {
+        const PassPlan &pl = plans[i];
+        Fb *fb = pl.fb;
+        const size_t k = i - b.first;
+        const int W = fb->pub.width, H = fb->pub.height;
+        PassParams P;
+        memset(&P, 0, sizeof P);
+        P.color = fb->d_color;
+        P.depth = fb->d_depth;
+        P.width = W;
+        P.height = H;
+        P.clear_color_pending = fb->clear_color_pending;
+        P.clear_depth_pending = fb->clear_depth_pending;
+        P.clear_color = fb->clear_color;
+        P.clear_depth = fb->clear_depth;
+        P.draws = (const DrawRec*)(db + pl.off_draws);
+        P.first_tri = (const uint32_t*)(db + pl.off_first);
+        P.num_draws = (int)(pl.last - pl.first);
+        P.num_tris = (int)pl.T;
+        P.clip = L.clip.ptr + tri_off * 3 * 4;
+        P.vary = L.vary.ptr + tri_off * 3 * RZ_VARY_STRIDE;
+        P.tri = L.tri.ptr + tri_off;
+        P.bbox = L.bbox.ptr + tri_off;
+        P.clip_list = L.clip_list.ptr + tri_off;
+        P.fan_tri = L.fan_tri.ptr + fan_off * RZ_MAX_FAN;
+        P.fan_vary = L.fan_vary.ptr + fan_off * RZ_MAX_POLY * RZ_VARY_STRIDE;
+        P.fan_capacity = (int)fan_cap[k];
+        P.bins_x = (W + RZ_BIN - 1) / RZ_BIN;
+        P.bins_y = (H + RZ_BIN - 1) / RZ_BIN;
+        P.bin_range = L.bin_range.ptr + bin_off;
+        P.bin_list = L.bin_list.ptr + list_off;
+        P.bin_capacity = (uint32_t)list_cap[k];
+        P.ref = L.ref.ptr ? L.ref.ptr + ref_off : nullptr;
+        P.control = (uint32_t*)(db + controls_at + CONTROL_BYTES * i);
+        P.counters = g.counting ? g.d_counters : nullptr;
+        P.debug_skip = dbg ? atoi(dbg) : 0;
+        P.num_tiles = ((W + RZ_TILE_W - 1) / RZ_TILE_W) * ((H + RZ_TILE_H - 1) / RZ_TILE_H);
+        P.tri_off = (uint32_t)tri_off;
+        P.fan_off = (uint32_t)fan_off;
+        P.list_off = (uint32_t)list_off;
+        P.bin_off = (uint32_t)bin_off;
+        P.ref_off = ref_off;
+        P.draws_off = pl.off_draws;
+        memcpy(hb + b.off_params + sizeof(PassParams) * k, &P, sizeof P);
+        tri_off += pl.T; fan_off += fan_cap[k]; list_off += list_cap[k];
+        bin_off += (size_t)P.bins_x * P.bins_y;
+        ref_off += (size_t)W * H;
+        fb->clear_color_pending = fb->clear_depth_pending = false;
+        g.host_counters[0] += pl.T;
+        g.host_counters[4] += 1;
+        g.host_counters[5] += (unsigned long long)(pl.last - pl.first);
+    }
+}
 
-    const unsigned vblocks = (unsigned)((T * 3 + 255) / 256), tblocks = (unsigned)((T + 255) / 256);
-    const int tiles_x = (W + RZ_TILE_W - 1) / RZ_TILE_W, tiles_y = (H + RZ_TILE_H - 1) / RZ_TILE_H;
+static void launch_batch(const Batch &b, const std::vector<PassPlan> &plans, char *db) {
+    Lane &L = g.lanes[b.lane];
+    hipStream_t st = L.stream;
+    const unsigned n = (unsigned)(b.last - b.first);
+    size_t max_T = 0, max_bins = 0, max_tiles = 0;
+    for (size_t i = b.first; i < b.last; i++) {
+        const PassPlan &pl = plans[i];
+        const int W = pl.fb->pub.width, H = pl.fb->pub.height;
+        max_T = std::max(max_T, pl.T);
+        max_bins = std::max(max_bins, (size_t)((W + RZ_BIN - 1) / RZ_BIN) * ((H + RZ_BIN - 1) / RZ_BIN));
+        max_tiles = std::max(max_tiles, (size_t)((W + RZ_TILE_W - 1) / RZ_TILE_W) * ((H + RZ_TILE_H - 1) / RZ_TILE_H));
+    }
+    const PassParams *passes = (const PassParams*)(db + b.off_params);
+    static const bool paranoid = getenv("MI355R_SYNC") != nullptr;     /* debugging: fence + check after every kernel */
+    int stage = 0;
     auto stamp = [&]() {
+        if (paranoid) {
+            hipError_t err = hipStreamSynchronize(st);
+            if (err != hipSuccess)
+                fatal("kernel stage %d of batch [%zu, %zu) on lane %d failed: %s", stage, b.first, b.last, b.lane, hipGetErrorString(err));
+            stage++;
+        }
         if (!g.timing) return;
         hipEvent_t e;
         HIP_OK(hipEventCreate(&e));
         HIP_OK(hipEventRecord(e, st));
         g.timing_events.push_back(e);
     };
+    const dim3 vgrid((unsigned)((max_T * 3 + 255) / 256), n), tgrid((unsigned)((max_T + 255) / 256), n);
+    const dim3 tiles((unsigned)max_tiles, n);
     stamp();
-    rz_vertex_kernel<<<dim3(vblocks), dim3(256), 0, st>>>(P);
+    rz_vertex_kernel<<<vgrid, dim3(256), 0, st>>>(passes);
     stamp();
-    rz_setup_kernel<<<dim3(tblocks), dim3(256), 0, st>>>(P);
-    rz_clip_kernel<<<dim3(256), dim3(64), 0, st>>>(P);
+    rz_setup_kernel<<<tgrid, dim3(256), 0, st>>>(passes);
+    rz_clip_kernel<<<dim3(256, n), dim3(64), 0, st>>>(passes);
     stamp();
-    rz_bin_kernel<<<dim3((unsigned)bins), dim3(RZ_BIN_WAVES * 64), 0, st>>>(P);
+    rz_bin_kernel<<<dim3((unsigned)max_bins, n), dim3(RZ_BIN_WAVES * 64), 0, st>>>(passes);
     stamp();
-    const dim3 tiles((unsigned)(tiles_x * tiles_y));
-    if (has_blend) {
+    if (b.has_blend) {
         /* blended fragments read the colour below them: visibility and shading stay in one kernel */
         rz_raster_kernel<false><<<tiles, dim3(256), 0, st>>>(
-            P, P.tri, P.fan_tri, P.bin_list, P.vary, P.fan_vary, P.draws, P.bin_range);
+            passes, L.tri.ptr, L.fan_tri.ptr, L.bin_list.ptr, L.vary.ptr, L.fan_vary.ptr, db, L.bin_range.ptr);
         stamp();
     } else {
         rz_raster_kernel<true><<<tiles, dim3(256), 0, st>>>(
-            P, P.tri, P.fan_tri, P.bin_list, P.vary, P.fan_vary, P.draws, P.bin_range);
+            passes, L.tri.ptr, L.fan_tri.ptr, L.bin_list.ptr, L.vary.ptr, L.fan_vary.ptr, db, L.bin_range.ptr);
         stamp();
-        if (families & (1 << RZ_FAMILY_SKYBOX))
-            rz_shade_kernel<2><<<tiles, dim3(256), 0, st>>>(P, P.tri, P.fan_tri, P.vary, P.fan_vary, P.draws, P.ref);
-        if (families & (1 << RZ_FAMILY_BLINN))
-            rz_shade_kernel<0><<<tiles, dim3(256), 0, st>>>(P, P.tri, P.fan_tri, P.vary, P.fan_vary, P.draws, P.ref);
-        if (families & (1 << RZ_FAMILY_PBR))
-            rz_shade_kernel<1><<<tiles, dim3(256), 0, st>>>(P, P.tri, P.fan_tri, P.vary, P.fan_vary, P.draws, P.ref);
+        if (b.families & (1 << RZ_FAMILY_SKYBOX))
+            rz_shade_kernel<2><<<tiles, dim3(256), 0, st>>>(passes, L.tri.ptr, L.fan_tri.ptr, L.vary.ptr, L.fan_vary.ptr, db, L.ref.ptr);
+        if (b.families & (1 << RZ_FAMILY_BLINN))
+            rz_shade_kernel<0><<<tiles, dim3(256), 0, st>>>(passes, L.tri.ptr, L.fan_tri.ptr, L.vary.ptr, L.fan_vary.ptr, db, L.ref.ptr);
+        if (b.families & (1 << RZ_FAMILY_PBR))
+            rz_shade_kernel<1><<<tiles, dim3(256), 0, st>>>(passes, L.tri.ptr, L.fan_tri.ptr, L.vary.ptr, L.fan_vary.ptr, db, L.ref.ptr);
     }
     stamp();
     HIP_OK(hipGetLastError());
-
-    fb->clear_color_pending = fb->clear_depth_pending = false;
-    g.host_counters[0] += T;
-    g.host_counters[4] += 1;
-    g.host_counters[5] += (unsigned long long)D;
+    if (g.timing) g.timing_passes.push_back(n);
 }
 
-/* One upload region per flush: [control block per pass][pass 0 tables][pass 1 tables]...
+/* One upload region per flush:
+ *   [control block per pass][PassParams per pass][pass 0 tables][pass 1 tables]...
  * -> one host-to-device copy in front of the kernels and one small copy of the
  * control blocks back behind them, whatever the number of passes.
  *
- * Scheduling: a pass runs on the lane its framebuffer last ran on (passes into
- * one framebuffer must stay ordered), a framebuffer without history takes the
- * next lane in turn.  Textures written on the GPU order passes across lanes
- * through events. */
+ * Passes are grouped into batches (one launch sequence each): a pass joins the
+ * running batch unless its framebuffer is already in it, it samples a texture
+ * some pass wrote on the GPU (shadow maps), or it needs the other rasteriser.
+ * A batch runs on the lane of its first framebuffer (passes into one
+ * framebuffer must stay ordered), or the next lane in turn; framebuffers and
+ * GPU-written textures that come from other lanes are ordered by events. */
 extern "C" void graphics_flush(void) {
     if (!g.ready || g.pending.empty()) return;
     std::vector<PassPlan> plans;
@@ -1041,35 +1112,67 @@ extern "C" void graphics_flush(void) {
         plans.push_back(std::move(pl));
         first = last;
     }
+    const size_t controls_at = 0;
     size_t total = CONTROL_BYTES * plans.size();
+    total = (total + 255) & ~(size_t)255;
+    const size_t params_at = total;
+    total += sizeof(PassParams) * plans.size();
     for (auto &pl : plans) plan_pass(pl, total);
+
+    /* batches and lanes */
+    const int lanes = g.timing ? 1 : g.num_lanes;      /* per-kernel timing wants kernels alone on the GPU */
+    std::vector<Batch> batches;
+    for (size_t i = 0; i < plans.size();) {
+        Batch b;
+        b.first = i;
+        b.has_blend = plans[i].has_blend;
+        b.families = 0;
+        std::vector<Fb*> members;
+        size_t j = i;
+        while (j < plans.size() && j - i < g.max_batch) {
+            const PassPlan &pl = plans[j];
+            if (j > i && (pl.has_blend != b.has_blend || pl.samples_gpu_texture ||
+                          std::find(members.begin(), members.end(), pl.fb) != members.end())) break;
+            members.push_back(pl.fb);
+            b.families |= pl.families;
+            j++;
+            if (pl.samples_gpu_texture) break;          /* ordered by events on its own */
+        }
+        b.last = j;
+        b.off_params = params_at + sizeof(PassParams) * i;
+        int lane = plans[i].fb->lane;
+        if (lane < 0 || lane >= lanes) { lane = g.next_lane % lanes; g.next_lane = (g.next_lane + 1) % lanes; }
+        b.lane = lane;
+        batches.push_back(b);
+        i = j;
+    }
+
     size_t at = ring_alloc(total);
     char *hb = g.ring_host + at, *db = g.ring_dev + at;
     for (auto &pl : plans) fill_pass(pl, hb, db);
-    size_t head = (CONTROL_BYTES * plans.size() + 255) & ~(size_t)255;
-    HIP_OK(hipMemcpyAsync(db + head, hb + head, total - head, hipMemcpyHostToDevice, g.copy_stream));
+    /* scratch first, for every batch: growing a buffer moves it, and the tables written next hold its address */
+    for (auto &b : batches) prepare_batch(b, plans, hb, db, controls_at, true);
+    for (auto &b : batches) prepare_batch(b, plans, hb, db, controls_at, false);
+    HIP_OK(hipMemcpyAsync(db + params_at, hb + params_at, total - params_at, hipMemcpyHostToDevice, g.copy_stream));
     hipEvent_t uploaded = new_event(g.copy_stream);
 
-    const int lanes = g.timing ? 1 : g.num_lanes;      /* per-kernel timing wants kernels alone on the GPU */
     bool used[MAX_LANES] = {false};
-    for (size_t i = 0; i < plans.size(); i++) {
-        const PassPlan &pl = plans[i];
-        Fb *fb = g.pending[pl.first].fb;
-        int lane = fb->lane;
-        if (lane < 0 || lane >= lanes) { lane = g.next_lane % lanes; g.next_lane = (g.next_lane + 1) % lanes; }
-        Lane &L = g.lanes[lane];
-        if (fb->lane >= 0 && fb->lane != lane) {        /* lane count changed (timing mode): order by hand */
-            HIP_OK(hipStreamWaitEvent(L.stream, new_event(g.lanes[fb->lane].stream), 0));
-        }
-        if (!used[lane]) { HIP_OK(hipStreamWaitEvent(L.stream, uploaded, 0)); used[lane] = true; }
+    for (auto &b : batches) {
+        Lane &L = g.lanes[b.lane];
+        if (!used[b.lane]) { HIP_OK(hipStreamWaitEvent(L.stream, uploaded, 0)); used[b.lane] = true; }
         std::vector<Tex*> sampled;
-        for (size_t d = pl.first; d < pl.last; d++)
-            for (Tex *t : g.pending[d].gpu_textures)
-                if (std::find(sampled.begin(), sampled.end(), t) == sampled.end()) sampled.push_back(t);
+        for (size_t i = b.first; i < b.last; i++) {
+            const PassPlan &pl = plans[i];
+            if (pl.fb->lane >= 0 && pl.fb->lane != b.lane)      /* last touched on another lane */
+                HIP_OK(hipStreamWaitEvent(L.stream, new_event(g.lanes[pl.fb->lane].stream), 0));
+            pl.fb->lane = b.lane;
+            for (size_t d = pl.first; d < pl.last; d++)
+                for (Tex *t : g.pending[d].gpu_textures)
+                    if (std::find(sampled.begin(), sampled.end(), t) == sampled.end()) sampled.push_back(t);
+        }
         for (Tex *t : sampled)
-            if (t->write_event && t->write_lane != lane) HIP_OK(hipStreamWaitEvent(L.stream, t->write_event, 0));
-        fb->lane = lane;
-        launch_pass(pl, db, (uint32_t*)(db + CONTROL_BYTES * i), L);
+            if (t->write_event && t->write_lane != b.lane) HIP_OK(hipStreamWaitEvent(L.stream, t->write_event, 0));
+        launch_batch(b, plans, db);
         if (!sampled.empty()) {
             hipEvent_t done = new_event(L.stream);
             for (Tex *t : sampled) t->read_events.push_back(done);
@@ -1132,14 +1235,15 @@ extern "C" unsigned long long mi355r_get_timing(double out_ms[5], int reset) {
     ensure_ready();
     graphics_flush();
     sync_stream();
-    for (size_t i = 0; i + 5 < g.timing_events.size(); i += 6) {
+    for (size_t i = 0, b = 0; i + 5 < g.timing_events.size(); i += 6, b++) {
         for (int k = 0; k < 5; k++) {
             float ms = 0;
             HIP_OK(hipEventElapsedTime(&ms, g.timing_events[i + k], g.timing_events[i + k + 1]));
             g.kernel_ms[k] += ms;
         }
-        g.kernel_launches++;
+        g.kernel_launches += b < g.timing_passes.size() ? g.timing_passes[b] : 1;
     }
+    g.timing_passes.clear();
     for (hipEvent_t e : g.timing_events) HIP_OK(hipEventDestroy(e));
     g.timing_events.clear();
     for (int k = 0; k < 5; k++) out_ms[k] = g.kernel_ms[k];

@@ -58,7 +58,8 @@ RZ_DEV void mat_mul(const float *a, const float *b, float *c) {
     }
 }
 
-__global__ void __launch_bounds__(256) rz_vertex_kernel(PassParams P) {
+__global__ void __launch_bounds__(256) rz_vertex_kernel(const PassParams *__restrict__ passes) {
+    const PassParams &P = passes[blockIdx.y];
     uint32_t gv = blockIdx.x * 256u + threadIdx.x;
     if (gv < 8u) P.control[gv] = 0;             /* the pass's device-written scalars start at zero */
     if (gv >= 3u * (uint32_t)P.num_tris) return;
@@ -217,7 +218,8 @@ RZ_DEV void store_tri(TriRec *dst, const TriRec &r) {
     o[3] = make_float4(r.rw[2], __uint_as_float(r.meta), __uint_as_float(r.bx), __uint_as_float(r.by));
 }
 
-__global__ void __launch_bounds__(256) rz_setup_kernel(PassParams P) {
+__global__ void __launch_bounds__(256) rz_setup_kernel(const PassParams *__restrict__ passes) {
+    const PassParams &P = passes[blockIdx.y];
     uint32_t t = blockIdx.x * 256u + threadIdx.x;
     if (t >= (uint32_t)P.num_tris) return;
     int d = find_draw(P.first_tri, P.num_draws, t);
@@ -258,7 +260,8 @@ __global__ void __launch_bounds__(256) rz_setup_kernel(PassParams P) {
  * the same ratio -- exactly what clip_against_plane does per float
  * (graphics.c:205-253).  Planes in the reference order W +X -X +Y -Y +Z -Z
  * (:304-310); the fan and its early end on a culled triangle as in :584-607. */
-__global__ void __launch_bounds__(64) rz_clip_kernel(PassParams P) {
+__global__ void __launch_bounds__(64) rz_clip_kernel(const PassParams *__restrict__ passes) {
+    const PassParams &P = passes[blockIdx.y];
     __shared__ float poly[2][RZ_MAX_POLY][32];
     __shared__ int s_box[4][RZ_MAX_FAN];
     const int lane = threadIdx.x;
@@ -402,10 +405,12 @@ RZ_DEV uint32_t wave_exclusive_scan(uint32_t v, uint32_t *total) {
 /* Wave w owns the w-th contiguous slice of the triangle range, so the list is
  * the concatenation of the waves' hits: one barrier in the whole kernel.
  * Every entry carries a copy of the triangle's record (BinEntry). */
-__global__ void __launch_bounds__(RZ_BIN_WAVES * 64) rz_bin_kernel(PassParams P) {
+__global__ void __launch_bounds__(RZ_BIN_WAVES * 64) rz_bin_kernel(const PassParams *__restrict__ passes) {
+    const PassParams &P = passes[blockIdx.y];
     __shared__ uint32_t s_count[RZ_BIN_WAVES];
     __shared__ uint32_t s_start;
     const int bin = blockIdx.x;
+    if (bin >= P.bins_x * P.bins_y) return;
     const int rx0 = (bin % P.bins_x) * RZ_BIN, ry0 = (bin / P.bins_x) * RZ_BIN;
     const int rx1 = rx0 + RZ_BIN - 1, ry1 = ry0 + RZ_BIN - 1;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -664,11 +669,21 @@ RZ_DEV bool block_outside(float4 c0, float4 c1, float x0, float x1, float y0, fl
  * entries the candidates' records are fetched lane-parallel (one memory round
  * trip for all of them) and then broadcast one at a time in list order. */
 template <bool SPLIT>
-__global__ void __launch_bounds__(256) rz_raster_kernel(PassParams P,
-        const TriRec *__restrict__ tri_table, const TriRec *__restrict__ fan_table,
-        const BinEntry *__restrict__ list_table,
-        const float *__restrict__ vary_table, const float *__restrict__ fan_vary_table,
-        const DrawRec *__restrict__ draw_table, const uint2 *__restrict__ bin_range_table) {
+__global__ void __launch_bounds__(256) rz_raster_kernel(const PassParams *__restrict__ passes,
+        const TriRec *__restrict__ tri_base, const TriRec *__restrict__ fan_base,
+        const BinEntry *__restrict__ list_base,
+        const float *__restrict__ vary_base, const float *__restrict__ fan_vary_base,
+        const char *__restrict__ upload_base, const uint2 *__restrict__ bin_range_base) {
+    const PassParams &P = passes[blockIdx.y];
+    if (blockIdx.x >= (unsigned)P.num_tiles) return;
+    /* this pass's slices of the batch-wide tables */
+    const TriRec *tri_table = tri_base + P.tri_off;
+    const TriRec *fan_table = fan_base + (size_t)P.fan_off * RZ_MAX_FAN;
+    const BinEntry *list_table = list_base + P.list_off;
+    const float *vary_table = vary_base + (size_t)P.tri_off * 3 * RZ_VARY_STRIDE;
+    const float *fan_vary_table = fan_vary_base + (size_t)P.fan_off * RZ_MAX_POLY * RZ_VARY_STRIDE;
+    const DrawRec *draw_table = (const DrawRec*)(upload_base + P.draws_off);
+    const uint2 *bin_range_table = bin_range_base + P.bin_off;
     /* A workgroup owns a 32x8-pixel tile, wave w its w-th 8x8 block.  Planes
      * are read and written through LDS so that every global access is a whole
      * 128-byte row of the tile instead of eight 32-byte pieces. */
@@ -843,10 +858,18 @@ __global__ void __launch_bounds__(256) rz_raster_kernel(PassParams P,
 /* K5  per-family fragment kernels for passes rasterised with SPLIT = true:
  * every lane shades the one fragment its pixel refers to. */
 template <int FAMILY>
-__global__ void __launch_bounds__(256) rz_shade_kernel(PassParams P,
-        const TriRec *__restrict__ tri_table, const TriRec *__restrict__ fan_table,
-        const float *__restrict__ vary_table, const float *__restrict__ fan_vary_table,
-        const DrawRec *__restrict__ draw_table, const uint32_t *__restrict__ ref_table) {
+__global__ void __launch_bounds__(256) rz_shade_kernel(const PassParams *__restrict__ passes,
+        const TriRec *__restrict__ tri_base, const TriRec *__restrict__ fan_base,
+        const float *__restrict__ vary_base, const float *__restrict__ fan_vary_base,
+        const char *__restrict__ upload_base, const uint32_t *__restrict__ ref_base) {
+    const PassParams &P = passes[blockIdx.y];
+    if (blockIdx.x >= (unsigned)P.num_tiles) return;
+    const TriRec *tri_table = tri_base + P.tri_off;
+    const TriRec *fan_table = fan_base + (size_t)P.fan_off * RZ_MAX_FAN;
+    const float *vary_table = vary_base + (size_t)P.tri_off * 3 * RZ_VARY_STRIDE;
+    const float *fan_vary_table = fan_vary_base + (size_t)P.fan_off * RZ_MAX_POLY * RZ_VARY_STRIDE;
+    const DrawRec *draw_table = (const DrawRec*)(upload_base + P.draws_off);
+    const uint32_t *ref_table = ref_base + P.ref_off;
     __shared__ uint32_t s_plane[2][RZ_TILE_H][RZ_TILE_W];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int tiles_x = (P.width + RZ_TILE_W - 1) / RZ_TILE_W;

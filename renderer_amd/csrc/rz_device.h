@@ -151,6 +151,16 @@ struct PassParams {
     uint32_t *control;
     unsigned long long *counters;   /* nullptr unless counting is enabled */
     int32_t debug_skip;             /* measurement only: 1 skip shading, 2 skip coverage too */
+    /* A launch covers a batch of passes (blockIdx.y = pass).  The rasteriser
+     * and the shade kernels address the batch-wide tables through restrict
+     * kernel arguments plus these per-pass offsets. */
+    int32_t num_tiles;              /* 32x8 tiles of this framebuffer */
+    uint32_t tri_off;               /* triangles before this pass (vertices = 3x) */
+    uint32_t fan_off;               /* fan blocks before this pass */
+    uint32_t list_off;              /* bin-list entries before this pass */
+    uint32_t bin_off;               /* bins before this pass */
+    uint64_t ref_off;               /* pixels before this pass in the reference plane */
+    uint64_t draws_off;             /* byte offset of draws[] in the flush's upload region */
 };
 
 enum { RZ_ERR_FAN_OVERFLOW = 1, RZ_ERR_BIN_OVERFLOW = 2 };

@@ -22,14 +22,26 @@ for f in glob.glob(os.path.join(out, "trace", "**", "*kernel_stats.csv"), recurs
     for row in csv.DictReader(open(f)):
         stats[short(row["Name"])] = (int(row["Calls"]), float(row["AverageNs"]) / 1e3, float(row["Percentage"]))
 
+# medians from the raw trace: first launches (code upload, cold caches) skew the averages
+durations = defaultdict(list)
+for f in glob.glob(os.path.join(out, "trace", "**", "*kernel_trace.csv"), recursive=True):
+    for row in csv.DictReader(open(f)):
+        durations[short(row["Kernel_Name"])].append((int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e3)
+
+
+def median(v):
+    v = sorted(v)
+    return v[len(v) // 2] if v else float("nan")
+
+
 pmc = defaultdict(lambda: defaultdict(list))
 for f in glob.glob(os.path.join(out, "*", "**", "*counter_collection.csv"), recursive=True):
     for row in csv.DictReader(open(f)):
         pmc[short(row["Kernel_Name"])][row["Counter_Name"]].append(float(row["Counter_Value"]))
 
-print(f"{'kernel':34s} {'calls':>6s} {'avg us':>9s} {'%':>6s}")
+print(f"{'kernel':34s} {'calls':>6s} {'avg us':>9s} {'%':>6s} {'median us':>10s}")
 for k, (calls, avg, pct) in sorted(stats.items(), key=lambda kv: -kv[1][2]):
-    print(f"{k:34s} {calls:6d} {avg:9.2f} {pct:6.2f}")
+    print(f"{k:34s} {calls:6d} {avg:9.2f} {pct:6.2f} {median(durations.get(k, [])):10.2f}")
     for c, vals in sorted(pmc.get(k, {}).items()):
         mean = sum(vals) / len(vals)
         note = ""
