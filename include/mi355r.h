@@ -265,6 +265,29 @@ void mi355r_enable_counters(int on);
 void mi355r_enable_timing(int on);
 unsigned long long mi355r_get_timing(double out_ms[5], int reset);
 
+/* Inspection of the geometry stage of the most recently submitted pass
+ * (a pass = a maximal run of draws into one framebuffer).  No counterpart in
+ * the reference, whose rasterize_triangle walks each bounding box at once
+ * (graphics.c:505-532); this is how tests compare the integer binning stage
+ * with its CPU statement.  Triangles are numbered in submission order.
+ *   boxes[t] = {x0 | x1 << 16, y0 | y1 << 16}: the pixel box of find_bounding_box
+ *              (graphics.c:355-364), for a clipped triangle the union over its
+ *              fan; x0 > x1 when nothing is rasterised
+ *   fans[t]  = triangles rasterised for input triangle t (0 when culled or
+ *              without pixels, 1 for an unclipped one, else the fan length up
+ *              to the first culled fan triangle, graphics.c:584-607)
+ *   bins     = square screen bins of bin_edge pixels, row-major from the
+ *              bottom-left; counts[b] entries each, concatenated in `entries`
+ *              as {triangle, fan index} pairs in rasterisation order
+ * mi355r_inspect_pass waits for the device and returns 0 if no pass ran. */
+typedef struct {
+    int num_tris, width, height, bin_edge, bins_x, bins_y;
+    unsigned int bin_entries;
+} rz_pass_info;
+int mi355r_inspect_pass(rz_pass_info *info);
+void mi355r_inspect_boxes(unsigned int *boxes, unsigned int *fans);
+void mi355r_inspect_bins(unsigned int *counts, unsigned int *entries);
+
 #ifdef __cplusplus
 }
 #endif

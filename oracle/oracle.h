@@ -5,6 +5,7 @@
 #ifndef ORACLE_H
 #define ORACLE_H
 
+#include <stddef.h>
 #include "../include/mi355r.h"
 
 /* the three shader pairs (oracle/shaders.c) */
@@ -37,6 +38,12 @@ typedef struct { rz_vec3 direction; } o_skybox_varyings;
 typedef struct {
     unsigned long long triangles, prims, tests, covered, shaded;
 } oracle_stats;
+
+/* CPU binning oracle (oracle/binning.c): the ordered per-bin triangle lists
+ * that follow from the triangles' pixel boxes.  counts[bins]; entries (may be
+ * NULL) receives {triangle, fan index} pairs; returns the number of entries. */
+size_t oracle_bin(const unsigned *boxes, const unsigned *fans, int num_tris, int width, int height, int edge,
+                  unsigned *counts, unsigned *entries);
 
 void oracle_get_stats(oracle_stats *out);
 void oracle_reset_stats(void);

@@ -20,6 +20,47 @@
 #include "omath.h"
 #include "oracle.h"
 
+/* ======================= geometry trace ================================= */
+
+/* What mi355r_inspect_* reports: per input triangle of the current pass its
+ * pixel box and the number of triangles rasterised for it.  A pass is the run
+ * of draws into one framebuffer since the last clear / read / sync. */
+static struct {
+    rz_framebuffer *fb;
+    int closed;
+    int width, height;
+    size_t n, cap;
+    unsigned *boxes, *fans;
+} g_trace;
+
+static int g_prim_box[4];           /* x0, x1, y0, y1 of the triangle raster() saw last */
+
+static void trace_close(rz_framebuffer *fb) {
+    if (g_trace.fb == fb) g_trace.closed = 1;
+}
+
+static void trace_add(rz_framebuffer *fb, const int box[4], int fan) {
+    size_t t;
+    if (g_trace.fb != fb || g_trace.closed) {
+        g_trace.fb = fb; g_trace.closed = 0; g_trace.n = 0;
+        g_trace.width = fb->width; g_trace.height = fb->height;
+    }
+    if (g_trace.n == g_trace.cap) {
+        g_trace.cap = g_trace.cap ? g_trace.cap * 2 : 4096;
+        g_trace.boxes = (unsigned*)realloc(g_trace.boxes, g_trace.cap * 2 * sizeof(unsigned));
+        g_trace.fans = (unsigned*)realloc(g_trace.fans, g_trace.cap * sizeof(unsigned));
+    }
+    t = g_trace.n++;
+    if (fan == 0 || box[0] > box[1] || box[2] > box[3]) {
+        g_trace.boxes[2 * t] = 0x0000ffffu; g_trace.boxes[2 * t + 1] = 0x0000ffffu;
+        g_trace.fans[t] = 0;
+    } else {
+        g_trace.boxes[2 * t] = (unsigned)box[0] | ((unsigned)box[1] << 16);
+        g_trace.boxes[2 * t + 1] = (unsigned)box[2] | ((unsigned)box[3] << 16);
+        g_trace.fans[t] = (unsigned)fan;
+    }
+}
+
 /* ======================= framebuffer (graphics.c:11-55) ================= */
 
 rz_framebuffer *framebuffer_create(int width, int height) {
@@ -45,6 +86,7 @@ void framebuffer_release(rz_framebuffer *fb) {
 void framebuffer_clear_color(rz_framebuffer *fb, rz_vec4 color) {
     size_t n = (size_t)fb->width * fb->height, i;
     unsigned char px[4];
+    trace_close(fb);
     px[0] = o_to_u8(color.x); px[1] = o_to_u8(color.y);
     px[2] = o_to_u8(color.z); px[3] = o_to_u8(color.w);
     for (i = 0; i < n; i++) memcpy(fb->color_buffer + i * 4, px, 4);
@@ -52,14 +94,16 @@ void framebuffer_clear_color(rz_framebuffer *fb, rz_vec4 color) {
 
 void framebuffer_clear_depth(rz_framebuffer *fb, float depth) {
     size_t n = (size_t)fb->width * fb->height, i;
+    trace_close(fb);
     for (i = 0; i < n; i++) fb->depth_buffer[i] = depth;
 }
 
-void framebuffer_sync(rz_framebuffer *fb) { (void)fb; }
+void framebuffer_sync(rz_framebuffer *fb) { trace_close(fb); }
 void graphics_flush(void) {}
 
 void framebuffer_read(rz_framebuffer *fb, void *color, void *depth) {
     size_t n = (size_t)fb->width * fb->height;
+    trace_close(fb);
     if (color) memcpy(color, fb->color_buffer, n * 4);
     if (depth) memcpy(depth, fb->depth_buffer, n * sizeof(float));
 }
@@ -236,6 +280,7 @@ static int raster(rz_framebuffer *fb, rz_program *p, const rz_vec4 clip[3], floa
     y0 = (int)floor(miny); if (y0 < 0) y0 = 0;
     x1 = (int)ceil(maxx); if (x1 > width - 1) x1 = width - 1;
     y1 = (int)ceil(maxy); if (y1 > height - 1) y1 = height - 1;
+    g_prim_box[0] = x0; g_prim_box[1] = x1; g_prim_box[2] = y0; g_prim_box[3] = y1;
     g_oracle_stats.prims++;
 
     for (x = x0; x <= x1; x++) {
@@ -289,7 +334,8 @@ static int raster(rz_framebuffer *fb, rz_program *p, const rz_vec4 clip[3], floa
 
 /* graphics.c:537-608 */
 void graphics_draw_triangle(rz_framebuffer *fb, rz_program *p) {
-    int n, side, i;
+    int n, side, i, fan = 0;
+    int box[4] = {65535, -1, 65535, -1};    /* union of the fan's non-empty pixel boxes */
     g_oracle_stats.triangles++;
     for (i = 0; i < 3; i++) p->pos[0][i] = p->vs(p->attribs[i], p->vary[0][i], p->uniforms);
     n = clip_triangle(p, &side);
@@ -299,7 +345,15 @@ void graphics_draw_triangle(rz_framebuffer *fb, rz_program *p) {
         c[0] = p->pos[side][0]; c[1] = p->pos[side][i + 1]; c[2] = p->pos[side][i + 2];
         v[0] = p->vary[side][0]; v[1] = p->vary[side][i + 1]; v[2] = p->vary[side][i + 2];
         if (raster(fb, p, c, v)) break;     /* a culled fan triangle ends the fan */
+        fan++;
+        if (g_prim_box[0] <= g_prim_box[1] && g_prim_box[2] <= g_prim_box[3]) {
+            if (g_prim_box[0] < box[0]) box[0] = g_prim_box[0];
+            if (g_prim_box[1] > box[1]) box[1] = g_prim_box[1];
+            if (g_prim_box[2] < box[2]) box[2] = g_prim_box[2];
+            if (g_prim_box[3] > box[3]) box[3] = g_prim_box[3];
+        }
     }
+    trace_add(fb, box, fan);
 }
 
 /* the per-face loops of the shaders' draw_model (blinn_shader.c:323-341,
@@ -421,6 +475,35 @@ rz_vec4 cubemap_clamp_sample(rz_cubemap *cube, rz_vec3 dir) {         /* :264 */
 rz_vec4 cubemap_sample(rz_cubemap *cube, rz_vec3 dir) { return cubemap_repeat_sample(cube, dir); }
 
 /* ======================= introspection ================================== */
+
+#define ORACLE_BIN_EDGE 64
+
+int mi355r_inspect_pass(rz_pass_info *info) {
+    size_t bins;
+    unsigned *counts;
+    if (!g_trace.fb || g_trace.n == 0) return 0;
+    info->num_tris = (int)g_trace.n;
+    info->width = g_trace.width;
+    info->height = g_trace.height;
+    info->bin_edge = ORACLE_BIN_EDGE;
+    info->bins_x = (g_trace.width + ORACLE_BIN_EDGE - 1) / ORACLE_BIN_EDGE;
+    info->bins_y = (g_trace.height + ORACLE_BIN_EDGE - 1) / ORACLE_BIN_EDGE;
+    bins = (size_t)info->bins_x * info->bins_y;
+    counts = (unsigned*)malloc(bins * sizeof(unsigned));
+    info->bin_entries = (unsigned)oracle_bin(g_trace.boxes, g_trace.fans, (int)g_trace.n, g_trace.width, g_trace.height,
+                                             ORACLE_BIN_EDGE, counts, NULL);
+    free(counts);
+    return 1;
+}
+
+void mi355r_inspect_boxes(unsigned int *boxes, unsigned int *fans) {
+    memcpy(boxes, g_trace.boxes, g_trace.n * 2 * sizeof(unsigned));
+    memcpy(fans, g_trace.fans, g_trace.n * sizeof(unsigned));
+}
+
+void mi355r_inspect_bins(unsigned int *counts, unsigned int *entries) {
+    oracle_bin(g_trace.boxes, g_trace.fans, (int)g_trace.n, g_trace.width, g_trace.height, ORACLE_BIN_EDGE, counts, entries);
+}
 
 const char *mi355r_backend(void) { return "cpu-oracle"; }
 void oracle_get_stats(oracle_stats *out) { *out = g_oracle_stats; }

@@ -32,6 +32,11 @@ class View(C.Structure):
                 ("frame_time", C.c_float), ("layer_view", C.c_int)]
 
 
+class PassInfo(C.Structure):
+    _fields_ = [("num_tris", C.c_int), ("width", C.c_int), ("height", C.c_int), ("bin_edge", C.c_int),
+                ("bins_x", C.c_int), ("bins_y", C.c_int), ("bin_entries", C.c_uint)]
+
+
 class Pipeline:
     """One loaded library (GPU or oracle)."""
 
@@ -65,6 +70,10 @@ class Pipeline:
         lib.rzs_scene_shadow_buffer.argtypes = [P]
         lib.rzs_catalogue.restype = C.c_char_p
         lib.rzs_catalogue.argtypes = [C.c_int]
+        lib.mi355r_inspect_pass.argtypes = [C.POINTER(PassInfo)]
+        lib.mi355r_inspect_pass.restype = C.c_int
+        lib.mi355r_inspect_boxes.argtypes = [P, P]
+        lib.mi355r_inspect_bins.argtypes = [P, P]
         self.backend = lib.mi355r_backend().decode()
         self.is_gpu = self.backend.startswith("hip")
         if self.is_gpu:
@@ -139,6 +148,29 @@ class Pipeline:
         fb = self.framebuffer(width, height)
         self.draw(scene, fb, view if view is not None else self.default_view())
         out = self.read(fb)
+        self.release(fb)
+        return out
+
+    def inspect(self):
+        """Geometry stage of the last pass: dict(info, boxes[T,2], fans[T], counts[bins], entries[E,2])."""
+        info = PassInfo()
+        if not self.lib.mi355r_inspect_pass(C.byref(info)):
+            raise RuntimeError("no pass has been submitted")
+        boxes = np.zeros((info.num_tris, 2), np.uint32)
+        fans = np.zeros(info.num_tris, np.uint32)
+        counts = np.zeros(info.bins_x * info.bins_y, np.uint32)
+        entries = np.zeros((info.bin_entries, 2), np.uint32)
+        as_p = lambda a: a.ctypes.data_as(C.c_void_p)
+        self.lib.mi355r_inspect_boxes(as_p(boxes), as_p(fans))
+        self.lib.mi355r_inspect_bins(as_p(counts), as_p(entries))
+        return {"info": {k: getattr(info, k) for k, _ in PassInfo._fields_},
+                "boxes": boxes, "fans": fans, "counts": counts, "entries": entries}
+
+    def geometry(self, scene, width, height, view=None):
+        """Draws one frame and returns inspect() of its (last) pass."""
+        fb = self.framebuffer(width, height)
+        self.draw(scene, fb, view if view is not None else self.default_view())
+        out = self.inspect()
         self.release(fb)
         return out
 

@@ -157,6 +157,9 @@ struct Context {
     bool counting = false;
     unsigned long long *d_counters = nullptr;
     unsigned long long host_counters[8] = {0};
+    /* the pass mi355r_inspect_* looks at: the last one submitted */
+    PassParams last_pass;
+    bool have_last_pass = false;
 };
 
 static Context g;
@@ -1019,6 +1022,8 @@ static void prepare_batch(const Batch &b, const std::vector<PassPlan> &plans, ch
         P.ref_off = ref_off;
         P.draws_off = pl.off_draws;
         memcpy(hb + b.off_params + sizeof(PassParams) * k, &P, sizeof P);
+        g.last_pass = P;
+        g.have_last_pass = true;
         tri_off += pl.T; fan_off += fan_cap[k]; list_off += list_cap[k];
         bin_off += (size_t)P.bins_x * P.bins_y;
         ref_off += (size_t)W * H;
@@ -1185,6 +1190,80 @@ extern "C" void graphics_flush(void) {
     for (size_t i = 0; i < plans.size(); i++) g.control_slots.push_back(at + CONTROL_BYTES * i);
     g.pending.clear();
     g.side.clear();
+}
+
+/* --------------------------------------------------------------- inspection -- */
+
+extern "C" int mi355r_inspect_pass(rz_pass_info *info) {
+    if (!g.ready || !g.have_last_pass) return 0;
+    graphics_flush();
+    sync_stream();
+    const PassParams &P = g.last_pass;
+    uint32_t control[8];
+    HIP_OK(hipMemcpy(control, P.control, sizeof control, hipMemcpyDeviceToHost));
+    info->num_tris = P.num_tris;
+    info->width = P.width;
+    info->height = P.height;
+    info->bin_edge = RZ_BIN;
+    info->bins_x = P.bins_x;
+    info->bins_y = P.bins_y;
+    info->bin_entries = control[1];
+    return 1;
+}
+
+extern "C" void mi355r_inspect_boxes(unsigned int *boxes, unsigned int *fans) {
+    if (!g.have_last_pass) fatal("mi355r_inspect_boxes: no pass to look at");
+    const PassParams &P = g.last_pass;
+    const size_t T = (size_t)P.num_tris;
+    std::vector<TriRec> recs(T);
+    HIP_OK(hipMemcpy(boxes, P.bbox, T * sizeof(uint2), hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(recs.data(), P.tri, T * sizeof(TriRec), hipMemcpyDeviceToHost));
+    for (size_t t = 0; t < T; t++) {
+        const bool empty = (boxes[2 * t] & 0xffffu) > (boxes[2 * t] >> 16);
+        /* a record is only written for a triangle with a non-empty box */
+        fans[t] = empty ? 0u : (RZ_META_CLIPPED(recs[t].meta) ? RZ_META_FAN(recs[t].meta) : 1u);
+    }
+}
+
+extern "C" void mi355r_inspect_bins(unsigned int *counts, unsigned int *entries) {
+    if (!g.have_last_pass) fatal("mi355r_inspect_bins: no pass to look at");
+    const PassParams &P = g.last_pass;
+    const size_t T = (size_t)P.num_tris, bins = (size_t)P.bins_x * P.bins_y;
+    std::vector<TriRec> recs(T);
+    std::vector<uint2> boxes(T), ranges(bins);
+    HIP_OK(hipMemcpy(recs.data(), P.tri, T * sizeof(TriRec), hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(boxes.data(), P.bbox, T * sizeof(uint2), hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(ranges.data(), P.bin_range, bins * sizeof(uint2), hipMemcpyDeviceToHost));
+    /* fan block -> input triangle (a clipped triangle's record carries its block in ax) */
+    std::unordered_map<uint32_t, uint32_t> owner;
+    for (size_t t = 0; t < T; t++) {
+        const bool empty = (boxes[t].x & 0xffffu) > (boxes[t].x >> 16);
+        if (!empty && RZ_META_CLIPPED(recs[t].meta)) {
+            uint32_t block;
+            memcpy(&block, &recs[t].ax, sizeof block);
+            owner[block] = (uint32_t)t;
+        }
+    }
+    size_t out = 0;
+    std::vector<BinEntry> list;
+    for (size_t b = 0; b < bins; b++) {
+        counts[b] = ranges[b].y;
+        list.resize(ranges[b].y);
+        if (ranges[b].y)
+            HIP_OK(hipMemcpy(list.data(), P.bin_list + ranges[b].x, ranges[b].y * sizeof(BinEntry), hipMemcpyDeviceToHost));
+        for (const BinEntry &e : list) {
+            if (e.tri & 0x80000000u) {
+                const uint32_t idx = e.tri & 0x7fffffffu;
+                auto it = owner.find(idx / RZ_MAX_FAN);
+                if (it == owner.end()) fatal("bin entry refers to fan block %u that no triangle owns", idx / RZ_MAX_FAN);
+                entries[out++] = it->second;
+                entries[out++] = idx % RZ_MAX_FAN;
+            } else {
+                entries[out++] = e.tri;
+                entries[out++] = 0;
+            }
+        }
+    }
 }
 
 /* -------------------------------------------------------------- measurement -- */
