@@ -122,6 +122,10 @@ static void model_update(model_t *m, const frame_t *f) {
 
 /* blinn_shader.c:306-342, pbr_shader.c:549-578, skybox_shader.c:47-66: one
  * triangle per face in mesh order; the skybox takes no part in shadow passes */
+static int g_per_triangle = 0;
+
+void rzs_set_per_triangle(int on) { g_per_triangle = on; }
+
 static void model_draw(model_t *m, rz_framebuffer *fb, int shadow_pass) {
     if (m->kind == MODEL_SKYBOX) {
         if (shadow_pass) return;
@@ -130,7 +134,32 @@ static void model_draw(model_t *m, rz_framebuffer *fb, int shadow_pass) {
     } else {
         ((rz_pbr_uniforms*)program_get_uniforms(m->program))->shadow_pass = shadow_pass;
     }
-    graphics_draw_mesh(fb, m->program, m->mesh->vertices, m->mesh->num_faces);
+    if (!g_per_triangle) {
+        graphics_draw_mesh(fb, m->program, m->mesh->vertices, m->mesh->num_faces);
+    } else {
+        /* the reference's own loop: three attribute blocks filled per face,
+         * then one graphics_draw_triangle call */
+        const rz_vertex *verts = m->mesh->vertices;
+        int f, j;
+        for (f = 0; f < m->mesh->num_faces; f++) {
+            for (j = 0; j < 3; j++) {
+                const rz_vertex *v = &verts[f * 3 + j];
+                void *attribs = program_get_attribs(m->program, j);
+                if (m->kind == MODEL_SKYBOX) {
+                    ((rz_skybox_attribs*)attribs)->position = v->position;
+                } else if (m->kind == MODEL_BLINN) {
+                    rz_blinn_attribs *a = (rz_blinn_attribs*)attribs;
+                    a->position = v->position; a->texcoord = v->texcoord; a->normal = v->normal;
+                    a->joint = v->joint; a->weight = v->weight;
+                } else {
+                    rz_pbr_attribs *a = (rz_pbr_attribs*)attribs;
+                    a->position = v->position; a->texcoord = v->texcoord; a->normal = v->normal;
+                    a->tangent = v->tangent; a->joint = v->joint; a->weight = v->weight;
+                }
+            }
+            graphics_draw_triangle(fb, m->program);
+        }
+    }
 }
 
 static void model_free(model_t *m) {

@@ -43,6 +43,10 @@ void rzs_orbit_view(rzs_view *view, int index, int count);
 
 /* Renders one frame into the framebuffer (asynchronously on the GPU build;
  * read the result with framebuffer_sync / framebuffer_read). */
+/* Submission mode of rzs_scene_draw: 0 (default) whole meshes through
+ * graphics_draw_mesh; 1 the reference's per-face loop (fill three attribute
+ * blocks, graphics_draw_triangle), e.g. pbr_shader.c:561-577. */
+void rzs_set_per_triangle(int on);
 void rzs_scene_draw(rzs_scene *scene, rz_framebuffer *framebuffer, const rzs_view *view);
 
 /* info: [0] models, [1] faces, [2] has skybox, [3] shadow width, [4] shadow
