@@ -8,16 +8,16 @@ renderer_amd/libmi355r.so.
 
 One step = one batch of FRAMES orbit views of the scene (camera on a circle of
 radius 1.5 around the model, animation time index/30 s), every frame a full
-pass of the pipeline (vertex -> setup/clip -> bin -> raster+shade) into its
+pass of the pipeline (vertex -> setup/clip -> bin -> raster -> shade) into its
 own framebuffer; scene data (meshes, textures, IBL maps) is resident in HBM
-before the timed region.  With N > 1 ranks every rank renders its own batch
-(frames are independent: weak scaling) and the finished RGBA8 frames are
-gathered on rank 0 over RCCL inside the timed region.
+before the timed region.  With N > 1 ranks every rank renders its own block of
+the orbit (frames are independent: weak scaling, no collective while
+rendering) and the finished RGBA8 frames are gathered on rank 0 over RCCL
+inside the timed region.
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
-import ctypes as C
 import json
 import os
 import sys
@@ -29,24 +29,35 @@ sys.path.insert(0, REPO)
 WIDTH, HEIGHT = 1920, 1080
 SCENE = "helmet"
 ORBIT = 64                  # views on the orbit circle
-HBM_PEAK_GBS = 8000.0       # MI355X HBM3E, spec
+HBM_PEAK_GBS = 8000.0       # MI355X HBM3E
+KERNEL_SYMBOL = {"vertex": "rz_vertex_kernel", "setup": "rz_setup_kernel", "bin": "rz_bin_kernel",
+                 "raster": "rz_raster_kernel<true>", "shade_skybox": "rz_shade_kernel<2>",
+                 "shade_blinn": "rz_shade_kernel<0>", "shade_pbr": "rz_shade_kernel<1>"}
 
 
-def algorithmic_bytes(counters, frames, faces):
-    """Algorithmic HBM bytes of the rendered frames: 240 B per input triangle
-    (3 x 80-byte vertices), 8 B per pixel (RGBA8 + f32 depth written once),
-    and per shaded fragment the texels its shader samples at the reference's
-    precision (16-byte float4): 9 for a pbr fragment (6 material maps, 2 cube
-    maps, BRDF LUT), 1 for a skybox fragment."""
-    shaded, skybox = counters[2], counters[6]
-    pbr = shaded - skybox
-    return frames * (240 * faces + 8 * WIDTH * HEIGHT) + 144 * pbr + 16 * skybox
+def reference_frame_bytes(counters, frames, faces):
+    """Algorithmic HBM bytes of one frame as the reference's work defines them: 240 B per input
+    triangle (3 x 80-byte vertices), 8 B per pixel (RGBA8 + f32 depth written once), and per
+    fragment the reference shades (its draw_fragment calls) the texels its shader samples at the
+    reference's precision (16-byte float4): 9 for a pbr fragment (6 material maps, 2 cube maps,
+    BRDF LUT), 1 for a skybox fragment."""
+    shaded, skybox = counters[2] / frames, counters[6] / frames
+    return 240 * faces + 8 * WIDTH * HEIGHT + 144 * (shaded - skybox) + 16 * skybox
+
+
+def kernel_frame_bytes(counters, frames, faces):
+    """The same figures attributed to the kernel that moves them, per frame, with the fragments
+    each shade kernel really shades (only fragments that stay visible): vertex stream -> vertex
+    kernel; depth plane -> raster; texels + the colour bytes of its pixels -> shade kernels."""
+    shaded, skybox = counters[8] / frames, counters[9] / frames
+    return {"vertex": 240.0 * faces, "setup": 0.0, "bin": 0.0, "raster": 4.0 * WIDTH * HEIGHT,
+            "shade_skybox": (16 + 4) * skybox, "shade_blinn": 0.0, "shade_pbr": (144 + 4) * (shaded - skybox)}
 
 
 def cpu_baseline(frames_wanted):
-    """The CPU restatement (oracle/, built with the reference's own flags
-    -O3 -flto -ffast-math), single thread, on a bounded sample of the same
-    workload.  Reported beside the GPU number; never part of `value`."""
+    """The CPU restatement (oracle/, built with the reference's own flags -O3 -flto -ffast-math),
+    single thread, on a bounded sample of the same workload.  Reported beside the GPU number;
+    never part of `value`."""
     from renderer_amd.binding import Pipeline
     lib = os.path.join(REPO, "oracle", "liboracle_fast.so")
     if not os.path.exists(lib):
@@ -70,6 +81,18 @@ def cpu_baseline(frames_wanted):
                       f"(gcc -O3 -flto -ffast-math), {os.cpu_count()} host cores available"}
 
 
+def measured_traffic(symbol, frames_per_launch):
+    """HBM bytes per launch of `symbol` from the committed PMC passes (tools/profile.sh), if they
+    were taken with the same number of frames per launch; else None."""
+    path = os.path.join(REPO, "profiles", "traffic.json")
+    if not os.path.exists(path):
+        return None
+    t = json.load(open(path))
+    if t.get("frames_per_launch") != frames_per_launch or symbol not in t.get("kernels", {}):
+        return None
+    return t["kernels"][symbol]["hbm_bytes_per_launch"]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -81,6 +104,7 @@ def main():
 
     import torch
     import torch.distributed as dist
+    from renderer_amd import orbit
     from renderer_amd.binding import Pipeline, GPU_LIB
 
     rank = int(os.environ.get("RANK", "0"))
@@ -101,20 +125,16 @@ def main():
     faces = info["faces"] + (12 if info["skybox"] else 0)
     B = args.frames
     fbs = [gpu.framebuffer(WIDTH, HEIGHT) for _ in range(B)]
-    # per-rank slice of the orbit: rank r renders views r*B .. r*B+B-1 (mod ORBIT)
-    views = [gpu.orbit_view((rank * B + i) % ORBIT, ORBIT) for i in range(B)]
-    frame_bytes = WIDTH * HEIGHT * 4
+    # weak scaling: B frames per rank; rank r renders block r of an orbit of B * world views
+    first, last = orbit.shard_views(B * world, rank, world)
+    views = [gpu.orbit_view(i % ORBIT, ORBIT) for i in range(first, last)]
     out = torch.empty((B, HEIGHT, WIDTH, 4), dtype=torch.uint8, device="cuda") if world > 1 else None
-    gathered = [torch.empty_like(out) for _ in range(world)] if (world > 1 and rank == 0) else None
 
     def step():
-        for i in range(B):
-            gpu.draw(scene, fbs[i], views[i])
-        gpu.lib.graphics_flush()
+        orbit.render_views(gpu, scene, fbs, views)
         if world > 1:
-            for i in range(B):
-                gpu.lib.framebuffer_read_device(fbs[i], C.c_void_p(out.data_ptr() + i * frame_bytes), None)
-            dist.gather(out, gathered, dst=0)
+            orbit.frames_to_tensor(gpu, fbs, B, out)
+            orbit.gather_frames(out, rank, world)
 
     def fence():
         if world > 1:
@@ -142,36 +162,27 @@ def main():
         # workload counters (untimed pass with device-side counting on)
         gpu.lib.mi355r_reset_counters()
         gpu.lib.mi355r_enable_counters(1)
-        step() if world == 1 else [gpu.draw(scene, fbs[i], views[i]) for i in range(B)]
+        orbit.render_views(gpu, scene, fbs, views)
         counters = gpu.counters()
         gpu.lib.mi355r_enable_counters(0)
         shaded_per_frame = counters[2] / B
 
-        # dominant kernel (raster + shade): HIP events on the pipeline's stream
+        # per-kernel device time: HIP events on the pipeline's own stream around every launch
         gpu.lib.mi355r_enable_timing(1)
         for _ in range(max(1, min(args.steps, 5))):
-            for i in range(B):
-                gpu.draw(scene, fbs[i], views[i])
-            gpu.lib.graphics_flush()
-        passes, ms = gpu.kernel_times()
+            orbit.render_views(gpu, scene, fbs, views)
+        passes, sequences, ms = gpu.kernel_times()
         gpu.lib.mi355r_enable_timing(0)
-        names = ["vertex", "setup", "bin", "raster", "shade"]
-        per_frame_ms = {n: ms[i] / passes for i, n in enumerate(names)}
-        # the frame's algorithmic bytes, attributed to the kernel that moves them:
-        # vertex stream -> vertex kernel; depth plane -> raster; colour plane + texels -> shade
-        # (when a pass shades inside the raster kernel, raster carries the shade share too)
-        frame_bytes_total = algorithmic_bytes(counters, B, faces) / B
-        share = {"vertex": 240.0 * faces, "raster": 4.0 * WIDTH * HEIGHT, "setup": 0.0, "bin": 0.0}
-        share["shade"] = frame_bytes_total - share["vertex"] - share["raster"]
-        if per_frame_ms["shade"] < 1e-6:
-            share["raster"] += share["shade"]
-            share["shade"] = 0.0
-        dominant = max(names, key=lambda n: per_frame_ms[n])
-        launch_ms = per_frame_ms[dominant]
-        bytes_per_launch = share[dominant]
+        frames_per_launch = passes / sequences
+        per_frame_ms = {k: v / passes for k, v in ms.items()}
+        share = kernel_frame_bytes(counters, B, faces)
+        dominant = max(per_frame_ms, key=lambda k: per_frame_ms[k])
+        launch_ms = per_frame_ms[dominant] * frames_per_launch
+        bytes_per_launch = share[dominant] * frames_per_launch
         achieved = bytes_per_launch / (launch_ms * 1e-3) / 1e9
         pipeline_ms = sum(per_frame_ms.values())
-        frame_achieved = frame_bytes_total / (pipeline_ms * 1e-3) / 1e9
+        frame_bytes = reference_frame_bytes(counters, B, faces)
+        frame_achieved = frame_bytes / (pipeline_ms * 1e-3) / 1e9
 
         result = {
             "metric": "fps @1080p 'pbr helmet' (orbit batch)", "value": fps, "unit": "frames/s",
@@ -185,14 +196,16 @@ def main():
             "ms_per_frame": elapsed / total_frames * 1e3,
             "shaded_fragments_per_frame": shaded_per_frame,
             "shaded_mfrags_per_s": shaded_per_frame * fps / 1e6,
+            "fragments_shaded_on_device_per_frame": counters[8] / B,
             "kernel_ms_per_frame": per_frame_ms,
-            "roofline": {"bound": "hbm", "kernel": "rz_%s_kernel" % dominant, "achieved": achieved,
+            "roofline": {"bound": "hbm", "kernel": KERNEL_SYMBOL[dominant], "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "algorithmic_bytes_per_launch": bytes_per_launch,
-                         "launch_ms": launch_ms},
+                         "traffic": measured_traffic(KERNEL_SYMBOL[dominant], frames_per_launch),
+                         "algorithmic_bytes_per_launch": bytes_per_launch, "launch_ms": launch_ms,
+                         "frames_per_launch": frames_per_launch},
             "frame_roofline": {"bound": "hbm", "achieved": frame_achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": frame_achieved / HBM_PEAK_GBS,
-                               "algorithmic_bytes_per_frame": frame_bytes_total,
+                               "algorithmic_bytes_per_frame": frame_bytes,
                                "kernel_ms_per_frame_total": pipeline_ms},
         }
         if world == 1 and not args.no_cpu:

@@ -253,17 +253,20 @@ void *mi355r_stream(void);              /* hipStream_t of the pipeline */
  * 1 triangles rasterised after clip/cull, 2 fragments shaded (the reference's
  * draw_fragment calls, graphics.c:437), 3 bin-list entries, 4 passes,
  * 5 draws, 6 skybox fragments, 7 blended fragments, 8 fragments the device
- * actually shaded (deferred shading skips fragments that get overdrawn). */
+ * actually shaded (deferred shading skips fragments that get overdrawn),
+ * 9 skybox fragments among those. */
 void mi355r_get_counters(unsigned long long out[12]);
 void mi355r_reset_counters(void);
 void mi355r_enable_counters(int on);
 
 /* Device time per kernel, from HIP events recorded on the pipeline's stream
- * around each launch while enabled: out_ms[0..4] = summed milliseconds of the
- * vertex, setup+clip, bin, raster and per-family shade kernels; returns the
- * number of passes. */
+ * around each launch while enabled (passes then run on one stream, so that a
+ * kernel has the device to itself): out[0..6] = summed milliseconds of the
+ * vertex, setup+clip, bin, raster, skybox-shade, blinn-shade and pbr-shade
+ * kernels, out[7] = launch sequences timed (one sequence covers a batch of
+ * passes); returns the number of passes. */
 void mi355r_enable_timing(int on);
-unsigned long long mi355r_get_timing(double out_ms[5], int reset);
+unsigned long long mi355r_get_timing(double out[8], int reset);
 
 /* Inspection of the geometry stage of the most recently submitted pass
  * (a pass = a maximal run of draws into one framebuffer).  No counterpart in

@@ -174,11 +174,13 @@ class Pipeline:
         self.release(fb)
         return out
 
+    KERNELS = ["vertex", "setup", "bin", "raster", "shade_skybox", "shade_blinn", "shade_pbr"]
+
     def kernel_times(self, reset=True):
-        """(passes, [vertex, setup, bin, raster, shade] summed ms) since timing was enabled/reset."""
-        ms = (C.c_double * 5)()
-        n = self.lib.mi355r_get_timing(ms, 1 if reset else 0)
-        return int(n), list(ms)
+        """(passes, launch sequences, {kernel: summed ms}) since timing was enabled/reset."""
+        out = (C.c_double * 8)()
+        n = self.lib.mi355r_get_timing(out, 1 if reset else 0)
+        return int(n), int(out[7]), dict(zip(self.KERNELS, list(out)[:7]))
 
     def counters(self):
         out = (C.c_ulonglong * 12)()

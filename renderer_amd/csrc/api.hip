@@ -150,9 +150,10 @@ struct Context {
     std::vector<Registered> families;
     /* measurement */
     bool timing = false;
-    std::vector<hipEvent_t> timing_events;  /* 6 per pass: before vertex, after vertex/setup/bin/raster/shade */
+    std::vector<hipEvent_t> timing_events;  /* 8 per launch sequence: before vertex, after each of the 7 timed kernels */
     std::vector<unsigned> timing_passes;    /* passes per timed launch sequence */
-    double kernel_ms[5] = {0, 0, 0, 0, 0};
+    double kernel_ms[7] = {0, 0, 0, 0, 0, 0, 0};
+    unsigned long long timed_sequences = 0;
     unsigned long long kernel_launches = 0;
     bool counting = false;
     unsigned long long *d_counters = nullptr;
@@ -1076,19 +1077,21 @@ static void launch_batch(const Batch &b, const std::vector<PassPlan> &plans, cha
         /* blended fragments read the colour below them: visibility and shading stay in one kernel */
         rz_raster_kernel<false><<<tiles, dim3(256), 0, st>>>(
             passes, L.tri.ptr, L.fan_tri.ptr, L.bin_list.ptr, L.vary.ptr, L.fan_vary.ptr, db, L.bin_range.ptr);
-        stamp();
+        stamp(); stamp(); stamp(); stamp();
     } else {
         rz_raster_kernel<true><<<tiles, dim3(256), 0, st>>>(
             passes, L.tri.ptr, L.fan_tri.ptr, L.bin_list.ptr, L.vary.ptr, L.fan_vary.ptr, db, L.bin_range.ptr);
         stamp();
         if (b.families & (1 << RZ_FAMILY_SKYBOX))
             rz_shade_kernel<2><<<tiles, dim3(256), 0, st>>>(passes, L.tri.ptr, L.fan_tri.ptr, L.vary.ptr, L.fan_vary.ptr, db, L.ref.ptr);
+        stamp();
         if (b.families & (1 << RZ_FAMILY_BLINN))
             rz_shade_kernel<0><<<tiles, dim3(256), 0, st>>>(passes, L.tri.ptr, L.fan_tri.ptr, L.vary.ptr, L.fan_vary.ptr, db, L.ref.ptr);
+        stamp();
         if (b.families & (1 << RZ_FAMILY_PBR))
             rz_shade_kernel<1><<<tiles, dim3(256), 0, st>>>(passes, L.tri.ptr, L.fan_tri.ptr, L.vary.ptr, L.fan_vary.ptr, db, L.ref.ptr);
+        stamp();
     }
-    stamp();
     HIP_OK(hipGetLastError());
     if (g.timing) g.timing_passes.push_back(n);
 }
@@ -1296,13 +1299,15 @@ extern "C" void mi355r_get_counters(unsigned long long out[12]) {
     out[6] = dev[6];
     out[7] = dev[7];
     out[8] = dev[8];
+    out[9] = dev[9];
 }
 
 /* Per-kernel device time, measured with HIP events on the pipeline's own
- * stream around every launch while enabled.  out_ms: summed milliseconds of
- * the vertex, setup+clip, bin, raster and shade kernels (shade is zero for
- * passes whose shading runs inside the raster kernel); returns the number of
- * passes. */
+ * stream around every launch while enabled.  out[0..6]: summed milliseconds of
+ * the vertex, setup+clip, bin, raster, skybox-shade, blinn-shade and pbr-shade
+ * kernels (the shade slots stay zero for passes whose shading runs inside the
+ * raster kernel); out[7]: launch sequences timed (each covers a batch of
+ * passes); returns the number of passes. */
 extern "C" void mi355r_enable_timing(int on) {
     ensure_ready();
     graphics_flush();
@@ -1310,24 +1315,26 @@ extern "C" void mi355r_enable_timing(int on) {
     g.timing = on != 0;
 }
 
-extern "C" unsigned long long mi355r_get_timing(double out_ms[5], int reset) {
+extern "C" unsigned long long mi355r_get_timing(double out[8], int reset) {
     ensure_ready();
     graphics_flush();
     sync_stream();
-    for (size_t i = 0, b = 0; i + 5 < g.timing_events.size(); i += 6, b++) {
-        for (int k = 0; k < 5; k++) {
+    for (size_t i = 0, b = 0; i + 7 < g.timing_events.size(); i += 8, b++) {
+        for (int k = 0; k < 7; k++) {
             float ms = 0;
             HIP_OK(hipEventElapsedTime(&ms, g.timing_events[i + k], g.timing_events[i + k + 1]));
             g.kernel_ms[k] += ms;
         }
         g.kernel_launches += b < g.timing_passes.size() ? g.timing_passes[b] : 1;
+        g.timed_sequences++;
     }
     g.timing_passes.clear();
     for (hipEvent_t e : g.timing_events) HIP_OK(hipEventDestroy(e));
     g.timing_events.clear();
-    for (int k = 0; k < 5; k++) out_ms[k] = g.kernel_ms[k];
+    for (int k = 0; k < 7; k++) out[k] = g.kernel_ms[k];
+    out[7] = (double)g.timed_sequences;
     unsigned long long n = g.kernel_launches;
-    if (reset) { for (int k = 0; k < 5; k++) g.kernel_ms[k] = 0; g.kernel_launches = 0; }
+    if (reset) { for (int k = 0; k < 7; k++) g.kernel_ms[k] = 0; g.kernel_launches = 0; g.timed_sequences = 0; }
     return n;
 }
 

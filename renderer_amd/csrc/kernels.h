@@ -602,7 +602,10 @@ RZ_DEV void shade_lanes(const PassParams &P, const DrawRec *__restrict__ draw_ta
         }
         if (P.counters) {       /* [8] fragments actually shaded on the device */
             unsigned long long n = (unsigned long long)__popcll(__ballot(sel));
-            if (lane == 0) atomicAdd(P.counters + 8, n);
+            if (lane == 0) {
+                atomicAdd(P.counters + 8, n);
+                if (D.family == 2) atomicAdd(P.counters + 9, n);    /* [9] of those, skybox */
+            }
         }
     }
 }

@@ -1,0 +1,48 @@
+"""One rank of the CPU rehearsal of the multi-GPU orbit: renders its shard of the views with the
+CPU oracle (test infrastructure), gathers RGBA8 frames on rank 0 over gloo, and rank 0 checks
+them against rendering every view itself.  Started by tests/test_orbit_gloo.py."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+from renderer_amd import orbit                                  # noqa: E402
+from renderer_amd.binding import Pipeline                       # noqa: E402
+
+
+def main():
+    total, width, height = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    pipe = Pipeline(os.path.join(REPO, "oracle", "liboracle.so"))
+    scene = pipe.open_scene("helmet")
+    first, last = orbit.shard_views(total, rank, world)
+    block = max(orbit.shard_views(total, r, world)[1] - orbit.shard_views(total, r, world)[0] for r in range(world))
+    fbs = [pipe.framebuffer(width, height) for _ in range(block)]
+    views = [pipe.orbit_view(i, total) for i in range(first, last)]
+    orbit.render_views(pipe, scene, fbs, views)
+    local = torch.zeros((block, height, width, 4), dtype=torch.uint8)
+    orbit.frames_to_tensor(pipe, fbs, last - first, local)
+    gathered = orbit.gather_frames(local, rank, world)
+    # the timing reduction bench.py uses: MAX over ranks
+    t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    ok = True
+    if rank == 0:
+        frames = orbit.assemble(gathered, total, world)
+        ok = len(frames) == total and float(t.item()) == float(world)
+        for i, frame in enumerate(frames):
+            want, _ = pipe.render(scene, width, height, pipe.orbit_view(i, total))
+            ok = ok and np.array_equal(frame.numpy(), want)
+        print("ORBIT_OK" if ok else "ORBIT_MISMATCH", flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+    sys.exit(0 if ok else 1)
+
+
+if __name__ == "__main__":
+    main()

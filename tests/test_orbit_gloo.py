@@ -1,0 +1,48 @@
+"""The N > 1 path of the orbit batch on CPU: sharding arithmetic, and a world_size-2 gloo run
+(one process per rank, as on the GPUs) whose gathered frames must equal a single-process render."""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+from conftest import REPO
+from renderer_amd.orbit import shard_views
+
+
+def test_shards_partition_the_views():
+    for total in [0, 1, 7, 64, 8192]:
+        for world in [1, 2, 3, 4, 8]:
+            blocks = [shard_views(total, r, world) for r in range(world)]
+            assert blocks[0][0] == 0 and blocks[-1][1] == total
+            assert all(blocks[r][1] == blocks[r + 1][0] for r in range(world - 1))
+            sizes = [b - a for a, b in blocks]
+            assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        shard_views(8, 2, 2)
+
+
+@pytest.mark.parametrize("world,total", [(2, 5), (2, 4)])
+def test_gloo_orbit_gather(oracle, world, total):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(REPO, "tests", "orbit_worker.py"), str(total), "96", "54"],
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=300)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append(out)
+    assert all(p.returncode == 0 for p in procs), outs
+    assert "ORBIT_OK" in outs[0], outs[0]

@@ -50,3 +50,20 @@ for k, (calls, avg, pct) in sorted(stats.items(), key=lambda kv: -kv[1][2]):
         if c == "WRITE_SIZE":
             note = f"  KiB -> {mean * 1024 / 1e6:.2f} MB/launch"
         print(f"    {c:28s} {mean:16.1f}{note}")
+
+# machine-readable HBM traffic per launch for bench.py's roofline.traffic
+import json
+frames = int(sys.argv[2]) if len(sys.argv) > 2 else None
+traffic = {"frames_per_launch": frames, "unit": "bytes per launch",
+           "note": "hbm_bytes_per_launch = 2 x FETCH_SIZE + WRITE_SIZE (KiB -> bytes); the factor 2 is the gfx950 "
+                   "correction for wide coalesced reads and an upper bound for 16-byte gathers",
+           "kernels": {}}
+for k in stats:
+    c = pmc.get(k, {})
+    if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+        fetch = sum(c["FETCH_SIZE"]) / len(c["FETCH_SIZE"]) * 1024
+        write = sum(c["WRITE_SIZE"]) / len(c["WRITE_SIZE"]) * 1024
+        traffic["kernels"][k] = {"fetch_size_bytes_raw": fetch, "write_size_bytes": write,
+                                 "hbm_bytes_per_launch": 2 * fetch + write,
+                                 "median_us": median(durations.get(k, []))}
+json.dump(traffic, open(os.path.join(out, "traffic.json"), "w"), indent=1)
