@@ -6,9 +6,9 @@
  * denormals on, so everything except the double-precision pow() calls is
  * bit-identical to the strict CPU path.
  *
- * A fragment shader here runs for the lanes of one wave that passed the depth
- * test of ONE triangle: the draw's uniforms are wave-uniform (scalar loads),
- * varyings are per lane.
+ * A fragment shader here runs for lanes of one wave whose fragments belong to
+ * ONE draw (whatever triangle each lane's fragment comes from): the draw's
+ * uniforms are wave-uniform (scalar loads), varyings are per lane.
  */
 #ifndef RZ_SHADE_H
 #define RZ_SHADE_H
