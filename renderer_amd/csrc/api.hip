@@ -117,6 +117,7 @@ struct Lane {
     DevBuf<uint2> bbox;
     DevBuf<uint32_t> clip_list, ref;
     DevBuf<uint2> bin_range;
+    DevBuf<uint32_t> bin_counts;
     DevBuf<BinEntry> bin_list;
 };
 
@@ -254,7 +255,7 @@ static bool has_pending_for(Fb *fb) {
 
 extern "C" rz_framebuffer *framebuffer_create(int width, int height) {
     ensure_ready();
-    if (width <= 0 || height <= 0 || width > 65535 || height > 65535) fatal("framebuffer size %dx%d", width, height);
+    if (width <= 0 || height <= 0 || width > 16384 || height > 16384) fatal("framebuffer size %dx%d (at most 16384x16384)", width, height);
     Fb *fb = new Fb();
     size_t n = (size_t)width * height;
     fb->pub.width = width;
@@ -955,7 +956,7 @@ static void prepare_batch(const Batch &b, const std::vector<PassPlan> &plans, ch
                           bool reserve_only) {
     Lane &L = g.lanes[b.lane];
     hipStream_t st = L.stream;
-    size_t tris = 0, fans = 0, lists = 0, bins = 0, pixels = 0;
+    size_t tris = 0, fans = 0, lists = 0, bins = 0, pixels = 0, matrix = 0;
     std::vector<size_t> fan_cap, list_cap;
     for (size_t i = b.first; i < b.last; i++) {
         const PassPlan &pl = plans[i];
@@ -963,6 +964,7 @@ static void prepare_batch(const Batch &b, const std::vector<PassPlan> &plans, ch
         fan_cap.push_back(std::min<size_t>(pl.T, 1u << 18));
         list_cap.push_back(std::min<size_t>(pl.T * 8 * nb, std::max<size_t>(pl.T * 16, 1u << 18)));
         tris += pl.T; fans += fan_cap.back(); lists += list_cap.back(); bins += nb;
+        matrix += ((pl.T + 63) / 64) * nb;
         pixels += (size_t)pl.fb->pub.width * pl.fb->pub.height;
     }
     reserve(L.clip, tris * 3 * 4, st);
@@ -973,11 +975,12 @@ static void prepare_batch(const Batch &b, const std::vector<PassPlan> &plans, ch
     reserve(L.fan_tri, fans * RZ_MAX_FAN, st);
     reserve(L.fan_vary, fans * RZ_MAX_POLY * RZ_VARY_STRIDE, st);
     reserve(L.bin_range, bins, st);
+    reserve(L.bin_counts, matrix, st);
     reserve(L.bin_list, lists, st);
     if (!b.has_blend) reserve(L.ref, pixels, st);
     if (reserve_only) return;
 
-    size_t tri_off = 0, fan_off = 0, list_off = 0, bin_off = 0, ref_off = 0;
+    size_t tri_off = 0, fan_off = 0, list_off = 0, bin_off = 0, ref_off = 0, matrix_off = 0;
     const char *dbg = getenv("MI355R_DEBUG_SKIP");
     for (size_t i = b.first; i < b.last; i++) {
         const PassPlan &pl = plans[i];
@@ -1009,6 +1012,7 @@ static void prepare_batch(const Batch &b, const std::vector<PassPlan> &plans, ch
         P.bins_x = (W + RZ_BIN - 1) / RZ_BIN;
         P.bins_y = (H + RZ_BIN - 1) / RZ_BIN;
         P.bin_range = L.bin_range.ptr + bin_off;
+        P.bin_counts = L.bin_counts.ptr + matrix_off;
         P.bin_list = L.bin_list.ptr + list_off;
         P.bin_capacity = (uint32_t)list_cap[k];
         P.ref = L.ref.ptr ? L.ref.ptr + ref_off : nullptr;
@@ -1027,6 +1031,7 @@ static void prepare_batch(const Batch &b, const std::vector<PassPlan> &plans, ch
         g.have_last_pass = true;
         tri_off += pl.T; fan_off += fan_cap[k]; list_off += list_cap[k];
         bin_off += (size_t)P.bins_x * P.bins_y;
+        matrix_off += ((pl.T + 63) / 64) * (size_t)P.bins_x * P.bins_y;
         ref_off += (size_t)W * H;
         fb->clear_color_pending = fb->clear_depth_pending = false;
         g.host_counters[0] += pl.T;
@@ -1071,7 +1076,18 @@ static void launch_batch(const Batch &b, const std::vector<PassPlan> &plans, cha
     rz_setup_kernel<<<tgrid, dim3(256), 0, st>>>(passes);
     rz_clip_kernel<<<dim3(256, n), dim3(64), 0, st>>>(passes);
     stamp();
-    rz_bin_kernel<<<dim3((unsigned)max_bins, n), dim3(RZ_BIN_WAVES * 64), 0, st>>>(passes);
+    {
+        size_t matrix = 0;
+        for (size_t i = b.first; i < b.last; i++) {
+            const PassPlan &pl = plans[i];
+            const int W = pl.fb->pub.width, H = pl.fb->pub.height;
+            matrix += ((pl.T + 63) / 64) * (size_t)((W + RZ_BIN - 1) / RZ_BIN) * ((H + RZ_BIN - 1) / RZ_BIN);
+        }
+        HIP_OK(hipMemsetAsync(L.bin_counts.ptr, 0, matrix * sizeof(uint32_t), st));
+    }
+    rz_bin_count_kernel<<<tgrid, dim3(256), 0, st>>>(passes);
+    rz_bin_scan_kernel<<<dim3((unsigned)((max_bins + 63) / 64), n), dim3(64 * RZ_SCAN_SEGMENTS), 0, st>>>(passes);
+    rz_bin_fill_kernel<<<dim3((unsigned)((max_T + 63) / 64), n), dim3(64 * RZ_FILL_WAVES), 0, st>>>(passes);
     stamp();
     if (b.has_blend) {
         /* blended fragments read the colour below them: visibility and shading stay in one kernel */
@@ -1222,9 +1238,13 @@ extern "C" void mi355r_inspect_boxes(unsigned int *boxes, unsigned int *fans) {
     HIP_OK(hipMemcpy(boxes, P.bbox, T * sizeof(uint2), hipMemcpyDeviceToHost));
     HIP_OK(hipMemcpy(recs.data(), P.tri, T * sizeof(TriRec), hipMemcpyDeviceToHost));
     for (size_t t = 0; t < T; t++) {
+        /* device packing (pack_bin_box): y0 | y1 << 14 | entries << 28 */
         const bool empty = (boxes[2 * t] & 0xffffu) > (boxes[2 * t] >> 16);
-        /* a record is only written for a triangle with a non-empty box */
-        fans[t] = empty ? 0u : (RZ_META_CLIPPED(recs[t].meta) ? RZ_META_FAN(recs[t].meta) : 1u);
+        const uint32_t y = boxes[2 * t + 1];
+        fans[t] = empty ? 0u : y >> 28;
+        boxes[2 * t + 1] = empty ? RZ_BBOX_EMPTY_X : ((y & 0x3fffu) | (((y >> 14) & 0x3fffu) << 16));
+        if (!empty && fans[t] != (RZ_META_CLIPPED(recs[t].meta) ? RZ_META_FAN(recs[t].meta) : 1u))
+            fatal("triangle %zu: packed entry count %u disagrees with its record", t, fans[t]);
     }
 }
 

@@ -210,6 +210,14 @@ RZ_DEV bool make_tri(const f4 c[3], int width, int height, bool double_sided, ui
     return true;
 }
 
+/* What the binning kernel reads per input triangle: x0 | x1 << 16 and
+ * y0 | y1 << 14 | entries << 28, entries = list entries the triangle adds to a
+ * bin it touches (1, or the length of its fan).  Framebuffers are at most
+ * 16384 pixels high, so 14 bits per y bound are enough. */
+RZ_DEV uint2 pack_bin_box(uint32_t bx, uint32_t by, uint32_t entries) {
+    return make_uint2(bx, (by & 0x3fffu) | ((by >> 16) << 14) | (entries << 28));
+}
+
 RZ_DEV void store_tri(TriRec *dst, const TriRec &r) {
     float4 *o = (float4*)dst;
     o[0] = make_float4(r.ax, r.ay, r.abx, r.aby);
@@ -240,7 +248,7 @@ __global__ void __launch_bounds__(256) rz_setup_kernel(const PassParams *__restr
         if (make_tri(c, P.width, P.height, double_sided, (uint32_t)d, rec, x0, x1, y0, y1)) {
             rec.meta |= class_bits;
             store_tri(&P.tri[t], rec);
-            P.bbox[t] = make_uint2(rec.bx, rec.by);
+            P.bbox[t] = pack_bin_box(rec.bx, rec.by, 1u);
             if (P.counters) atomicAdd(&P.counters[1], 1ull);
         } else {
             P.bbox[t] = empty;
@@ -358,7 +366,7 @@ __global__ void __launch_bounds__(64) rz_clip_kernel(const PassParams *__restric
                 head.bx = (uint32_t)ux0 | ((uint32_t)ux1 << 16);
                 head.by = (uint32_t)uy0 | ((uint32_t)uy1 << 16);
                 store_tri(&P.tri[t], head);
-                P.bbox[t] = make_uint2(head.bx, head.by);
+                P.bbox[t] = pack_bin_box(head.bx, head.by, (uint32_t)fan);
             }
         }
     }
@@ -381,14 +389,109 @@ RZ_DEV bool box_overlaps(uint2 bb, int rx0, int ry0, int rx1, int ry1) {
     return x0 <= rx1 && x1 >= rx0 && y0 <= ry1 && y1 >= ry0;
 }
 
-#define RZ_BIN_WAVES 16
+/* The triangle range is cut into chunks of 64 (one wave each).  counts[c][b]
+ * = list entries chunk c adds to bin b.  Three small kernels:
+ *   count  every triangle adds its entry count to the bins its box touches
+ *   scan   per bin, exclusive prefix over the chunks -> where each chunk's
+ *          entries start in the bin's list; one atomic reserves the list
+ *   fill   every chunk writes its entries bin by bin, lanes in order
+ * so a list is ascending in (chunk, lane, fan index) = submission order. */
 
-/* entries a triangle contributes to a bin it touches: one, or one per fan
- * triangle when it was clipped (the fan keeps its order inside the list) */
-RZ_DEV uint32_t bin_entries_of(const PassParams &P, uint32_t t, bool hit) {
-    if (!hit) return 0u;
-    uint32_t meta = P.tri[t].meta;
-    return RZ_META_CLIPPED(meta) ? RZ_META_FAN(meta) : 1u;
+struct BinRect { int bx0, bx1, by0, by1; uint32_t entries; };
+
+/* bins touched by a packed box (pack_bin_box); entries == 0: none */
+RZ_DEV BinRect bin_rect_of(uint2 bb) {
+    BinRect r;
+    int x0 = (int)(bb.x & 0xffffu), x1 = (int)(bb.x >> 16);
+    int y0 = (int)(bb.y & 0x3fffu), y1 = (int)((bb.y >> 14) & 0x3fffu);
+    r.entries = x0 <= x1 ? bb.y >> 28 : 0u;
+    r.bx0 = x0 / RZ_BIN; r.bx1 = x1 / RZ_BIN; r.by0 = y0 / RZ_BIN; r.by1 = y1 / RZ_BIN;
+    return r;
+}
+
+#define RZ_BCAST_F(v, j) __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), (j)))
+#define RZ_BCAST_I(v, j) __builtin_amdgcn_readlane((int)(v), (j))
+
+__global__ void __launch_bounds__(256) rz_bin_count_kernel(const PassParams *__restrict__ passes) {
+    const PassParams &P = passes[blockIdx.y];
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    if ((t & ~63u) >= (uint32_t)P.num_tris) return;             /* uniform over the wave */
+    BinRect r;
+    r.entries = 0; r.bx0 = r.bx1 = r.by0 = r.by1 = 0;
+    if (t < (uint32_t)P.num_tris) r = bin_rect_of(P.bbox[t]);
+    uint32_t *row = P.bin_counts + (size_t)(t >> 6) * (uint32_t)(P.bins_x * P.bins_y);
+    const int w = r.bx1 - r.bx0 + 1, area = w * (r.by1 - r.by0 + 1);
+    /* a triangle over many bins (a sky box face) is spread over the wave's lanes */
+    unsigned long long big = __ballot(r.entries != 0 && area > 8);
+    if (r.entries != 0 && area <= 8) {
+        for (int by = r.by0; by <= r.by1; by++)
+            for (int bx = r.bx0; bx <= r.bx1; bx++) atomicAdd(&row[by * P.bins_x + bx], r.entries);
+    }
+    while (big) {
+        const int L = __ffsll((long long)big) - 1;
+        big &= big - 1;
+        const int x0 = RZ_BCAST_I(r.bx0, L), y0 = RZ_BCAST_I(r.by0, L), wL = RZ_BCAST_I(w, L), aL = RZ_BCAST_I(area, L);
+        const uint32_t e = (uint32_t)RZ_BCAST_I(r.entries, L);
+        for (int i = lane; i < aL; i += 64) atomicAdd(&row[(y0 + i / wL) * P.bins_x + x0 + i % wL], e);
+    }
+}
+
+/* 1024 threads = 64 bins x 16 segments of the chunk range */
+#define RZ_SCAN_SEGMENTS 16
+__global__ void __launch_bounds__(64 * RZ_SCAN_SEGMENTS) rz_bin_scan_kernel(const PassParams *__restrict__ passes) {
+    const PassParams &P = passes[blockIdx.y];
+    __shared__ uint32_t s_part[RZ_SCAN_SEGMENTS][64];
+    const int bins = P.bins_x * P.bins_y;
+    if ((int)(blockIdx.x * 64u) >= bins) return;
+    const int bin = (int)(blockIdx.x * 64u) + (threadIdx.x & 63), segment = threadIdx.x >> 6;
+    const uint32_t chunks = ((uint32_t)P.num_tris + 63u) / 64u;
+    const uint32_t per = (chunks + RZ_SCAN_SEGMENTS - 1u) / RZ_SCAN_SEGMENTS;
+    const uint32_t c0 = min((uint32_t)segment * per, chunks), c1 = min(c0 + per, chunks);
+    uint32_t *col = P.bin_counts + bin;
+    uint32_t sum = 0;
+    if (bin < bins) {
+        for (uint32_t c = c0; c < c1; c += 8u) {
+            uint32_t v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) v[u] = (c + u) < c1 ? col[(size_t)(c + u) * bins] : 0u;
+#pragma unroll
+            for (int u = 0; u < 8; u++) sum += v[u];
+        }
+    }
+    s_part[segment][threadIdx.x & 63] = sum;
+    __syncthreads();
+    uint32_t before = 0, total = 0;
+    for (int q = 0; q < RZ_SCAN_SEGMENTS; q++) {
+        uint32_t v = s_part[q][threadIdx.x & 63];
+        if (q < segment) before += v;
+        total += v;
+    }
+    /* every segment's thread of a bin needs the list's start: segment 0 reserves it */
+    __syncthreads();
+    if (segment == 0 && bin < bins) {
+        uint32_t start = total ? atomicAdd(&P.control[1], total) : 0u;
+        if (start + total > P.bin_capacity) {
+            atomicOr(&P.control[2], (uint32_t)RZ_ERR_BIN_OVERFLOW);
+            total = 0;
+        }
+        P.bin_range[bin] = make_uint2(start, total);
+        s_part[0][threadIdx.x & 63] = total ? start : 0xffffffffu;
+    }
+    __syncthreads();
+    const uint32_t start = s_part[0][threadIdx.x & 63];
+    if (bin >= bins || start == 0xffffffffu) return;    /* empty or overflowed bin: its entries are never written */
+    uint32_t run = start + before;
+    for (uint32_t c = c0; c < c1; c += 8u) {
+        uint32_t v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = (c + u) < c1 ? col[(size_t)(c + u) * bins] : 0u;
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            if ((c + u) < c1) col[(size_t)(c + u) * bins] = run;    /* count -> first entry of the chunk */
+            run += v[u];
+        }
+    }
 }
 
 RZ_DEV uint32_t wave_exclusive_scan(uint32_t v, uint32_t *total) {
@@ -402,78 +505,125 @@ RZ_DEV uint32_t wave_exclusive_scan(uint32_t v, uint32_t *total) {
     return inc - v;
 }
 
-/* Wave w owns the w-th contiguous slice of the triangle range, so the list is
- * the concatenation of the waves' hits: one barrier in the whole kernel.
- * Every entry carries a copy of the triangle's record (BinEntry). */
-__global__ void __launch_bounds__(RZ_BIN_WAVES * 64) rz_bin_kernel(const PassParams *__restrict__ passes) {
+RZ_DEV int wave_min_i(int v) {
+    for (int off = 32; off > 0; off >>= 1) v = min(v, __shfl_xor(v, off));
+    return v;
+}
+
+RZ_DEV int wave_max_i(int v) {
+    for (int off = 32; off > 0; off >>= 1) v = max(v, __shfl_xor(v, off));
+    return v;
+}
+
+#define RZ_FILL_FAN_SLOTS 64
+
+/* One workgroup of RZ_FILL_WAVES waves per chunk.  Lanes first hold the
+ * chunk's 64 triangles (box, record), then turn into BINS: the chunk's joint
+ * bin rectangle is cut into rounds of 64 bins, wave w takes rounds w,
+ * w + RZ_FILL_WAVES, ..., lane i of a round one bin, and walks the 64
+ * triangles in order (their data broadcast with readlane), appending those
+ * that touch its bin.  No lane waits on another and the only dependent loads
+ * are the per-bin start offsets.  Every entry carries a copy of the
+ * triangle's record. */
+#define RZ_FILL_WAVES 4
+__global__ void __launch_bounds__(64 * RZ_FILL_WAVES) rz_bin_fill_kernel(const PassParams *__restrict__ passes) {
     const PassParams &P = passes[blockIdx.y];
-    __shared__ uint32_t s_count[RZ_BIN_WAVES];
-    __shared__ uint32_t s_start;
-    const int bin = blockIdx.x;
-    if (bin >= P.bins_x * P.bins_y) return;
-    const int rx0 = (bin % P.bins_x) * RZ_BIN, ry0 = (bin / P.bins_x) * RZ_BIN;
-    const int rx1 = rx0 + RZ_BIN - 1, ry1 = ry0 + RZ_BIN - 1;
+    const uint32_t chunk = blockIdx.x;
+    if (chunk * 64u >= (uint32_t)P.num_tris) return;            /* uniform over the workgroup */
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t T = (uint32_t)P.num_tris;
-    const uint32_t chunks = (T + 63u) / 64u;
-    const uint32_t per_wave = (chunks + RZ_BIN_WAVES - 1) / RZ_BIN_WAVES;
-    const uint32_t c0 = min((uint32_t)wave * per_wave, chunks), c1 = min(c0 + per_wave, chunks);
-
-    uint32_t mine = 0;
-    for (uint32_t c = c0; c < c1; c += 4u) {
-        bool hit[4];
-        for (int u = 0; u < 4; u++) {           /* four independent loads in flight */
-            uint32_t t = (c + u) * 64u + lane;
-            hit[u] = (c + u) < c1 && t < T && box_overlaps(P.bbox[t], rx0, ry0, rx1, ry1);
-        }
-        for (int u = 0; u < 4; u++) mine += bin_entries_of(P, (c + u) * 64u + lane, hit[u]);
+    const uint32_t t = chunk * 64u + lane;
+    const int bins = P.bins_x * P.bins_y;
+    BinRect r;
+    r.entries = 0; r.bx0 = r.bx1 = r.by0 = r.by1 = 0;
+    if (t < (uint32_t)P.num_tris) r = bin_rect_of(P.bbox[t]);
+    const unsigned long long active = __ballot(r.entries != 0);
+    if (!active) return;                                        /* same for every wave of the workgroup */
+    if (P.debug_skip == 5) return;
+    const int ux0 = wave_min_i(r.entries ? r.bx0 : 0x7fffffff), ux1 = wave_max_i(r.entries ? r.bx1 : -1);
+    const int uy0 = wave_min_i(r.entries ? r.by0 : 0x7fffffff), uy1 = wave_max_i(r.entries ? r.by1 : -1);
+    const int uw = ux1 - ux0 + 1, ubins = uw * (uy1 - uy0 + 1);
+    float4 r0 = make_float4(0, 0, 0, 0), r1 = r0, r2 = r0, r3 = r0;
+    uint32_t ref = t;
+    if (r.entries) {
+        const float4 *src = (const float4*)&P.tri[t];
+        r0 = src[0]; r1 = src[1]; r2 = src[2]; r3 = src[3];
+        if (RZ_META_CLIPPED(__float_as_uint(r3.y)))
+            ref = RZ_REF_FAN | (__float_as_uint(r0.x) * RZ_MAX_FAN);     /* first fan record */
     }
-    for (int off = 32; off > 0; off >>= 1) mine += __shfl_down(mine, off);
-    mine = (uint32_t)__builtin_amdgcn_readfirstlane((int)mine);
-    if (lane == 0) s_count[wave] = mine;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t total = 0;
-        for (int w = 0; w < RZ_BIN_WAVES; w++) total += s_count[w];
-        uint32_t start = total ? atomicAdd(&P.control[1], total) : 0u;
-        if (start + total > P.bin_capacity) {
-            atomicOr(&P.control[2], (uint32_t)RZ_ERR_BIN_OVERFLOW);
-            total = 0;
+    /* the chunk's fan records, staged in LDS by wave 0 so that the walk below has no dependent
+     * global loads (beyond RZ_FILL_FAN_SLOTS records per chunk they are read from memory) */
+    __shared__ float4 s_fan[RZ_FILL_FAN_SLOTS][4];
+    uint32_t slot = 0xffffffffu;
+    {
+        const bool clipped = r.entries && (ref & RZ_REF_FAN);
+        const uint32_t need = clipped ? r.entries : 0u;
+        uint32_t total;
+        const uint32_t first = wave_exclusive_scan(need, &total);
+        if (clipped && first + need <= RZ_FILL_FAN_SLOTS) {
+            slot = first;
+            if (wave == 0) {
+                for (uint32_t k = 0; k < need; k++) {
+                    const float4 *src = (const float4*)&P.fan_tri[(ref & ~RZ_REF_FAN) + k];
+                    for (int q = 0; q < 4; q++) s_fan[slot + k][q] = src[q];
+                }
+            }
         }
-        P.bin_range[bin] = make_uint2(start, total);
-        s_start = total ? start : 0xffffffffu;
+        if (total) __syncthreads();                             /* total is the same in every wave */
     }
-    __syncthreads();
-    uint32_t cursor = s_start;
-    if (cursor == 0xffffffffu || mine == 0) return;
-    for (int w = 0; w < wave; w++) cursor += s_count[w];
+    const uint32_t *row = P.bin_counts + (size_t)chunk * (uint32_t)bins;
+    const TriRec *__restrict__ fan_tri = P.fan_tri;
+    if (P.debug_skip == 6) return;
 
-    for (uint32_t c = c0; c < c1; c += 4u) {
-        bool hit[4];
-        for (int u = 0; u < 4; u++) {
-            uint32_t t = (c + u) * 64u + lane;
-            hit[u] = (c + u) < c1 && t < T && box_overlaps(P.bbox[t], rx0, ry0, rx1, ry1);
+    for (int base = wave * 64; base < ubins; base += 64 * RZ_FILL_WAVES) {
+        const int i = base + lane;
+        const bool have = i < ubins;
+        const int bx = ux0 + i % uw, by = uy0 + i / uw;
+        const int b = by * P.bins_x + bx;
+        uint32_t cursor = 0;
+        bool keep = false;
+        if (have) {
+            cursor = row[b];
+            keep = P.bin_range[b].y != 0;       /* zero: the list is empty or overflowed, nothing is kept */
         }
-        for (int u = 0; u < 4; u++) {
-            if (!__any(hit[u])) continue;
-            const uint32_t t = (c + u) * 64u + lane;
-            uint32_t n = bin_entries_of(P, t, hit[u]), total;
-            uint32_t at = cursor + wave_exclusive_scan(n, &total);
-            cursor += total;
-            if (n) {
-                const float4 *src = (const float4*)&P.tri[t];
-                float4 r0 = src[0], r1 = src[1], r2 = src[2], r3 = src[3];
-                uint32_t ref = t;
-                if (RZ_META_CLIPPED(__float_as_uint(r3.y))) {
-                    ref = RZ_REF_FAN | (__float_as_uint(r0.x) * RZ_MAX_FAN);     /* first fan record */
-                    src = (const float4*)&P.fan_tri[ref & ~RZ_REF_FAN];
+        unsigned long long todo = active;
+        while (todo) {
+            const int L = __ffsll((long long)todo) - 1;
+            todo &= todo - 1;
+            const int x0 = RZ_BCAST_I(r.bx0, L), x1 = RZ_BCAST_I(r.bx1, L);
+            const int y0 = RZ_BCAST_I(r.by0, L), y1 = RZ_BCAST_I(r.by1, L);
+            const bool hit = keep && bx >= x0 && bx <= x1 && by >= y0 && by <= y1 && P.debug_skip != 7;
+            if (!__any(hit)) continue;
+            const uint32_t e = (uint32_t)RZ_BCAST_I(r.entries, L);
+            const uint32_t refL = (uint32_t)RZ_BCAST_I(ref, L);
+            if (!(refL & RZ_REF_FAN)) {
+                const float4 q0 = make_float4(RZ_BCAST_F(r0.x, L), RZ_BCAST_F(r0.y, L), RZ_BCAST_F(r0.z, L), RZ_BCAST_F(r0.w, L));
+                const float4 q1 = make_float4(RZ_BCAST_F(r1.x, L), RZ_BCAST_F(r1.y, L), RZ_BCAST_F(r1.z, L), RZ_BCAST_F(r1.w, L));
+                const float4 q2 = make_float4(RZ_BCAST_F(r2.x, L), RZ_BCAST_F(r2.y, L), RZ_BCAST_F(r2.z, L), RZ_BCAST_F(r2.w, L));
+                const float4 q3 = make_float4(RZ_BCAST_F(r3.x, L), RZ_BCAST_F(r3.y, L), RZ_BCAST_F(r3.z, L), RZ_BCAST_F(r3.w, L));
+                if (hit) {
+                    float4 *dst = (float4*)&P.bin_list[cursor];
+                    dst[0] = make_float4(__uint_as_float(refL), 0.0f, 0.0f, 0.0f);
+                    dst[1] = q0; dst[2] = q1; dst[3] = q2; dst[4] = q3;
+                    cursor += 1u;
                 }
-                for (uint32_t k = 0; k < n; k++) {
-                    if (k || (ref & RZ_REF_FAN)) { r0 = src[4 * k]; r1 = src[4 * k + 1]; r2 = src[4 * k + 2]; r3 = src[4 * k + 3]; }
-                    float4 *dst = (float4*)&P.bin_list[at + k];
-                    dst[0] = make_float4(__uint_as_float(ref + k), 0.0f, 0.0f, 0.0f);
-                    dst[1] = r0; dst[2] = r1; dst[3] = r2; dst[4] = r3;
+            } else {
+                const uint32_t slotL = (uint32_t)RZ_BCAST_I(slot, L);
+                for (uint32_t k = 0; k < e; k++) {
+                    float4 q0, q1, q2, q3;
+                    if (slotL != 0xffffffffu) {
+                        q0 = s_fan[slotL + k][0]; q1 = s_fan[slotL + k][1];
+                        q2 = s_fan[slotL + k][2]; q3 = s_fan[slotL + k][3];
+                    } else {
+                        const float4 *src = (const float4*)&fan_tri[(refL & ~RZ_REF_FAN) + k];  /* uniform address */
+                        q0 = src[0]; q1 = src[1]; q2 = src[2]; q3 = src[3];
+                    }
+                    if (hit) {
+                        float4 *dst = (float4*)&P.bin_list[cursor + k];
+                        dst[0] = make_float4(__uint_as_float(refL + k), 0.0f, 0.0f, 0.0f);
+                        dst[1] = q0; dst[2] = q1; dst[3] = q2; dst[4] = q3;
+                    }
                 }
+                if (hit) cursor += e;
             }
         }
     }
@@ -660,7 +810,6 @@ RZ_DEV bool block_outside(float4 c0, float4 c1, float x0, float x1, float y0, fl
     return finite && (smax + es < -RZ_EPS || tmax + et < -RZ_EPS || wmax + ew < -RZ_EPS);
 }
 
-#define RZ_BCAST_F(v, j) __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), (j)))
 
 /* Rasteriser.  SPLIT = true: the pass has no blended draw, so one reference per
  * pixel is enough; the kernel resolves visibility only and leaves depth plus the

@@ -142,6 +142,7 @@ struct PassParams {
     uint32_t *clip_list;            /* triangles queued for the clipper (count in control[3]) */
     /* binning */
     int32_t bins_x, bins_y;
+    uint32_t *bin_counts;           /* [chunks of 64 triangles][bins]: entries, then first entry */
     uint2 *bin_range;               /* per bin: {first entry, entries} */
     BinEntry *bin_list;
     uint32_t bin_capacity;

@@ -1,0 +1,11 @@
+# parity tests, then the default bench; stops at the first failure
+set -e
+mkdir -p gpurun_out
+timeout -k 10 600 python -u -m pytest tests -m gpu -x -q --timeout 180 --timeout-method thread > gpurun_out/pytest_gpu.log 2>&1 || { tail -30 gpurun_out/pytest_gpu.log; exit 1; }
+tail -2 gpurun_out/pytest_gpu.log
+timeout -k 10 300 python bench.py --no-cpu > gpurun_out/bench_check.json
+python - <<'PY'
+import json
+r = json.load(open('gpurun_out/bench_check.json'))
+print(round(r['value']), 'fps', {k: round(v * 1000, 1) for k, v in r['kernel_ms_per_frame'].items()})
+PY
