@@ -1019,7 +1019,8 @@ static void prepare_batch(const Batch &b, const std::vector<PassPlan> &plans, ch
         P.control = (uint32_t*)(db + controls_at + CONTROL_BYTES * i);
         P.counters = g.counting ? g.d_counters : nullptr;
         P.debug_skip = dbg ? atoi(dbg) : 0;
-        P.num_tiles = ((W + RZ_TILE_W - 1) / RZ_TILE_W) * ((H + RZ_TILE_H - 1) / RZ_TILE_H);
+        P.tiles_x = (W + RZ_TILE_W - 1) / RZ_TILE_W;
+        P.tiles_y = (H + RZ_TILE_H - 1) / RZ_TILE_H;
         P.tri_off = (uint32_t)tri_off;
         P.fan_off = (uint32_t)fan_off;
         P.list_off = (uint32_t)list_off;
@@ -1044,13 +1045,14 @@ static void launch_batch(const Batch &b, const std::vector<PassPlan> &plans, cha
     Lane &L = g.lanes[b.lane];
     hipStream_t st = L.stream;
     const unsigned n = (unsigned)(b.last - b.first);
-    size_t max_T = 0, max_bins = 0, max_tiles = 0;
+    size_t max_T = 0, max_bins = 0, max_tiles_x = 0, max_tiles_y = 0;
     for (size_t i = b.first; i < b.last; i++) {
         const PassPlan &pl = plans[i];
         const int W = pl.fb->pub.width, H = pl.fb->pub.height;
         max_T = std::max(max_T, pl.T);
         max_bins = std::max(max_bins, (size_t)((W + RZ_BIN - 1) / RZ_BIN) * ((H + RZ_BIN - 1) / RZ_BIN));
-        max_tiles = std::max(max_tiles, (size_t)((W + RZ_TILE_W - 1) / RZ_TILE_W) * ((H + RZ_TILE_H - 1) / RZ_TILE_H));
+        max_tiles_x = std::max(max_tiles_x, (size_t)((W + RZ_TILE_W - 1) / RZ_TILE_W));
+        max_tiles_y = std::max(max_tiles_y, (size_t)((H + RZ_TILE_H - 1) / RZ_TILE_H));
     }
     const PassParams *passes = (const PassParams*)(db + b.off_params);
     static const bool paranoid = getenv("MI355R_SYNC") != nullptr;     /* debugging: fence + check after every kernel */
@@ -1069,7 +1071,7 @@ static void launch_batch(const Batch &b, const std::vector<PassPlan> &plans, cha
         g.timing_events.push_back(e);
     };
     const dim3 vgrid((unsigned)((max_T * 3 + 255) / 256), n), tgrid((unsigned)((max_T + 255) / 256), n);
-    const dim3 tiles((unsigned)max_tiles, n);
+    const dim3 tiles((unsigned)max_tiles_x, (unsigned)max_tiles_y, n);
     stamp();
     rz_vertex_kernel<<<vgrid, dim3(256), 0, st>>>(passes);
     stamp();

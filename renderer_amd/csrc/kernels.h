@@ -826,8 +826,9 @@ __global__ void __launch_bounds__(256) rz_raster_kernel(const PassParams *__rest
         const BinEntry *__restrict__ list_base,
         const float *__restrict__ vary_base, const float *__restrict__ fan_vary_base,
         const char *__restrict__ upload_base, const uint2 *__restrict__ bin_range_base) {
-    const PassParams &P = passes[blockIdx.y];
-    if (blockIdx.x >= (unsigned)P.num_tiles) return;
+    /* grid: x, y = tile column / row, z = pass of the batch */
+    const PassParams &P = passes[blockIdx.z];
+    if ((int)blockIdx.x >= P.tiles_x || (int)blockIdx.y >= P.tiles_y) return;
     /* this pass's slices of the batch-wide tables */
     const TriRec *tri_table = tri_base + P.tri_off;
     const TriRec *fan_table = fan_base + (size_t)P.fan_off * RZ_MAX_FAN;
@@ -842,9 +843,7 @@ __global__ void __launch_bounds__(256) rz_raster_kernel(const PassParams *__rest
     __shared__ uint32_t s_plane[3][RZ_TILE_H][RZ_TILE_W];
     if (P.debug_skip == 3) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int tiles_x = (P.width + RZ_TILE_W - 1) / RZ_TILE_W;
-    const int tile_x = blockIdx.x % tiles_x, tile_y = blockIdx.x / tiles_x;
-    const int tx0 = tile_x * RZ_TILE_W, ty0 = tile_y * RZ_TILE_H;
+    const int tx0 = (int)blockIdx.x * RZ_TILE_W, ty0 = (int)blockIdx.y * RZ_TILE_H;
     const int bx0 = tx0 + wave * 8, by0 = ty0;
     const int lx = wave * 8 + (lane & 7), ly = lane >> 3;      /* position inside the tile */
     const int px = tx0 + lx, py = ty0 + ly;
@@ -1008,55 +1007,41 @@ __global__ void __launch_bounds__(256) rz_raster_kernel(const PassParams *__rest
 }
 
 /* K5  per-family fragment kernels for passes rasterised with SPLIT = true:
- * every lane shades the one fragment its pixel refers to. */
+ * every lane shades the one fragment its pixel refers to.  Pixels are
+ * independent here, so a wave takes two 32-pixel rows of the tile: reference
+ * and colour planes are read and written as whole 128-byte lines, no LDS. */
 template <int FAMILY>
 __global__ void __launch_bounds__(256) rz_shade_kernel(const PassParams *__restrict__ passes,
         const TriRec *__restrict__ tri_base, const TriRec *__restrict__ fan_base,
         const float *__restrict__ vary_base, const float *__restrict__ fan_vary_base,
         const char *__restrict__ upload_base, const uint32_t *__restrict__ ref_base) {
-    const PassParams &P = passes[blockIdx.y];
-    if (blockIdx.x >= (unsigned)P.num_tiles) return;
+    const PassParams &P = passes[blockIdx.z];
+    if ((int)blockIdx.x >= P.tiles_x || (int)blockIdx.y >= P.tiles_y) return;
     const TriRec *tri_table = tri_base + P.tri_off;
     const TriRec *fan_table = fan_base + (size_t)P.fan_off * RZ_MAX_FAN;
     const float *vary_table = vary_base + (size_t)P.tri_off * 3 * RZ_VARY_STRIDE;
     const float *fan_vary_table = fan_vary_base + (size_t)P.fan_off * RZ_MAX_POLY * RZ_VARY_STRIDE;
     const DrawRec *draw_table = (const DrawRec*)(upload_base + P.draws_off);
     const uint32_t *ref_table = ref_base + P.ref_off;
-    __shared__ uint32_t s_plane[2][RZ_TILE_H][RZ_TILE_W];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int tiles_x = (P.width + RZ_TILE_W - 1) / RZ_TILE_W;
-    const int tile_x = blockIdx.x % tiles_x, tile_y = blockIdx.x / tiles_x;
-    const int tx0 = tile_x * RZ_TILE_W, ty0 = tile_y * RZ_TILE_H;
-    const int lx = wave * 8 + (lane & 7), ly = lane >> 3;
-    const int px = tx0 + lx, py = ty0 + ly;
-    const int rx = lane & 31, ry = wave * 2 + (lane >> 5);
-    const bool row_valid = tx0 + rx < P.width && ty0 + ry < P.height;
-    const size_t row_pixel = (size_t)(ty0 + ry) * P.width + (tx0 + rx);
-    /* whole rows of the tile in, 8x8 blocks out of LDS */
-    uint32_t ref_row = row_valid ? ref_table[row_pixel] : RZ_REF_NONE;
-    if (P.debug_skip) ref_row = RZ_REF_NONE;
-    s_plane[0][ry][rx] = ref_row;
-    const bool tile_has_work = __syncthreads_or(ref_row != RZ_REF_NONE) != 0;
-    if (!tile_has_work) return;
-    const uint32_t myref = s_plane[0][ly][lx];
+    const int px = (int)blockIdx.x * RZ_TILE_W + (lane & 31);
+    const int py = (int)blockIdx.y * RZ_TILE_H + wave * 2 + (lane >> 5);
+    const bool valid = px < P.width && py < P.height;
+    const uint32_t pixel = (uint32_t)py * (uint32_t)P.width + (uint32_t)px;
+    uint32_t myref = valid ? ref_table[pixel] : RZ_REF_NONE;
+    if (P.debug_skip) myref = RZ_REF_NONE;
     bool want = myref != RZ_REF_NONE;
+    if (!__any(want)) return;
     TriRec m;
     const float *m0 = vary_table, *m1 = vary_table, *m2 = vary_table;
     if (want) {
         fetch_ref(myref, tri_table, fan_table, vary_table, fan_vary_table, m, m0, m1, m2);
         want = RZ_META_FAMILY(m.meta) == (uint32_t)FAMILY;
     }
-    const bool tile_has_family = __syncthreads_or(want) != 0;
-    if (!tile_has_family) return;
-    s_plane[1][ry][rx] = row_valid ? P.color[row_pixel] : 0u;
-    __syncthreads();
-    uint32_t ccur = s_plane[1][ly][lx];
-    if (__any(want)) shade_lanes<FAMILY>(P, draw_table, want, m, m0, m1, m2, px, py, ccur);
-    __syncthreads();
-    s_plane[1][ly][lx] = ccur;
-    s_plane[0][ly][lx] = want ? 1u : 0u;
-    __syncthreads();
-    if (row_valid && s_plane[0][ry][rx]) P.color[row_pixel] = s_plane[1][ry][rx];
+    if (!__any(want)) return;
+    uint32_t ccur = want ? P.color[pixel] : 0u;                 /* keeps the alpha byte */
+    shade_lanes<FAMILY>(P, draw_table, want, m, m0, m1, m2, px, py, ccur);
+    if (want) P.color[pixel] = ccur;
 }
 
 /* ========================================================================

@@ -155,7 +155,7 @@ struct PassParams {
     /* A launch covers a batch of passes (blockIdx.y = pass).  The rasteriser
      * and the shade kernels address the batch-wide tables through restrict
      * kernel arguments plus these per-pass offsets. */
-    int32_t num_tiles;              /* 32x8 tiles of this framebuffer */
+    int32_t tiles_x, tiles_y;       /* 32x8 tiles of this framebuffer */
     uint32_t tri_off;               /* triangles before this pass (vertices = 3x) */
     uint32_t fan_off;               /* fan blocks before this pass */
     uint32_t list_off;              /* bin-list entries before this pass */
