@@ -225,6 +225,16 @@ extern "C" int mi355r_init(int device) {
     HIP_OK(hipHostMalloc((void**)&g.ring_host, RING_BYTES, hipHostMallocDefault));
     HIP_OK(hipMalloc((void**)&g.ring_dev, RING_BYTES));
     g.ring_size = RING_BYTES;
+    {
+        /* tables of d_srgb (shade.h), from the host's pow */
+        static SrgbTables tables;
+        for (int e = -149; e <= 0; e++) tables.pow2[e + 149] = pow(ldexp(1.0, e), 1 / 2.2);
+        for (int i = 0; i < 32; i++) {
+            tables.m0[i] = pow(1.0 + i / 32.0, 1 / 2.2);
+            tables.inv[i] = 1.0 / (1.0 + i / 32.0);
+        }
+        HIP_OK(hipMemcpyToSymbol(HIP_SYMBOL(rz_srgb_tables), &tables, sizeof tables));
+    }
     HIP_OK(hipMalloc((void**)&g.d_counters, 12 * sizeof(unsigned long long)));
     HIP_OK(hipMemset(g.d_counters, 0, 12 * sizeof(unsigned long long)));
     HIP_OK(hipDeviceSynchronize());
@@ -354,9 +364,9 @@ static int log2_exact(int v) {
 }
 
 static void choose_layout(int w, int h, int *flags, int *mbits) {
-    int lw = log2_exact(w), lh = log2_exact(h);
-    if (lw >= 0 && lh >= 0) { *flags |= RZ_TEX_MORTON; *mbits = std::min(lw, lh); }
-    else { *flags &= ~RZ_TEX_MORTON; *mbits = 0; }
+    *mbits = 0;
+    if (w % 8 == 0 && h % 8 == 0) *flags |= RZ_TEX_TILED;
+    else *flags &= ~RZ_TEX_TILED;
 }
 
 static void drop_derived_handles();
@@ -411,7 +421,7 @@ static void device_image(Tex *t, int flags_wanted, size_t texel_bytes) {
     t->mbits = mbits;
 }
 
-/* host float4 image -> device (Morton where possible); load-time path */
+/* host float4 image -> device (8x8 tiles where possible); load-time path */
 static void upload_texture(Tex *t) {
     int w = t->pub.width, h = t->pub.height;
     size_t bytes = (size_t)w * h * sizeof(float4);
@@ -442,7 +452,7 @@ static DevTex dev_tex(rz_texture *p) {
     d.w = t->pub.width;
     d.h = t->pub.height;
     d.flags = t->flags;
-    d.mbits = t->mbits;
+    d.reserved = 0;
     return d;
 }
 

@@ -1062,7 +1062,7 @@ __global__ void rz_clear_kernel(uint32_t *color, float *depth, size_t n, int do_
 __global__ void rz_depth_to_texture_kernel(const float *depth, float *texels, int w, int h, int flags, int mbits) {
     int x = blockIdx.x * 16 + (threadIdx.x & 15), y = blockIdx.y * 16 + (threadIdx.x >> 4);
     if (x >= w || y >= h) return;
-    texels[texel_index(w, flags, mbits, x, y)] = depth[(size_t)y * w + x];
+    texels[texel_index(w, flags, x, y)] = depth[(size_t)y * w + x];
 }
 
 /* texture_from_colorbuffer (texture.c:130-145): byte / 255.0f per channel */
@@ -1070,23 +1070,23 @@ __global__ void rz_color_to_texture_kernel(const uint32_t *color, float4 *texels
     int x = blockIdx.x * 16 + (threadIdx.x & 15), y = blockIdx.y * 16 + (threadIdx.x >> 4);
     if (x >= w || y >= h) return;
     uint32_t c = color[(size_t)y * w + x];
-    texels[texel_index(w, flags, mbits, x, y)] =
+    texels[texel_index(w, flags, x, y)] =
         make_float4((float)(c & 0xffu) / 255.0f, (float)((c >> 8) & 0xffu) / 255.0f,
                     (float)((c >> 16) & 0xffu) / 255.0f, (float)(c >> 24) / 255.0f);
 }
 
-/* row-major float4 image -> device layout (Morton where the size allows) */
+/* row-major float4 image -> device layout (8x8 tiles where the size allows) */
 __global__ void rz_texture_tile_kernel(const float4 *linear, float4 *texels, int w, int h, int flags, int mbits) {
     int x = blockIdx.x * 16 + (threadIdx.x & 15), y = blockIdx.y * 16 + (threadIdx.x >> 4);
     if (x >= w || y >= h) return;
-    texels[texel_index(w, flags, mbits, x, y)] = linear[(size_t)y * w + x];
+    texels[texel_index(w, flags, x, y)] = linear[(size_t)y * w + x];
 }
 
 /* device layout -> row-major float4 (texture_sync) */
 __global__ void rz_texture_untile_kernel(const void *texels, float4 *linear, int w, int h, int flags, int mbits) {
     int x = blockIdx.x * 16 + (threadIdx.x & 15), y = blockIdx.y * 16 + (threadIdx.x >> 4);
     if (x >= w || y >= h) return;
-    uint32_t i = texel_index(w, flags, mbits, x, y);
+    uint32_t i = texel_index(w, flags, x, y);
     float4 v;
     if (flags & RZ_TEX_R32F) { float d = ((const float*)texels)[i]; v = make_float4(d, d, d, 1.0f); }
     else v = ((const float4*)texels)[i];

@@ -31,14 +31,14 @@
 #define RZ_TILE_H 8                 /* so a tile row is one 128-byte line of a 4-byte plane */
 
 enum { RZ_FMT_RGBA32F = 0, RZ_FMT_R32F = 1 };
-enum { RZ_TEX_MORTON = 1, RZ_TEX_R32F = 2 };
+enum { RZ_TEX_TILED = 1, RZ_TEX_R32F = 2 };
 
 /* a sampled image; data == nullptr means "no map bound" */
 struct DevTex {
     const void *data;
     int32_t w, h;
     int32_t flags;                  /* RZ_TEX_* */
-    int32_t mbits;                  /* Morton: interleaved low bits per axis */
+    int32_t reserved;
 };
 
 struct DevIbl {                     /* pbr_shader.h:13-18 in device form */

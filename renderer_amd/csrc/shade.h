@@ -89,7 +89,40 @@ RZ_DEV float d_powf(float base, double exponent) {
     if (base == 0.0f) return exponent > 0 ? 0.0f : (exponent == 0 ? 1.0f : inf);
     return nan;                                                 /* NaN in, or a negative base */
 }
-RZ_DEV float d_srgb(float v) { return d_powf(v, 1 / 2.2); }                      /* maths.c:41 */
+/* one copy of the general routine for the rare inputs outside the table's range */
+static __device__ __noinline__ float d_powf_outlined(float base, double exponent) { return d_powf(base, exponent); }
+
+/* float_linear2srgb (maths.c:41): (float)pow(v, 1 / 2.2), the one pow on the pbr path (three per
+ * fragment).  For 0 < v <= 1 split v = 2^e * m0 * (1 + r) with m0 = 1 + i/32 the mantissa's top five
+ * bits: v^p = (2^e)^p * m0^p * (1 + r)^p, the first two from tables filled by the host's own pow
+ * (150 + 32 doubles), the last by its binomial series (r < 1/32: the x^10 term is below 1e-17).
+ * Three roundings at 1.1e-16 each: the same accuracy class as d_powf at a twentieth of the work. */
+struct SrgbTables {
+    double pow2[150];       /* (2^e)^(1/2.2), e = -149 .. 0 */
+    double m0[32];          /* (1 + i/32)^(1/2.2) */
+    double inv[32];         /* 1 / (1 + i/32) */
+};
+__device__ SrgbTables rz_srgb_tables;
+
+RZ_DEV float d_srgb(float v) {
+    if (v == 0.0f) return 0.0f;
+    if (!(v > 0.0f && v <= 1.0f)) return d_powf_outlined(v, 1 / 2.2);       /* NaN, out of the display range */
+    constexpr double p = 1 / 2.2;
+    constexpr double c1 = p, c2 = c1 * (p - 1) / 2, c3 = c2 * (p - 2) / 3, c4 = c3 * (p - 3) / 4, c5 = c4 * (p - 4) / 5,
+                     c6 = c5 * (p - 5) / 6, c7 = c6 * (p - 6) / 7, c8 = c7 * (p - 7) / 8, c9 = c8 * (p - 8) / 9;
+    const unsigned long long bits = (unsigned long long)__double_as_longlong((double)v);
+    const int e = (int)(bits >> 52) - 1023;                     /* -149 .. 0 (the sign bit is clear) */
+    const unsigned long long mant = bits & 0x000fffffffffffffull;
+    const int i = (int)(mant >> 47);
+    const double m = __longlong_as_double((long long)(0x3ff0000000000000ull | mant));
+    const double m0 = __longlong_as_double((long long)(0x3ff0000000000000ull | ((unsigned long long)i << 47)));
+    const double r = (m - m0) * rz_srgb_tables.inv[i];
+    double q = c9;
+    q = fma(q, r, c8); q = fma(q, r, c7); q = fma(q, r, c6); q = fma(q, r, c5);
+    q = fma(q, r, c4); q = fma(q, r, c3); q = fma(q, r, c2); q = fma(q, r, c1);
+    q = fma(q, r, 1.0);
+    return (float)((rz_srgb_tables.pow2[e + 149] * rz_srgb_tables.m0[i]) * q);
+}
 RZ_DEV float d_aces(float v) {                                                 /* maths.c:49 */
     float a = 2.51f, b = 0.03f, c = 2.43f, d = 0.59f, e = 0.14f;
     v = (v * (a * v + b)) / (v * (c * v + d) + e);
@@ -128,23 +161,14 @@ RZ_DEV f3 m3v3(const float *m, f3 v) {                                          
 
 /* ---- texture addressing -------------------------------------------------- */
 
-RZ_DEV uint32_t spread_bits(uint32_t x) {      /* abcd -> 0a0b0c0d (16 bits) */
-    x &= 0xffffu;
-    x = (x | (x << 8)) & 0x00ff00ffu;
-    x = (x | (x << 4)) & 0x0f0f0f0fu;
-    x = (x | (x << 2)) & 0x33333333u;
-    x = (x | (x << 1)) & 0x55555555u;
-    return x;
-}
-
-/* Morton (Z-order) inside the largest square power of two, remaining high
- * bits of the longer axis on top; row-major for other sizes */
-RZ_DEV uint32_t texel_index(int w, int flags, int mbits, int c, int r) {
-    if (flags & RZ_TEX_MORTON) {
-        uint32_t mask = (1u << mbits) - 1u;
-        uint32_t lo = spread_bits((uint32_t)c & mask) | (spread_bits((uint32_t)r & mask) << 1);
-        uint32_t hi = ((uint32_t)c >> mbits) | ((uint32_t)r >> mbits);
-        return lo | (hi << (2 * mbits));
+/* Images whose sides are multiples of 8 are stored as 8x8-texel tiles (one
+ * 128-byte line per tile row of float4 texels, 1 KiB per tile), tiles in
+ * row-major order: the 2-D locality of nearest-texel gathers becomes address
+ * locality for a handful of integer operations.  Other sizes stay row-major. */
+RZ_DEV uint32_t texel_index(int w, int flags, int c, int r) {
+    if (flags & RZ_TEX_TILED) {
+        uint32_t tile = ((uint32_t)r >> 3) * ((uint32_t)w >> 3) + ((uint32_t)c >> 3);
+        return (tile << 6) | (((uint32_t)r & 7u) << 3) | ((uint32_t)c & 7u);
     }
     return (uint32_t)r * (uint32_t)w + (uint32_t)c;
 }
@@ -152,7 +176,7 @@ RZ_DEV uint32_t texel_index(int w, int flags, int mbits, int c, int r) {
 RZ_DEV f4 fetch_texel(const DevTex &t, int c, int r) {
     c = c < 0 ? 0 : (c > t.w - 1 ? t.w - 1 : c);       /* never taken for finite coordinates */
     r = r < 0 ? 0 : (r > t.h - 1 ? t.h - 1 : r);
-    uint32_t i = texel_index(t.w, t.flags, t.mbits, c, r);
+    uint32_t i = texel_index(t.w, t.flags, c, r);
     if (t.flags & RZ_TEX_R32F) {
         float d = ((const float*)t.data)[i];
         return mk4(d, d, d, 1.0f);
@@ -180,22 +204,14 @@ RZ_DEV f4 sample_clamp(const DevTex &t, float x, float y) {
 /* GL ES 2.0 3.7.5 face selection with strict comparisons (texture.c:210-255);
  * the face index differs per lane, so the six descriptors are read per lane */
 RZ_DEV int cube_face(f3 d, float *s, float *t) {
-    float ax = fabsf(d.x), ay = fabsf(d.y), az = fabsf(d.z);
-    float ma, sc, tc;
-    int face;
-    if (ax > ay && ax > az) {
-        ma = ax;
-        if (d.x > 0) { face = 0; sc = -d.z; tc = -d.y; }
-        else         { face = 1; sc = +d.z; tc = -d.y; }
-    } else if (ay > az) {
-        ma = ay;
-        if (d.y > 0) { face = 2; sc = +d.x; tc = +d.z; }
-        else         { face = 3; sc = +d.x; tc = -d.z; }
-    } else {
-        ma = az;
-        if (d.z > 0) { face = 4; sc = +d.x; tc = -d.y; }
-        else         { face = 5; sc = -d.x; tc = -d.y; }
-    }
+    const float ax = fabsf(d.x), ay = fabsf(d.y), az = fabsf(d.z);
+    /* selects instead of branches: every value below is one of +-d.x, +-d.y, +-d.z, so nothing is rounded */
+    const bool x_major = ax > ay && ax > az, y_major = !x_major && ay > az;
+    const bool px = d.x > 0, py = d.y > 0, pz = d.z > 0;
+    const float ma = x_major ? ax : (y_major ? ay : az);
+    const float sc = x_major ? (px ? -d.z : d.z) : (y_major ? d.x : (pz ? d.x : -d.x));
+    const float tc = x_major ? -d.y : (y_major ? (py ? d.z : -d.z) : -d.y);
+    const int face = x_major ? (px ? 0 : 1) : (y_major ? (py ? 2 : 3) : (pz ? 4 : 5));
     *s = (sc / ma + 1) / 2;
     *t = (tc / ma + 1) / 2;
     return face;
