@@ -382,6 +382,7 @@ __global__ void __launch_bounds__(64) rz_clip_kernel(const PassParams *__restric
 /* a fragment / list reference: a triangle index, or RZ_REF_FAN | index into fan_tri */
 #define RZ_REF_NONE 0xffffffffu
 #define RZ_REF_FAN 0x80000000u
+#define RZ_REF_FAMILY_BITS 0x30000000u  /* in the reference plane only: the fragment's shader family */
 
 RZ_DEV bool box_overlaps(uint2 bb, int rx0, int ry0, int rx1, int ry1) {
     int x0 = (int)(bb.x & 0xffffu), x1 = (int)(bb.x >> 16);
@@ -837,45 +838,27 @@ __global__ void __launch_bounds__(256) rz_raster_kernel(const PassParams *__rest
     const float *fan_vary_table = fan_vary_base + (size_t)P.fan_off * RZ_MAX_POLY * RZ_VARY_STRIDE;
     const DrawRec *draw_table = (const DrawRec*)(upload_base + P.draws_off);
     const uint2 *bin_range_table = bin_range_base + P.bin_off;
-    /* A workgroup owns a 32x8-pixel tile, wave w its w-th 8x8 block.  Planes
-     * are read and written through LDS so that every global access is a whole
-     * 128-byte row of the tile instead of eight 32-byte pieces. */
-    __shared__ uint32_t s_plane[3][RZ_TILE_H][RZ_TILE_W];
+    /* A workgroup owns a 32x8-pixel tile, wave w its w-th 8x8 block, lane = pixel. */
     if (P.debug_skip == 3) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int tx0 = (int)blockIdx.x * RZ_TILE_W, ty0 = (int)blockIdx.y * RZ_TILE_H;
     const int bx0 = tx0 + wave * 8, by0 = ty0;
-    const int lx = wave * 8 + (lane & 7), ly = lane >> 3;      /* position inside the tile */
-    const int px = tx0 + lx, py = ty0 + ly;
+    const int px = bx0 + (lane & 7), py = by0 + (lane >> 3);
     const bool valid = px < P.width && py < P.height;
-    /* row-wise view for global access: this lane moves pixel (rx, ry) of the tile */
-    const int rx = lane & 31, ry = wave * 2 + (lane >> 5);
-    const bool row_valid = tx0 + rx < P.width && ty0 + ry < P.height;
-    const size_t row_pixel = (size_t)(ty0 + ry) * P.width + (tx0 + rx);
+    const uint32_t pixel = (uint32_t)py * (uint32_t)P.width + (uint32_t)px;
     const int bin = (ty0 / RZ_BIN) * P.bins_x + tx0 / RZ_BIN;
     const uint2 range = bin_range_table[bin];          /* {first entry, entries} */
     const uint32_t count = range.y;
     if (count == 0 && !P.clear_color_pending && !P.clear_depth_pending) {   /* uniform over the workgroup */
-        if (SPLIT && row_valid) P.ref[row_pixel] = RZ_REF_NONE;
+        if (SPLIT && valid) P.ref[pixel] = RZ_REF_NONE;
         return;
     }
 
-    float zcur = 1.0f;
-    uint32_t ccur = 0;
-    {
-        const bool need_color = !SPLIT || P.clear_color_pending;
-        float zrow = P.clear_depth;
-        uint32_t crow = P.clear_color;
-        if (row_valid) {
-            if (!P.clear_depth_pending) zrow = P.depth[row_pixel];
-            if (need_color && !P.clear_color_pending) crow = P.color[row_pixel];
-        }
-        s_plane[0][ry][rx] = __float_as_uint(zrow);
-        s_plane[1][ry][rx] = crow;
-        __syncthreads();
-        zcur = __uint_as_float(s_plane[0][ly][lx]);
-        ccur = s_plane[1][ly][lx];
-        __syncthreads();
+    float zcur = P.clear_depth;
+    uint32_t ccur = P.clear_color;
+    if (valid) {
+        if (!P.clear_depth_pending) zcur = P.depth[pixel];
+        if (!SPLIT && !P.clear_color_pending) ccur = P.color[pixel];
     }
     const BinEntry *list = list_table + range.x;
     const int bx1 = bx0 + 7, by1 = by0 + 7;
@@ -971,7 +954,7 @@ __global__ void __launch_bounds__(256) rz_raster_kernel(const PassParams *__rest
                 zcur = depth;
                 if (blend && depth_of_stack == 1) { ref1 = ref; depth_of_stack = 2; }
                 else if (blend && depth_of_stack == 0) { ref0 = ref; depth_of_stack = 1; }
-                else if (!blend) { ref0 = ref; depth_of_stack = 1; }
+                else if (!blend) { ref0 = SPLIT ? (ref | (RZ_META_FAMILY(r.meta) << 28)) : ref; depth_of_stack = 1; }
             }
             have = false;
         }
@@ -991,17 +974,14 @@ __global__ void __launch_bounds__(256) rz_raster_kernel(const PassParams *__rest
         if (exhausted || !stack_full) break;
     }
 
-    s_plane[0][ly][lx] = __float_as_uint(zcur);
-    s_plane[1][ly][lx] = ccur;
-    s_plane[2][ly][lx] = depth_of_stack ? ref0 : RZ_REF_NONE;
-    __syncthreads();
-    if (row_valid) {
-        P.depth[row_pixel] = __uint_as_float(s_plane[0][ry][rx]);
+    if (valid) {
+        P.depth[pixel] = zcur;
         if (SPLIT) {
-            P.ref[row_pixel] = s_plane[2][ry][rx];
-            if (P.clear_color_pending) P.color[row_pixel] = s_plane[1][ry][rx];
+            /* the shade kernels write the colour of every pixel that has a fragment */
+            P.ref[pixel] = depth_of_stack ? ref0 : RZ_REF_NONE;
+            if (P.clear_color_pending && !depth_of_stack) P.color[pixel] = ccur;
         } else {
-            P.color[row_pixel] = s_plane[1][ry][rx];
+            P.color[pixel] = ccur;
         }
     }
 }
@@ -1030,16 +1010,16 @@ __global__ void __launch_bounds__(256) rz_shade_kernel(const PassParams *__restr
     const uint32_t pixel = (uint32_t)py * (uint32_t)P.width + (uint32_t)px;
     uint32_t myref = valid ? ref_table[pixel] : RZ_REF_NONE;
     if (P.debug_skip) myref = RZ_REF_NONE;
-    bool want = myref != RZ_REF_NONE;
+    /* the rasteriser tagged the reference with the fragment's family (RZ_REF_NONE reads as family 3) */
+    const bool want = ((myref >> 28) & 3u) == (uint32_t)FAMILY;
     if (!__any(want)) return;
+    myref &= ~RZ_REF_FAMILY_BITS;
     TriRec m;
     const float *m0 = vary_table, *m1 = vary_table, *m2 = vary_table;
-    if (want) {
-        fetch_ref(myref, tri_table, fan_table, vary_table, fan_vary_table, m, m0, m1, m2);
-        want = RZ_META_FAMILY(m.meta) == (uint32_t)FAMILY;
-    }
-    if (!__any(want)) return;
-    uint32_t ccur = want ? P.color[pixel] : 0u;                 /* keeps the alpha byte */
+    if (want) fetch_ref(myref, tri_table, fan_table, vary_table, fan_vary_table, m, m0, m1, m2);
+    /* the colour below only lends its alpha byte; under a pending clear it is the clear colour */
+    uint32_t ccur = P.clear_color;
+    if (want && !P.clear_color_pending) ccur = P.color[pixel];
     shade_lanes<FAMILY>(P, draw_table, want, m, m0, m1, m2, px, py, ccur);
     if (want) P.color[pixel] = ccur;
 }
