@@ -870,7 +870,7 @@ __global__ void __launch_bounds__(256) rz_raster_kernel(const PassParams *__rest
     /* iterator over this block's triangles, in list order */
     uint32_t base = 0;
     unsigned long long todo = 0;
-    uint32_t mine = 0;
+    uint32_t mine = 0; (void)mine;
     float4 c0 = make_float4(0, 0, 0, 0), c1 = c0, c2 = c0, c3 = c0;    /* this lane's candidate record */
     bool have = false, exhausted = false;
     TriRec r;
@@ -884,16 +884,11 @@ __global__ void __launch_bounds__(256) rz_raster_kernel(const PassParams *__rest
         while (true) {
             if (!have) {
                 if (todo) {
-                    int j = __ffsll((long long)todo) - 1;
+                    /* the wave-uniform entry index makes these scalar loads */
+                    const BinEntry *e = &list[base - 64u + (uint32_t)(__ffsll((long long)todo) - 1)];
                     todo &= todo - 1;
-                    ref = (uint32_t)__builtin_amdgcn_readlane((int)mine, j);
-                    r.ax = RZ_BCAST_F(c0.x, j); r.ay = RZ_BCAST_F(c0.y, j); r.abx = RZ_BCAST_F(c0.z, j); r.aby = RZ_BCAST_F(c0.w, j);
-                    r.acx = RZ_BCAST_F(c1.x, j); r.acy = RZ_BCAST_F(c1.y, j); r.factor = RZ_BCAST_F(c1.z, j); r.z[0] = RZ_BCAST_F(c1.w, j);
-                    r.z[1] = RZ_BCAST_F(c2.x, j); r.z[2] = RZ_BCAST_F(c2.y, j); r.rw[0] = RZ_BCAST_F(c2.z, j); r.rw[1] = RZ_BCAST_F(c2.w, j);
-                    r.rw[2] = RZ_BCAST_F(c3.x, j);
-                    r.meta = (uint32_t)__builtin_amdgcn_readlane(__float_as_int(c3.y), j);
-                    r.bx = (uint32_t)__builtin_amdgcn_readlane(__float_as_int(c3.z), j);
-                    r.by = (uint32_t)__builtin_amdgcn_readlane(__float_as_int(c3.w), j);
+                    ref = e->tri;
+                    r = e->rec;
                     have = true;
                 } else {
                     if (base >= count || P.debug_skip == 4) { exhausted = true; break; }
