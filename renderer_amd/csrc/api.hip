@@ -132,6 +132,7 @@ struct Context {
     Lane lanes[MAX_LANES];
     int num_lanes = 1, next_lane = 0;
     size_t max_batch = 16;                  /* passes per launch sequence */
+    bool pack_textures = true;              /* MI355R_PACK=0: keep every image as float4 */
     std::vector<hipEvent_t> events;     /* recorded since the last full sync */
     std::vector<Tex*> current_gpu_textures;
     /* upload ring: pinned host memory mirrored 1:1 in device memory */
@@ -181,6 +182,7 @@ template <typename T> static void reserve(DevBuf<T> &b, size_t n, hipStream_t us
 }
 
 static void check_passes_in_flight();
+static void init_packed_formats();
 
 static void sync_stream();
 
@@ -216,6 +218,8 @@ extern "C" int mi355r_init(int device) {
         g.num_lanes = env ? atoi(env) : 4;
         if (g.num_lanes < 1) g.num_lanes = 1;
         if (g.num_lanes > MAX_LANES) g.num_lanes = MAX_LANES;
+        env = getenv("MI355R_PACK");
+        if (env) g.pack_textures = atoi(env) != 0;
         env = getenv("MI355R_BATCH");
         if (env && atoi(env) >= 1) g.max_batch = std::min<size_t>((size_t)atoi(env), MAX_BATCH);
     }
@@ -235,6 +239,7 @@ extern "C" int mi355r_init(int device) {
         }
         HIP_OK(hipMemcpyToSymbol(HIP_SYMBOL(rz_srgb_tables), &tables, sizeof tables));
     }
+    init_packed_formats();
     HIP_OK(hipMalloc((void**)&g.d_counters, 12 * sizeof(unsigned long long)));
     HIP_OK(hipMemset(g.d_counters, 0, 12 * sizeof(unsigned long long)));
     HIP_OK(hipDeviceSynchronize());
@@ -421,13 +426,91 @@ static void device_image(Tex *t, int flags_wanted, size_t texel_bytes) {
     t->mbits = mbits;
 }
 
-/* host float4 image -> device (8x8 tiles where possible); load-time path */
+/* ---- lossless 4-byte device formats (rz_device.h) --------------------------
+ * texture->buffer is always float RGBA, as the reference defines it.  Most of
+ * the reference's images come from 8-bit TGA or RGBE .hdr files, so their
+ * floats take one of 256 values per channel (or mantissa * 2^e): such an image
+ * is stored in 4 bytes per texel and decoded on fetch to the SAME floats.
+ * Every texel is verified; an image with one texel that does not fit stays
+ * float4. */
+static float g_unorm8[256], g_srgb8[256];
+
+static void init_packed_formats() {
+    for (int k = 0; k < 256; k++) {
+        g_unorm8[k] = (float)k / 255.0f;                        /* texture.c:40-61 */
+        g_srgb8[k] = (float)pow((double)g_unorm8[k], 2.2);      /* maths.c:37-39 */
+        /* the device computes k/255 as fma(fma(-q, 255, k), r, q), q = k * r, r = 1/255 */
+        const float r = 1.0f / 255.0f, f = (float)k, q = f * r;
+        if (fmaf(fmaf(-q, 255.0f, f), r, q) != g_unorm8[k]) fatal("byte %d: the division-free k/255 is off", k);
+    }
+    HIP_OK(hipMemcpyToSymbol(HIP_SYMBOL(rz_srgb8_table), g_srgb8, sizeof g_srgb8));
+}
+
+static int byte_of(const float *table, float v) {               /* tables ascend strictly */
+    const float *hit = std::lower_bound(table, table + 256, v);
+    return (hit != table + 256 && *hit == v) ? (int)(hit - table) : -1;
+}
+
+/* returns the format flag and fills `out`, or 0 when the image needs float4 */
+static int pack_texels(const rz_vec4 *texels, size_t n, std::vector<uint32_t> &out) {
+    out.resize(n);
+    for (int format : {RZ_TEX_UNORM8, RZ_TEX_SRGB8}) {
+        const float *rgb = format == RZ_TEX_UNORM8 ? g_unorm8 : g_srgb8;
+        size_t i = 0;
+        for (; i < n; i++) {
+            const int r = byte_of(rgb, texels[i].x), g_ = byte_of(rgb, texels[i].y), b = byte_of(rgb, texels[i].z);
+            const int a = byte_of(g_unorm8, texels[i].w);
+            if ((r | g_ | b | a) < 0) break;
+            out[i] = (uint32_t)r | ((uint32_t)g_ << 8) | ((uint32_t)b << 16) | ((uint32_t)a << 24);
+        }
+        if (i == n) return format;
+    }
+    for (size_t i = 0; i < n; i++) {                            /* shared-exponent: rgb = mantissa * 2^(e - 136) */
+        const float v[3] = {texels[i].x, texels[i].y, texels[i].z};
+        if (texels[i].w != 1.0f) return 0;
+        const float top = std::max(v[0], std::max(v[1], v[2]));
+        if (!(v[0] >= 0 && v[1] >= 0 && v[2] >= 0) || std::isinf(top)) return 0;
+        if (top == 0) { out[i] = 0; continue; }
+        int e2;
+        frexpf(top, &e2);                                       /* top = f * 2^e2, f in [0.5, 1): mantissa = f * 256 */
+        const int e = e2 + 128;
+        if (e < 1 || e > 255) return 0;
+        const float factor = ldexpf(1.0f, e - 136);
+        uint32_t word = (uint32_t)e << 24;
+        for (int c = 0; c < 3; c++) {
+            const float m = v[c] / factor;                      /* exact: a power of two */
+            if (!(m >= 0 && m <= 255 && m == (float)(int)m) || (float)(int)m * factor != v[c]) return 0;
+            word |= (uint32_t)(int)m << (8 * c);
+        }
+        out[i] = word;
+    }
+    return RZ_TEX_RGBE8;
+}
+
+/* host float4 image -> device (packed when lossless, 8x8 tiles where possible); load-time path */
 static void upload_texture(Tex *t) {
     int w = t->pub.width, h = t->pub.height;
     size_t bytes = (size_t)w * h * sizeof(float4);
     graphics_flush();               /* recorded draws may still sample the old image */
     if (t->write_lane >= 0 || !t->read_events.empty()) sync_stream();
     t->write_lane = -1;
+    std::vector<uint32_t> packed;
+    const int format = g.pack_textures ? pack_texels(t->pub.buffer, (size_t)w * h, packed) : 0;
+    if (getenv("MI355R_VERBOSE")) fprintf(stderr, "mi355r: texture %dx%d -> format %d\n", w, h, format);
+    if (format) {
+        device_image(t, format, sizeof(uint32_t));
+        uint32_t *staging;
+        HIP_OK(hipMalloc((void**)&staging, packed.size() * sizeof(uint32_t)));
+        HIP_OK(hipMemcpyAsync(staging, packed.data(), packed.size() * sizeof(uint32_t), hipMemcpyHostToDevice, g.stream));
+        rz_texture_tile32_kernel<<<dim3((w + 15) / 16, (h + 15) / 16), dim3(256), 0, g.stream>>>(
+            staging, (uint32_t*)t->d_data, w, h, t->flags);
+        HIP_OK(hipGetLastError());
+        HIP_OK(hipStreamSynchronize(g.stream));
+        HIP_OK(hipFree(staging));
+        t->device_stale = false;
+        t->host_stale = false;
+        return;
+    }
     device_image(t, 0, sizeof(float4));
     float4 *staging;
     HIP_OK(hipMalloc((void**)&staging, bytes));

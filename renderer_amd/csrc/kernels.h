@@ -1057,6 +1057,13 @@ __global__ void rz_texture_tile_kernel(const float4 *linear, float4 *texels, int
     texels[texel_index(w, flags, x, y)] = linear[(size_t)y * w + x];
 }
 
+/* the same for the 4-byte packed formats */
+__global__ void rz_texture_tile32_kernel(const uint32_t *linear, uint32_t *texels, int w, int h, int flags) {
+    int x = blockIdx.x * 16 + (threadIdx.x & 15), y = blockIdx.y * 16 + (threadIdx.x >> 4);
+    if (x >= w || y >= h) return;
+    texels[texel_index(w, flags, x, y)] = linear[(size_t)y * w + x];
+}
+
 /* device layout -> row-major float4 (texture_sync) */
 __global__ void rz_texture_untile_kernel(const void *texels, float4 *linear, int w, int h, int flags, int mbits) {
     int x = blockIdx.x * 16 + (threadIdx.x & 15), y = blockIdx.y * 16 + (threadIdx.x >> 4);

@@ -31,7 +31,15 @@
 #define RZ_TILE_H 8                 /* so a tile row is one 128-byte line of a 4-byte plane */
 
 enum { RZ_FMT_RGBA32F = 0, RZ_FMT_R32F = 1 };
-enum { RZ_TEX_TILED = 1, RZ_TEX_R32F = 2 };
+/* texel formats: float4 unless one of the format bits is set.  The packed
+ * formats are used only for images they hold without loss:
+ *   R32F    one float, read as (d, d, d, 1)                    shadow maps
+ *   UNORM8  4 bytes, channel = byte / 255.0f                   8-bit data maps
+ *   SRGB8   4 bytes, rgb = (float)pow(byte / 255.0f, 2.2),     8-bit colour maps
+ *           alpha = byte / 255.0f
+ *   RGBE8   3 mantissa bytes + shared exponent byte e,         Radiance .hdr maps
+ *           rgb = (float)mantissa * 2^(e - 136), alpha = 1 */
+enum { RZ_TEX_TILED = 1, RZ_TEX_R32F = 2, RZ_TEX_UNORM8 = 4, RZ_TEX_SRGB8 = 8, RZ_TEX_RGBE8 = 16 };
 
 /* a sampled image; data == nullptr means "no map bound" */
 struct DevTex {

@@ -173,10 +173,30 @@ RZ_DEV uint32_t texel_index(int w, int flags, int c, int r) {
     return (uint32_t)r * (uint32_t)w + (uint32_t)c;
 }
 
+/* (float)k / 255.0f for a byte k without a division: one Newton step on k * (1/255) is the
+ * correctly rounded quotient for all 256 inputs (checked against the division when the library
+ * starts and in the tests) */
+RZ_DEV float d_unorm8(uint32_t k) {
+    const float r = 1.0f / 255.0f, f = (float)k;
+    float q = f * r;
+    return __builtin_fmaf(__builtin_fmaf(-q, 255.0f, f), r, q);
+}
+
+/* (float)pow(k / 255.0f, 2.2) for every byte k (texture.c:32-62 with maths.c:37-39), filled by the host */
+__device__ float rz_srgb8_table[256];
+
 RZ_DEV f4 fetch_texel(const DevTex &t, int c, int r) {
     c = c < 0 ? 0 : (c > t.w - 1 ? t.w - 1 : c);       /* never taken for finite coordinates */
     r = r < 0 ? 0 : (r > t.h - 1 ? t.h - 1 : r);
     uint32_t i = texel_index(t.w, t.flags, c, r);
+    if (t.flags & (RZ_TEX_UNORM8 | RZ_TEX_SRGB8 | RZ_TEX_RGBE8)) {
+        const uint32_t p = ((const uint32_t*)t.data)[i];
+        const uint32_t b0 = p & 0xffu, b1 = (p >> 8) & 0xffu, b2 = (p >> 16) & 0xffu, b3 = p >> 24;
+        if (t.flags & RZ_TEX_UNORM8) return mk4(d_unorm8(b0), d_unorm8(b1), d_unorm8(b2), d_unorm8(b3));
+        if (t.flags & RZ_TEX_SRGB8) return mk4(rz_srgb8_table[b0], rz_srgb8_table[b1], rz_srgb8_table[b2], d_unorm8(b3));
+        const float factor = ldexpf(1.0f, (int)b3 - 136);           /* image.c:329-347; a zero texel is stored as four zero bytes */
+        return mk4((float)b0 * factor, (float)b1 * factor, (float)b2 * factor, 1.0f);
+    }
     if (t.flags & RZ_TEX_R32F) {
         float d = ((const float*)t.data)[i];
         return mk4(d, d, d, 1.0f);
