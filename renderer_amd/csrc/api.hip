@@ -117,7 +117,7 @@ struct Lane {
     DevBuf<uint2> bbox;
     DevBuf<uint32_t> clip_list, ref;
     DevBuf<uint2> bin_range;
-    DevBuf<uint32_t> bin_counts;
+    DevBuf<uint32_t> bin_counts, queue, queue_counts;
     DevBuf<BinEntry> bin_list;
 };
 
@@ -133,6 +133,7 @@ struct Context {
     int num_lanes = 1, next_lane = 0;
     size_t max_batch = 16;                  /* passes per launch sequence */
     bool pack_textures = true;              /* MI355R_PACK=0: keep every image as float4 */
+    int shade_workgroups = 4096;            /* 256-thread workgroups per shade launch (compute units x 16) */
     std::vector<hipEvent_t> events;     /* recorded since the last full sync */
     std::vector<Tex*> current_gpu_textures;
     /* upload ring: pinned host memory mirrored 1:1 in device memory */
@@ -211,6 +212,8 @@ extern "C" int mi355r_init(int device) {
     HIP_OK(hipGetDevice(&g.device));
     hipDeviceProp_t prop;
     HIP_OK(hipGetDeviceProperties(&prop, g.device));
+    g.shade_workgroups = std::max(1, prop.multiProcessorCount) * 16;
+    if (const char *env = getenv("MI355R_SHADE_WGS")) g.shade_workgroups = std::max(1, atoi(env));
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         fprintf(stderr, "mi355r: warning: built for gfx950, running on %s\n", prop.gcnArchName);
     {
@@ -413,7 +416,8 @@ extern "C" void texture_invalidate(rz_texture *p) {
 }
 
 static void device_image(Tex *t, int flags_wanted, size_t texel_bytes) {
-    size_t bytes = (size_t)t->pub.width * t->pub.height * texel_bytes;
+    /* whole 16-byte units: the samplers read the aligned 16 bytes around a 4-byte texel */
+    size_t bytes = ((size_t)t->pub.width * t->pub.height * texel_bytes + 15) & ~(size_t)15;
     int flags = flags_wanted, mbits = 0;
     choose_layout(t->pub.width, t->pub.height, &flags, &mbits);
     if (t->d_bytes != bytes) {
@@ -1049,7 +1053,7 @@ static void prepare_batch(const Batch &b, const std::vector<PassPlan> &plans, ch
                           bool reserve_only) {
     Lane &L = g.lanes[b.lane];
     hipStream_t st = L.stream;
-    size_t tris = 0, fans = 0, lists = 0, bins = 0, pixels = 0, matrix = 0;
+    size_t tris = 0, fans = 0, lists = 0, bins = 0, pixels = 0, matrix = 0, tiles = 0;
     std::vector<size_t> fan_cap, list_cap;
     for (size_t i = b.first; i < b.last; i++) {
         const PassPlan &pl = plans[i];
@@ -1058,6 +1062,7 @@ static void prepare_batch(const Batch &b, const std::vector<PassPlan> &plans, ch
         list_cap.push_back(std::min<size_t>(pl.T * 8 * nb, std::max<size_t>(pl.T * 16, 1u << 18)));
         tris += pl.T; fans += fan_cap.back(); lists += list_cap.back(); bins += nb;
         matrix += ((pl.T + 63) / 64) * nb;
+        tiles += (size_t)((pl.fb->pub.width + RZ_TILE_W - 1) / RZ_TILE_W) * ((pl.fb->pub.height + RZ_TILE_H - 1) / RZ_TILE_H);
         pixels += (size_t)pl.fb->pub.width * pl.fb->pub.height;
     }
     reserve(L.clip, tris * 3 * 4, st);
@@ -1069,11 +1074,14 @@ static void prepare_batch(const Batch &b, const std::vector<PassPlan> &plans, ch
     reserve(L.fan_vary, fans * RZ_MAX_POLY * RZ_VARY_STRIDE, st);
     reserve(L.bin_range, bins, st);
     reserve(L.bin_counts, matrix, st);
+    const size_t queue_capacity = (tiles + RZ_QUEUE_WAYS - 1) / RZ_QUEUE_WAYS;
+    reserve(L.queue, 3 * RZ_QUEUE_WAYS * queue_capacity, st);
+    reserve(L.queue_counts, 3 * RZ_QUEUE_WAYS * RZ_QUEUE_PAD, st);
     reserve(L.bin_list, lists, st);
     if (!b.has_blend) reserve(L.ref, pixels, st);
     if (reserve_only) return;
 
-    size_t tri_off = 0, fan_off = 0, list_off = 0, bin_off = 0, ref_off = 0, matrix_off = 0;
+    size_t tri_off = 0, fan_off = 0, list_off = 0, bin_off = 0, ref_off = 0, matrix_off = 0, tile_off = 0;
     const char *dbg = getenv("MI355R_DEBUG_SKIP");
     for (size_t i = b.first; i < b.last; i++) {
         const PassPlan &pl = plans[i];
@@ -1114,6 +1122,11 @@ static void prepare_batch(const Batch &b, const std::vector<PassPlan> &plans, ch
         P.debug_skip = dbg ? atoi(dbg) : 0;
         P.tiles_x = (W + RZ_TILE_W - 1) / RZ_TILE_W;
         P.tiles_y = (H + RZ_TILE_H - 1) / RZ_TILE_H;
+        P.queue = L.queue.ptr;
+        P.queue_counts = L.queue_counts.ptr;
+        P.queue_capacity = (uint32_t)queue_capacity;
+        P.tile_off = (uint32_t)tile_off;
+        tile_off += (size_t)P.tiles_x * P.tiles_y;
         P.tri_off = (uint32_t)tri_off;
         P.fan_off = (uint32_t)fan_off;
         P.list_off = (uint32_t)list_off;
@@ -1165,6 +1178,12 @@ static void launch_batch(const Batch &b, const std::vector<PassPlan> &plans, cha
     };
     const dim3 vgrid((unsigned)((max_T * 3 + 255) / 256), n), tgrid((unsigned)((max_T + 255) / 256), n);
     const dim3 tiles((unsigned)max_tiles_x, (unsigned)max_tiles_y, n);
+    /* the shade kernels stride over work lists: enough workgroups to fill the device, no more */
+    size_t batch_tiles = 0;
+    for (size_t i = b.first; i < b.last; i++)
+        batch_tiles += (size_t)((plans[i].fb->pub.width + RZ_TILE_W - 1) / RZ_TILE_W) * ((plans[i].fb->pub.height + RZ_TILE_H - 1) / RZ_TILE_H);
+    const uint32_t queue_capacity = (uint32_t)((batch_tiles + RZ_QUEUE_WAYS - 1) / RZ_QUEUE_WAYS);
+    const dim3 shade_grid((unsigned)std::min<size_t>(max_tiles_x * max_tiles_y * n, (size_t)g.shade_workgroups));
     stamp();
     rz_vertex_kernel<<<vgrid, dim3(256), 0, st>>>(passes);
     stamp();
@@ -1194,13 +1213,16 @@ static void launch_batch(const Batch &b, const std::vector<PassPlan> &plans, cha
             passes, L.tri.ptr, L.fan_tri.ptr, L.bin_list.ptr, L.vary.ptr, L.fan_vary.ptr, db, L.bin_range.ptr);
         stamp();
         if (b.families & (1 << RZ_FAMILY_SKYBOX))
-            rz_shade_kernel<2><<<tiles, dim3(256), 0, st>>>(passes, L.tri.ptr, L.fan_tri.ptr, L.vary.ptr, L.fan_vary.ptr, db, L.ref.ptr);
+            rz_shade_kernel<2><<<shade_grid, dim3(256), 0, st>>>(passes, L.tri.ptr, L.fan_tri.ptr, L.vary.ptr, L.fan_vary.ptr, db, L.ref.ptr,
+                                                                 L.queue.ptr, L.queue_counts.ptr, queue_capacity);
         stamp();
         if (b.families & (1 << RZ_FAMILY_BLINN))
-            rz_shade_kernel<0><<<tiles, dim3(256), 0, st>>>(passes, L.tri.ptr, L.fan_tri.ptr, L.vary.ptr, L.fan_vary.ptr, db, L.ref.ptr);
+            rz_shade_kernel<0><<<shade_grid, dim3(256), 0, st>>>(passes, L.tri.ptr, L.fan_tri.ptr, L.vary.ptr, L.fan_vary.ptr, db, L.ref.ptr,
+                                                                 L.queue.ptr, L.queue_counts.ptr, queue_capacity);
         stamp();
         if (b.families & (1 << RZ_FAMILY_PBR))
-            rz_shade_kernel<1><<<tiles, dim3(256), 0, st>>>(passes, L.tri.ptr, L.fan_tri.ptr, L.vary.ptr, L.fan_vary.ptr, db, L.ref.ptr);
+            rz_shade_kernel<1><<<shade_grid, dim3(256), 0, st>>>(passes, L.tri.ptr, L.fan_tri.ptr, L.vary.ptr, L.fan_vary.ptr, db, L.ref.ptr,
+                                                                 L.queue.ptr, L.queue_counts.ptr, queue_capacity);
         stamp();
     }
     HIP_OK(hipGetLastError());

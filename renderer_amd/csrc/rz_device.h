@@ -27,6 +27,8 @@
 #define RZ_MAX_POLY 10              /* corners of a triangle clipped by 7 planes */
 #define RZ_MAX_FAN 8                /* RZ_MAX_POLY - 2 */
 #define RZ_BIN 64                   /* bin edge in pixels */
+#define RZ_QUEUE_WAYS 64u           /* parts of a shade work list (one wave reads all the lengths) */
+#define RZ_QUEUE_PAD 32u            /* counters sit one 128-byte line apart: atomics on one line serialise */
 #define RZ_TILE_W 32                /* raster / shade workgroup tile: 4 waves of 8x8 side by side, */
 #define RZ_TILE_H 8                 /* so a tile row is one 128-byte line of a 4-byte plane */
 
@@ -164,6 +166,12 @@ struct PassParams {
      * and the shade kernels address the batch-wide tables through restrict
      * kernel arguments plus these per-pass offsets. */
     int32_t tiles_x, tiles_y;       /* 32x8 tiles of this framebuffer */
+    /* per batch and shader family: a work list of tiles (pass << 20 | tile y << 9 | tile x) in
+     * RZ_QUEUE_WAYS parts of queue_capacity entries; lengths in queue_counts[family][part] */
+    uint32_t *queue;
+    uint32_t *queue_counts;
+    uint32_t queue_capacity;
+    uint32_t tile_off;              /* tiles before this pass in the batch */
     uint32_t tri_off;               /* triangles before this pass (vertices = 3x) */
     uint32_t fan_off;               /* fan blocks before this pass */
     uint32_t list_off;              /* bin-list entries before this pass */
