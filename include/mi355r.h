@@ -17,6 +17,8 @@
 #ifndef MI355R_H
 #define MI355R_H
 
+#include <stddef.h>
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -290,6 +292,17 @@ typedef struct {
 int mi355r_inspect_pass(rz_pass_info *info);
 void mi355r_inspect_boxes(unsigned int *boxes, unsigned int *fans);
 void mi355r_inspect_bins(unsigned int *counts, unsigned int *entries);
+
+/* Device image formats.  texture->buffer is float RGBA as in the reference
+ * (texture.h:14-17); on the device an image is kept in 4 bytes per texel when
+ * that loses nothing, which is decided by looking at every texel.  This entry
+ * point exposes that decision (host code only, usable without a device):
+ * returns 0 (stays float4), 4 (channel = byte / 255.0f, texture.c:40-61),
+ * 8 (rgb = (float)pow(byte / 255.0f, 2.2), alpha = byte / 255.0f,
+ * texture.c:63-75) or 16 (rgb = (float)mantissa * 2^(e - 136), alpha 1,
+ * image.c:329-347) and, for a non-zero result, the packed words
+ * r | g << 8 | b << 16 | a-or-e << 24 in packed[count]. */
+int mi355r_pack_texels(const rz_vec4 *texels, size_t count, unsigned int *packed);
 
 #ifdef __cplusplus
 }

@@ -439,7 +439,10 @@ static void device_image(Tex *t, int flags_wanted, size_t texel_bytes) {
  * float4. */
 static float g_unorm8[256], g_srgb8[256];
 
-static void init_packed_formats() {
+static void fill_packed_tables() {
+    static bool done = false;
+    if (done) return;
+    done = true;
     for (int k = 0; k < 256; k++) {
         g_unorm8[k] = (float)k / 255.0f;                        /* texture.c:40-61 */
         g_srgb8[k] = (float)pow((double)g_unorm8[k], 2.2);      /* maths.c:37-39 */
@@ -447,6 +450,10 @@ static void init_packed_formats() {
         const float r = 1.0f / 255.0f, f = (float)k, q = f * r;
         if (fmaf(fmaf(-q, 255.0f, f), r, q) != g_unorm8[k]) fatal("byte %d: the division-free k/255 is off", k);
     }
+}
+
+static void init_packed_formats() {
+    fill_packed_tables();
     HIP_OK(hipMemcpyToSymbol(HIP_SYMBOL(rz_srgb8_table), g_srgb8, sizeof g_srgb8));
 }
 
@@ -477,8 +484,8 @@ static int pack_texels(const rz_vec4 *texels, size_t n, std::vector<uint32_t> &o
         if (top == 0) { out[i] = 0; continue; }
         int e2;
         frexpf(top, &e2);                                       /* top = f * 2^e2, f in [0.5, 1): mantissa = f * 256 */
-        const int e = e2 + 128;
-        if (e < 1 || e > 255) return 0;
+        const int e = std::max(e2 + 128, 1);                    /* a smaller exponent byte does not exist; mantissas shrink */
+        if (e > 255) return 0;
         const float factor = ldexpf(1.0f, e - 136);
         uint32_t word = (uint32_t)e << 24;
         for (int c = 0; c < 3; c++) {
@@ -489,6 +496,15 @@ static int pack_texels(const rz_vec4 *texels, size_t n, std::vector<uint32_t> &o
         out[i] = word;
     }
     return RZ_TEX_RGBE8;
+}
+
+/* the format decision alone, for tests: host code only, no device needed */
+extern "C" int mi355r_pack_texels(const rz_vec4 *texels, size_t count, unsigned int *packed) {
+    fill_packed_tables();
+    std::vector<uint32_t> out;
+    const int format = pack_texels(texels, count, out);
+    if (format && packed) memcpy(packed, out.data(), count * sizeof(uint32_t));
+    return format;
 }
 
 /* host float4 image -> device (packed when lossless, 8x8 tiles where possible); load-time path */

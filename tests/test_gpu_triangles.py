@@ -1,0 +1,178 @@
+"""The reference's own entry points driven directly (program_create, program_get_attribs /
+program_get_uniforms, graphics_draw_triangle), with hand-made triangles instead of scenes:
+random overlapping triangles at equal depth (last writer wins), ordered blending over several
+draws, triangles that need the clipper, degenerate and non-finite input, empty passes.
+GPU library against the CPU oracle, bit for bit."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from renderer_amd.binding import Vec4
+
+pytestmark = pytest.mark.gpu
+
+IDENTITY4 = (C.c_float * 16)(1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1)
+IDENTITY3 = (C.c_float * 9)(1, 0, 0, 0, 1, 0, 0, 0, 1)
+
+
+class SkyboxUniforms(C.Structure):
+    _fields_ = [("vp_matrix", C.c_float * 16), ("skybox", C.c_void_p)]
+
+
+class BlinnUniforms(C.Structure):
+    _fields_ = [("light_dir", C.c_float * 3), ("camera_pos", C.c_float * 3), ("model_matrix", C.c_float * 16),
+                ("normal_matrix", C.c_float * 9), ("light_vp_matrix", C.c_float * 16), ("camera_vp_matrix", C.c_float * 16),
+                ("joint_matrices", C.c_void_p), ("joint_n_matrices", C.c_void_p),
+                ("ambient_intensity", C.c_float), ("punctual_intensity", C.c_float), ("shadow_map", C.c_void_p),
+                ("basecolor", C.c_float * 4), ("shininess", C.c_float),
+                ("diffuse_map", C.c_void_p), ("specular_map", C.c_void_p), ("emission_map", C.c_void_p),
+                ("alpha_cutoff", C.c_float), ("shadow_pass", C.c_int)]
+
+
+class BlinnAttribs(C.Structure):
+    _fields_ = [("position", C.c_float * 3), ("texcoord", C.c_float * 2), ("normal", C.c_float * 3),
+                ("joint", C.c_float * 4), ("weight", C.c_float * 4)]
+
+
+assert C.sizeof(SkyboxUniforms) == 72 and C.sizeof(BlinnUniforms) == 344 and C.sizeof(BlinnAttribs) == 64
+
+
+def declare(lib):
+    P = C.c_void_p
+    lib.program_create.restype = P
+    lib.program_create.argtypes = [P, P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+    lib.program_release.argtypes = [P]
+    lib.program_get_attribs.restype = P
+    lib.program_get_attribs.argtypes = [P, C.c_int]
+    lib.program_get_uniforms.restype = P
+    lib.program_get_uniforms.argtypes = [P]
+    lib.graphics_draw_triangle.argtypes = [P, P]
+    lib.cubemap_from_files.restype = P
+    lib.cubemap_from_files.argtypes = [C.c_char_p] * 6 + [C.c_int]
+    lib.cubemap_release.argtypes = [P]
+
+
+def fn(lib, name):
+    return C.cast(getattr(lib, name), C.c_void_p)
+
+
+def skybox_frame(pipe, size, triangles):
+    """triangles: (n, 3, 3) float32 clip-space positions (w = 1 through an identity matrix)."""
+    lib = pipe.lib
+    declare(lib)
+    faces = [("workshop/m1_%s.hdr" % f).encode() for f in ("px", "nx", "py", "ny", "pz", "nz")]
+    cube = lib.cubemap_from_files(*faces, 0)
+    prog = lib.program_create(fn(lib, "skybox_vertex_shader"), fn(lib, "skybox_fragment_shader"), 12, 12, 72, 1, 0)
+    u = SkyboxUniforms.from_address(lib.program_get_uniforms(prog))
+    u.vp_matrix[:] = IDENTITY4[:]
+    u.skybox = cube
+    fb = pipe.framebuffer(*size)
+    lib.framebuffer_clear_color(fb, Vec4(0.1, 0.2, 0.3, 1.0))
+    lib.framebuffer_clear_depth(fb, 1.0)
+    for tri in triangles:
+        for j in range(3):
+            (C.c_float * 3).from_address(lib.program_get_attribs(prog, j))[:] = [float(x) for x in tri[j]]
+        lib.graphics_draw_triangle(C.cast(fb, C.c_void_p), prog)
+    out = pipe.read(fb)
+    pipe.release(fb)
+    lib.program_release(prog)
+    lib.cubemap_release(cube)
+    return out
+
+
+def blinn_frame(pipe, size, triangles, colours, blend, depth_step=0.0):
+    """One draw (own uniform block) per triangle: flat colours, optional alpha blending."""
+    lib = pipe.lib
+    declare(lib)
+    prog = lib.program_create(fn(lib, "blinn_vertex_shader"), fn(lib, "blinn_fragment_shader"), 64, 44, 344, 1, 1 if blend else 0)
+    u = BlinnUniforms.from_address(lib.program_get_uniforms(prog))
+    u.light_dir[:] = [0.0, 0.0, -1.0]
+    u.camera_pos[:] = [0.0, 0.0, 2.0]
+    u.model_matrix[:] = IDENTITY4[:]
+    u.normal_matrix[:] = IDENTITY3[:]
+    u.light_vp_matrix[:] = IDENTITY4[:]
+    u.camera_vp_matrix[:] = IDENTITY4[:]
+    u.ambient_intensity = 0.7
+    u.punctual_intensity = 0.6
+    u.shininess = 12.0
+    fb = pipe.framebuffer(*size)
+    lib.framebuffer_clear_color(fb, Vec4(0.25, 0.25, 0.25, 1.0))
+    lib.framebuffer_clear_depth(fb, 1.0)
+    for i, (tri, colour) in enumerate(zip(triangles, colours)):
+        u.basecolor[:] = [float(c) for c in colour]
+        for j in range(3):
+            a = BlinnAttribs.from_address(lib.program_get_attribs(prog, j))
+            a.position[:] = [float(tri[j][0]), float(tri[j][1]), float(tri[j][2]) - depth_step * i]
+            a.texcoord[:] = [0.5, 0.5]
+            a.normal[:] = [0.0, 0.0, 1.0]
+            a.joint[:] = [0, 0, 0, 0]
+            a.weight[:] = [0, 0, 0, 0]
+        lib.graphics_draw_triangle(C.cast(fb, C.c_void_p), prog)
+    out = pipe.read(fb)
+    pipe.release(fb)
+    lib.program_release(prog)
+    return out
+
+
+def same(a, b):
+    return np.array_equal(a[0], b[0]) and np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32))
+
+
+def random_triangles(seed, n, spread):
+    rng = np.random.default_rng(seed)
+    centre = rng.uniform(-spread, spread, (n, 1, 3))
+    tris = centre + rng.uniform(-0.6, 0.6, (n, 3, 3))
+    tris[..., 2] = rng.uniform(-0.5, 0.5, (n, 3))
+    return tris.astype(np.float32)
+
+
+@pytest.mark.parametrize("size,n,spread", [((160, 90), 200, 0.9), ((333, 77), 64, 1.6), ((64, 64), 1000, 1.0)])
+def test_equal_depth_overlap_last_writer_wins(gpu, oracle, size, n, spread):
+    """The skybox vertex shader pins every depth to the same value: overlapping triangles are
+    resolved purely by submission order (depth test <=, graphics.c:523)."""
+    tris = random_triangles(11 + n, n, spread)
+    assert same(skybox_frame(gpu, size, tris), skybox_frame(oracle, size, tris))
+
+
+def test_triangles_through_the_clipper(gpu, oracle):
+    """Corners far outside the view volume in x, y and z, and behind w = 0 is impossible here
+    (w = 1), so the +-x, +-y, +-z planes do the work (graphics.c:279-313)."""
+    tris = random_triangles(5, 120, 2.5)
+    tris[::3, :, 2] *= 6.0
+    assert same(blinn_frame(gpu, (200, 120), tris, np.tile([[0.8, 0.3, 0.2, 1.0]], (120, 1)), False),
+                blinn_frame(oracle, (200, 120), tris, np.tile([[0.8, 0.3, 0.2, 1.0]], (120, 1)), False))
+
+
+def test_ordered_blending_over_many_draws(gpu, oracle):
+    """Every triangle is its own draw with its own colour and alpha; the blend reads the 8-bit
+    colour below it (graphics.c:455-463), so any reordering changes bytes."""
+    n = 150
+    rng = np.random.default_rng(21)
+    tris = random_triangles(8, n, 0.8)
+    colours = np.concatenate([rng.uniform(0, 1, (n, 3)), rng.uniform(0.2, 0.9, (n, 1))], axis=1)
+    for depth_step in (0.0, 0.001):     # equal depth, and each triangle slightly in front of the last
+        assert same(blinn_frame(gpu, (192, 108), tris * [1, 1, 0], colours, True, depth_step),
+                    blinn_frame(oracle, (192, 108), tris * [1, 1, 0], colours, True, depth_step))
+
+
+def test_degenerate_and_non_finite_triangles(gpu, oracle):
+    tris = random_triangles(3, 40, 0.7)
+    tris[0, 1] = tris[0, 0]                     # two corners coincide
+    tris[1] = tris[1, 0]                        # a point
+    tris[2, 2] = (tris[2, 0] + tris[2, 1]) / 2  # collinear
+    tris[3, 0, 0] = np.nan
+    tris[4, 1, 1] = np.inf
+    tris[5, :, :2] *= 1e20                      # far outside: every corner is clipped away or huge
+    tris[6, :, :2] *= 1e-20                     # smaller than a pixel
+    colours = np.tile([[0.2, 0.7, 0.4, 1.0]], (40, 1))
+    assert same(blinn_frame(gpu, (128, 96), tris, colours, False), blinn_frame(oracle, (128, 96), tris, colours, False))
+
+
+def test_empty_pass_and_clear_only(gpu, oracle):
+    none = np.zeros((0, 3, 3), np.float32)
+    a, b = skybox_frame(gpu, (70, 40), none), skybox_frame(oracle, (70, 40), none)
+    assert same(a, b)
+    assert np.all(a[0] == [25, 51, 76, 255]) and np.all(a[1] == 1.0)      # float_to_uchar truncates (maths.c:33)
+    outside = random_triangles(1, 10, 0.3) + np.float32(5.0)             # all off screen
+    assert same(skybox_frame(gpu, (70, 40), outside), b)

@@ -1,0 +1,136 @@
+"""Lossless device image formats: the host-side decision (mi355r_pack_texels, CPU) must pack an
+image only when decoding gives back the very same floats, and frames rendered from packed images
+must equal frames rendered from float4 images (GPU)."""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import REPO
+from renderer_amd.binding import GPU_LIB
+
+
+@pytest.fixture(scope="module")
+def pack():
+    lib = C.CDLL(GPU_LIB)              # loading and calling this entry point needs no device
+    lib.mi355r_pack_texels.restype = C.c_int
+    lib.mi355r_pack_texels.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
+
+    def run(texels):
+        texels = np.ascontiguousarray(texels, np.float32).reshape(-1, 4)
+        out = np.zeros(len(texels), np.uint32)
+        fmt = lib.mi355r_pack_texels(texels.ctypes.data_as(C.c_void_p), len(texels), out.ctypes.data_as(C.c_void_p))
+        return fmt, out
+    return run
+
+
+UNORM = (np.arange(256, dtype=np.float32) / np.float32(255)).astype(np.float32)            # texture.c:40-61
+SRGB = np.power(UNORM.astype(np.float64), 2.2).astype(np.float32)                           # maths.c:37-39
+
+
+def decode(fmt, words):
+    b = [(words >> s) & 0xff for s in (0, 8, 16, 24)]
+    if fmt == 4:
+        return np.stack([UNORM[b[0]], UNORM[b[1]], UNORM[b[2]], UNORM[b[3]]], axis=1)
+    if fmt == 8:
+        return np.stack([SRGB[b[0]], SRGB[b[1]], SRGB[b[2]], UNORM[b[3]]], axis=1)
+    factor = np.ldexp(np.float32(1), b[3].astype(np.int32) - 136).astype(np.float32)       # image.c:329-347
+    rgb = [(b[i].astype(np.float32) * factor).astype(np.float32) for i in range(3)]
+    return np.stack(rgb + [np.ones(len(words), np.float32)], axis=1)
+
+
+def test_eight_bit_images_pack_and_decode_exactly(pack):
+    rng = np.random.default_rng(3)
+    k = rng.integers(0, 256, (5000, 4))
+    data = np.stack([UNORM[k[:, i]] for i in range(4)], axis=1)
+    fmt, words = pack(data)
+    assert fmt == 4 and np.array_equal(decode(fmt, words), data)
+    colour = np.stack([SRGB[k[:, 0]], SRGB[k[:, 1]], SRGB[k[:, 2]], UNORM[k[:, 3]]], axis=1)
+    fmt, words = pack(colour)
+    assert fmt == 8 and np.array_equal(decode(fmt, words), colour)
+
+
+def test_rgbe_images_pack_and_decode_exactly(pack):
+    rng = np.random.default_rng(4)
+    rgbe = rng.integers(0, 256, (5000, 4))
+    rgbe[:50, 3] = 0                                       # exponent 0 decodes to black
+    rgbe[50:60, 3] = rng.integers(1, 12, 10)               # tiny exponents: denormal floats
+    rgbe[60:70, :3] = [[3, 0, 1]] * 10                     # unnormalised mantissas
+    factor = np.ldexp(1.0 / 256, rgbe[:, 3] - 128).astype(np.float32)
+    texels = np.ones((5000, 4), np.float32)
+    for c in range(3):
+        texels[:, c] = np.where(rgbe[:, 3] == 0, 0, rgbe[:, c].astype(np.float32) * factor)
+    fmt, words = pack(texels)
+    assert fmt == 16 and np.array_equal(decode(fmt, words), texels)
+
+
+@pytest.mark.parametrize("spoil", ["value", "alpha", "nan", "negative", "huge"])
+def test_images_that_do_not_fit_stay_float4(pack, spoil):
+    rng = np.random.default_rng(5)
+    k = rng.integers(0, 256, (1000, 4))
+    data = np.stack([UNORM[k[:, i]] for i in range(4)], axis=1)
+    bad = {"value": (7, 1, np.nextafter(np.float32(0.5), np.float32(1))), "alpha": (7, 3, np.float32(0.123)),
+           "nan": (7, 0, np.float32("nan")), "negative": (7, 2, np.float32(-0.25)), "huge": (7, 0, np.float32(3e38))}[spoil]
+    data[bad[0], bad[1]] = bad[2]
+    fmt, _ = pack(data)
+    assert fmt == 0
+    # the same for an otherwise shared-exponent image
+    hdr = np.ones((100, 4), np.float32)
+    hdr[:, :3] = (rng.integers(0, 256, (100, 3)) * 2.0 ** -7).astype(np.float32)
+    assert pack(hdr)[0] == 16
+    hdr[3, 1] = np.float32(1 / 3)
+    assert pack(hdr)[0] == 0
+
+
+def test_every_loaded_scene_texture_round_trips(pack, oracle):
+    """All images of the benchmark scene as the host layer builds them (TGA / HDR decode + usage
+    conversion): whatever format is chosen decodes to the identical floats."""
+    class Texture(C.Structure):
+        _fields_ = [("width", C.c_int), ("height", C.c_int), ("buffer", C.POINTER(C.c_float))]
+    lib = oracle.lib
+    lib.texture_from_file.restype = C.POINTER(Texture)
+    lib.texture_from_file.argtypes = [C.c_char_p, C.c_int]
+    lib.texture_release.argtypes = [C.POINTER(Texture)]
+    seen = set()
+    for name, usage in [("helmet/helmet_basecolor.tga", 2), ("helmet/helmet_metalness.tga", 1), ("helmet/helmet_normal.tga", 1),
+                        ("common/brdf_lut.hdr", 3), ("workshop/i_px.hdr", 2), ("workshop/m1_nz.hdr", 0)]:
+        tex = lib.texture_from_file(name.encode(), usage)
+        n = tex.contents.width * tex.contents.height
+        texels = np.ctypeslib.as_array(tex.contents.buffer, (n, 4)).copy()
+        lib.texture_release(tex)
+        fmt, words = pack(texels)
+        seen.add(fmt)
+        if fmt:
+            assert np.array_equal(decode(fmt, words), texels), name
+    assert seen == {0, 4, 8, 16}       # tone-mapped sky face, data map, colour map, radiance maps
+
+
+PACK_OFF_SCRIPT = r"""
+import sys, numpy as np
+sys.path.insert(0, %r)
+sys.path.insert(0, %r)
+from conftest import golden_cases, load_golden, render_case
+from renderer_amd.binding import Pipeline, GPU_LIB
+gpu = Pipeline(GPU_LIB)
+bad = 0
+for case in golden_cases():
+    if case["name"] not in ("helmet_default", "azura_shadow", "drone_specgloss"):
+        continue
+    want = load_golden(case["name"]); got = render_case(gpu, case)
+    bad += int((got[0] != want[0]).sum()) + int((got[1] != want[1]).sum())
+print("DIFFS", bad)
+sys.exit(0 if bad == 0 else 1)
+"""
+
+
+@pytest.mark.gpu
+def test_gpu_float4_and_packed_images_give_the_same_frames(gpu):
+    """The default run (packed images) is what every other GPU test checks against the goldens;
+    here the same goldens with packing switched off (MI355R_PACK=0, read when the library starts)."""
+    env = dict(os.environ, MI355R_PACK="0")
+    r = subprocess.run([sys.executable, "-c", PACK_OFF_SCRIPT % (REPO, os.path.join(REPO, "tests"))],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "DIFFS 0" in r.stdout, r.stdout + r.stderr
