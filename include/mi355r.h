@@ -271,7 +271,8 @@ void mi355r_enable_timing(int on);
 unsigned long long mi355r_get_timing(double out[8], int reset);
 
 /* Inspection of the geometry stage of the most recently submitted pass
- * (a pass = a maximal run of draws into one framebuffer).  No counterpart in
+ * (a pass = a maximal run of draws into one framebuffer, cut once more in
+ * front of its first blended draw).  No counterpart in
  * the reference, whose rasterize_triangle walks each bounding box at once
  * (graphics.c:505-532); this is how tests compare the integer binning stage
  * with its CPU statement.  Triangles are numbered in submission order.

@@ -27,7 +27,7 @@
  * of draws into one framebuffer since the last clear / read / sync. */
 static struct {
     rz_framebuffer *fb;
-    int closed;
+    int closed, blended;
     int width, height;
     size_t n, cap;
     unsigned *boxes, *fans;
@@ -39,10 +39,11 @@ static void trace_close(rz_framebuffer *fb) {
     if (g_trace.fb == fb) g_trace.closed = 1;
 }
 
-static void trace_add(rz_framebuffer *fb, const int box[4], int fan) {
+static void trace_add(rz_framebuffer *fb, int blend, const int box[4], int fan) {
     size_t t;
-    if (g_trace.fb != fb || g_trace.closed) {
-        g_trace.fb = fb; g_trace.closed = 0; g_trace.n = 0;
+    /* a pass also ends in front of its first blended draw (include/mi355r.h) */
+    if (g_trace.fb != fb || g_trace.closed || (blend && !g_trace.blended)) {
+        g_trace.fb = fb; g_trace.closed = 0; g_trace.n = 0; g_trace.blended = blend;
         g_trace.width = fb->width; g_trace.height = fb->height;
     }
     if (g_trace.n == g_trace.cap) {
@@ -353,7 +354,7 @@ void graphics_draw_triangle(rz_framebuffer *fb, rz_program *p) {
             if (g_prim_box[3] > box[3]) box[3] = g_prim_box[3];
         }
     }
-    trace_add(fb, box, fan);
+    trace_add(fb, p->blend, box, fan);
 }
 
 /* the per-face loops of the shaders' draw_model (blinn_shader.c:323-341,

@@ -1057,7 +1057,7 @@ static void fill_pass(const PassPlan &pl, char *hb, char *db) {
 /* A batch: passes that do not depend on each other and run in ONE launch
  * sequence (grid y = pass), on one lane. */
 struct Batch {
-    size_t first, last;             /* range in the flush's plan list */
+    std::vector<size_t> members;    /* indices into the flush's plan list, in submission order */
     int lane;
     size_t off_params;              /* PassParams[] in the upload region */
     bool has_blend;
@@ -1071,7 +1071,7 @@ static void prepare_batch(const Batch &b, const std::vector<PassPlan> &plans, ch
     hipStream_t st = L.stream;
     size_t tris = 0, fans = 0, lists = 0, bins = 0, pixels = 0, matrix = 0, tiles = 0;
     std::vector<size_t> fan_cap, list_cap;
-    for (size_t i = b.first; i < b.last; i++) {
+    for (size_t i : b.members) {
         const PassPlan &pl = plans[i];
         const size_t nb = (size_t)((pl.fb->pub.width + RZ_BIN - 1) / RZ_BIN) * ((pl.fb->pub.height + RZ_BIN - 1) / RZ_BIN);
         fan_cap.push_back(std::min<size_t>(pl.T, 1u << 18));
@@ -1099,10 +1099,10 @@ static void prepare_batch(const Batch &b, const std::vector<PassPlan> &plans, ch
 
     size_t tri_off = 0, fan_off = 0, list_off = 0, bin_off = 0, ref_off = 0, matrix_off = 0, tile_off = 0;
     const char *dbg = getenv("MI355R_DEBUG_SKIP");
-    for (size_t i = b.first; i < b.last; i++) {
+    for (size_t k = 0; k < b.members.size(); k++) {
+        const size_t i = b.members[k];
         const PassPlan &pl = plans[i];
         Fb *fb = pl.fb;
-        const size_t k = i - b.first;
         const int W = fb->pub.width, H = fb->pub.height;
         PassParams P;
         memset(&P, 0, sizeof P);
@@ -1166,9 +1166,9 @@ static void prepare_batch(const Batch &b, const std::vector<PassPlan> &plans, ch
 static void launch_batch(const Batch &b, const std::vector<PassPlan> &plans, char *db) {
     Lane &L = g.lanes[b.lane];
     hipStream_t st = L.stream;
-    const unsigned n = (unsigned)(b.last - b.first);
+    const unsigned n = (unsigned)b.members.size();
     size_t max_T = 0, max_bins = 0, max_tiles_x = 0, max_tiles_y = 0;
-    for (size_t i = b.first; i < b.last; i++) {
+    for (size_t i : b.members) {
         const PassPlan &pl = plans[i];
         const int W = pl.fb->pub.width, H = pl.fb->pub.height;
         max_T = std::max(max_T, pl.T);
@@ -1183,7 +1183,7 @@ static void launch_batch(const Batch &b, const std::vector<PassPlan> &plans, cha
         if (paranoid) {
             hipError_t err = hipStreamSynchronize(st);
             if (err != hipSuccess)
-                fatal("kernel stage %d of batch [%zu, %zu) on lane %d failed: %s", stage, b.first, b.last, b.lane, hipGetErrorString(err));
+                fatal("kernel stage %d of the batch starting at pass %zu on lane %d failed: %s", stage, b.members[0], b.lane, hipGetErrorString(err));
             stage++;
         }
         if (!g.timing) return;
@@ -1196,7 +1196,7 @@ static void launch_batch(const Batch &b, const std::vector<PassPlan> &plans, cha
     const dim3 tiles((unsigned)max_tiles_x, (unsigned)max_tiles_y, n);
     /* the shade kernels stride over work lists: enough workgroups to fill the device, no more */
     size_t batch_tiles = 0;
-    for (size_t i = b.first; i < b.last; i++)
+    for (size_t i : b.members)
         batch_tiles += (size_t)((plans[i].fb->pub.width + RZ_TILE_W - 1) / RZ_TILE_W) * ((plans[i].fb->pub.height + RZ_TILE_H - 1) / RZ_TILE_H);
     const uint32_t queue_capacity = (uint32_t)((batch_tiles + RZ_QUEUE_WAYS - 1) / RZ_QUEUE_WAYS);
     const dim3 shade_grid((unsigned)std::min<size_t>(max_tiles_x * max_tiles_y * n, (size_t)g.shade_workgroups));
@@ -1208,7 +1208,7 @@ static void launch_batch(const Batch &b, const std::vector<PassPlan> &plans, cha
     stamp();
     {
         size_t matrix = 0;
-        for (size_t i = b.first; i < b.last; i++) {
+        for (size_t i : b.members) {
             const PassPlan &pl = plans[i];
             const int W = pl.fb->pub.width, H = pl.fb->pub.height;
             matrix += ((pl.T + 63) / 64) * (size_t)((W + RZ_BIN - 1) / RZ_BIN) * ((H + RZ_BIN - 1) / RZ_BIN);
@@ -1262,7 +1262,12 @@ extern "C" void graphics_flush(void) {
     size_t n = g.pending.size(), first = 0;
     while (first < n) {
         size_t last = first + 1;
-        while (last < n && g.pending[last].fb == g.pending[first].fb) last++;
+        /* A pass ends where the framebuffer changes -- and in front of its first blended draw:
+         * the draws before it need no colour below them and go through the split rasteriser and
+         * the per-family shade kernels, only the rest needs ordered in-kernel shading. */
+        const bool starts_blended = (g.pending[first].rec.flags & RZ_DRAW_BLEND) != 0;
+        while (last < n && g.pending[last].fb == g.pending[first].fb &&
+               (starts_blended || !(g.pending[last].rec.flags & RZ_DRAW_BLEND))) last++;
         PassPlan pl;
         pl.first = first;
         pl.last = last;
@@ -1278,30 +1283,43 @@ extern "C" void graphics_flush(void) {
 
     /* batches and lanes */
     const int lanes = g.timing ? 1 : g.num_lanes;      /* per-kernel timing wants kernels alone on the GPU */
+    /* Batches.  Inside one flush a pass depends only on the earlier passes into its own
+     * framebuffer (textures written on the GPU were written before this flush started), so passes
+     * are taken level by level: level = number of earlier passes into the same framebuffer.  A
+     * batch holds passes of one level and one kind of rasteriser, in submission order. */
     std::vector<Batch> batches;
-    for (size_t i = 0; i < plans.size();) {
-        Batch b;
-        b.first = i;
-        b.has_blend = plans[i].has_blend;
-        b.families = 0;
-        std::vector<Fb*> members;
-        size_t j = i;
-        while (j < plans.size() && j - i < g.max_batch) {
-            const PassPlan &pl = plans[j];
-            if (j > i && (pl.has_blend != b.has_blend || pl.samples_gpu_texture ||
-                          std::find(members.begin(), members.end(), pl.fb) != members.end())) break;
-            members.push_back(pl.fb);
-            b.families |= pl.families;
-            j++;
-            if (pl.samples_gpu_texture) break;          /* ordered by events on its own */
+    {
+        std::unordered_map<Fb*, int> depth_of;
+        std::vector<int> level(plans.size());
+        int levels = 0;
+        for (size_t i = 0; i < plans.size(); i++) {
+            level[i] = depth_of[plans[i].fb]++;
+            levels = std::max(levels, level[i] + 1);
         }
-        b.last = j;
-        b.off_params = params_at + sizeof(PassParams) * i;
-        int lane = plans[i].fb->lane;
-        if (lane < 0 || lane >= lanes) { lane = g.next_lane % lanes; g.next_lane = (g.next_lane + 1) % lanes; }
-        b.lane = lane;
-        batches.push_back(b);
-        i = j;
+        size_t params_used = 0;
+        for (int l = 0; l < levels; l++) {
+            for (int blend = 0; blend < 2; blend++) {
+                Batch b;
+                auto close = [&]() {
+                    if (b.members.empty()) return;
+                    b.off_params = params_at + sizeof(PassParams) * params_used;
+                    params_used += b.members.size();
+                    int lane = plans[b.members[0]].fb->lane;
+                    if (lane < 0 || lane >= lanes) { lane = g.next_lane % lanes; g.next_lane = (g.next_lane + 1) % lanes; }
+                    b.lane = lane;
+                    batches.push_back(std::move(b));
+                    b = Batch();
+                };
+                for (size_t i = 0; i < plans.size(); i++) {
+                    if (level[i] != l || (int)plans[i].has_blend != blend) continue;
+                    if (b.members.empty()) { b.has_blend = blend != 0; b.families = 0; }
+                    b.members.push_back(i);
+                    b.families |= plans[i].families;
+                    if (b.members.size() >= g.max_batch) close();
+                }
+                close();
+            }
+        }
     }
 
     size_t at = ring_alloc(total);
@@ -1318,7 +1336,7 @@ extern "C" void graphics_flush(void) {
         Lane &L = g.lanes[b.lane];
         if (!used[b.lane]) { HIP_OK(hipStreamWaitEvent(L.stream, uploaded, 0)); used[b.lane] = true; }
         std::vector<Tex*> sampled;
-        for (size_t i = b.first; i < b.last; i++) {
+        for (size_t i : b.members) {
             const PassPlan &pl = plans[i];
             if (pl.fb->lane >= 0 && pl.fb->lane != b.lane)      /* last touched on another lane */
                 HIP_OK(hipStreamWaitEvent(L.stream, new_event(g.lanes[pl.fb->lane].stream), 0));

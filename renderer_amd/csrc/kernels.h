@@ -871,8 +871,14 @@ __global__ void __launch_bounds__(256) rz_raster_kernel(const PassParams *__rest
     /* iterator over this block's triangles, in list order */
     uint32_t base = 0;
     unsigned long long todo = 0;
-    uint32_t mine = 0; (void)mine;
-    float4 c0 = make_float4(0, 0, 0, 0), c1 = c0, c2 = c0, c3 = c0;    /* this lane's candidate record */
+    /* this lane's candidate of the NEXT group of 64 entries (edge data and box), loaded one group
+     * ahead so that the walk over a long list never waits for memory */
+    float4 n0 = make_float4(0, 0, 0, 0), n1 = n0;
+    float2 nbox = make_float2(0, 0);
+    if (lane < count) {
+        const float4 *e = (const float4*)&list[lane];              /* reference + record, 80 bytes */
+        n0 = e[1]; n1 = e[2]; nbox = *(const float2*)((const char*)e + 72);
+    }
     bool have = false, exhausted = false;
     TriRec r;
     uint32_t ref = 0;
@@ -893,18 +899,20 @@ __global__ void __launch_bounds__(256) rz_raster_kernel(const PassParams *__rest
                     have = true;
                 } else {
                     if (base >= count || P.debug_skip == 4) { exhausted = true; break; }
-                    bool hit = false;
-                    mine = 0;
+                    const float4 c0 = n0, c1 = n1;
+                    const float2 cbox = nbox;
+                    const bool present = base + lane < count;
+                    base += 64u;
                     if (base + lane < count) {
-                        const float4 *e = (const float4*)&list[base + lane];    /* reference + record, 80 bytes */
-                        float4 head = e[0];
-                        c0 = e[1]; c1 = e[2]; c2 = e[3]; c3 = e[4];
-                        mine = __float_as_uint(head.x);
-                        hit = box_overlaps(make_uint2(__float_as_uint(c3.z), __float_as_uint(c3.w)), bx0, by0, bx1, by1);
+                        const float4 *e = (const float4*)&list[base + lane];
+                        n0 = e[1]; n1 = e[2]; nbox = *(const float2*)((const char*)e + 72);
+                    }
+                    bool hit = false;
+                    if (present) {
+                        hit = box_overlaps(make_uint2(__float_as_uint(cbox.x), __float_as_uint(cbox.y)), bx0, by0, bx1, by1);
                         if (hit) hit = !block_outside(c0, c1, cx0, cx1, cy0, cy1);
                     }
                     todo = __ballot(hit);
-                    base += 64u;
                     continue;
                 }
             }
