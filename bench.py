@@ -98,7 +98,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--frames", type=int, default=32, help="frames per step and rank")
+    ap.add_argument("--frames", type=int, default=64, help="frames per step and rank (default: one 64-view orbit)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (gloo: CPU rehearsal of the gather)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     args = ap.parse_args()
 
@@ -114,9 +115,14 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch N>1 with torch.distributed.run")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    local = local % torch.cuda.device_count()       # a rehearsal may put several ranks on one GPU
     torch.cuda.set_device(local)
+    on_device = args.backend == "nccl"
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if on_device:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(args.backend)
 
     gpu = Pipeline(GPU_LIB)
     gpu.lib.mi355r_init(local)
@@ -128,31 +134,39 @@ def main():
     # weak scaling: B frames per rank; rank r renders block r of an orbit of B * world views
     first, last = orbit.shard_views(B * world, rank, world)
     views = [gpu.orbit_view(i % ORBIT, ORBIT) for i in range(first, last)]
-    out = torch.empty((B, HEIGHT, WIDTH, 4), dtype=torch.uint8, device="cuda") if world > 1 else None
+    gather = orbit.FrameGather(B, HEIGHT, WIDTH, "cuda" if on_device else "cpu", rank, world)
 
-    def step():
+    def step(with_gather=True):
         orbit.render_views(gpu, scene, fbs, views)
-        if world > 1:
-            orbit.frames_to_tensor(gpu, fbs, B, out)
-            orbit.gather_frames(out, rank, world)
+        if with_gather:
+            gather.submit(gpu, fbs, B)      # N > 1: this step's transfer overlaps the next step's rendering
 
     def fence():
+        gather.drain()                      # every frame submitted so far has arrived on rank 0
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
+    def timed(steps, with_gather=True):
+        """`steps` steps between two fences; the slowest rank's time."""
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step(with_gather)
+        fence()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device="cuda" if on_device else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
     for _ in range(args.warmup):
         step()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = timed(args.steps)
+    # for N > 1 also the rendering alone, outside the reported value: it separates what the GPUs
+    # render from what rank 0 can take in over its xGMI links
+    render_only = timed(args.steps, with_gather=False) if world > 1 else None
 
     result = None
     if rank == 0:
@@ -192,8 +206,11 @@ def main():
             "config": {"workload": f"pbr helmet + blurred skybox, {WIDTH}x{HEIGHT}, {B} orbit views per step and GPU "
                                    f"(eye 1.5*(sin a, 0.3, cos a), {ORBIT}-view circle)",
                        "frames_per_step": B * world, "triangles_per_frame": faces,
-                       "gather": "rccl gather of RGBA8 frames to rank 0" if world > 1 else "none"},
+                       "gather": ("%s gather of RGBA8 frames to rank 0, overlapped with the next step's rendering"
+                                  % ("rccl" if on_device else args.backend)) if world > 1 else "none"},
             "ms_per_frame": elapsed / total_frames * 1e3,
+            "render_only_fps": (total_frames / render_only) if render_only else None,
+            "gathered_gb_per_s": (total_frames * (world - 1) / world * WIDTH * HEIGHT * 4 / elapsed / 1e9) if world > 1 else None,
             "shaded_fragments_per_frame": shaded_per_frame,
             "shaded_mfrags_per_s": shaded_per_frame * fps / 1e6,
             "fragments_shaded_on_device_per_frame": counters[8] / B,

@@ -55,6 +55,52 @@ def gather_frames(local, rank, world, dst=0):
     return gathered
 
 
+class FrameGather:
+    """The gather as a pipeline of `depth` slots: a step's frames go into the next slot and their
+    gather starts at once (async_op); the slot is only waited for when it comes round again, so
+    the transfer of one step overlaps the rendering of the next.  Rank 0 ends up with
+    `received(slot)` = list over ranks of that step's frames.  world == 1: nothing is moved."""
+
+    def __init__(self, frames, height, width, device, rank, world, depth=2):
+        import torch
+        self.rank, self.world, self.depth, self.count = rank, world, depth, 0
+        self.on_device = torch.device(device).type == "cuda"
+        self.slots = self.inbox = self.work = None
+        if world > 1:
+            shape = (frames, height, width, 4)
+            self.slots = [torch.empty(shape, dtype=torch.uint8, device=device) for _ in range(depth)]
+            self.inbox = [[torch.empty(shape, dtype=torch.uint8, device=device) for _ in range(world)] if rank == 0 else None
+                          for _ in range(depth)]
+            self.work = [None] * depth
+
+    def _finish(self, slot):
+        import torch
+        if self.work[slot] is not None:
+            self.work[slot].wait()
+            if self.on_device:
+                torch.cuda.current_stream().synchronize()   # wait() only orders streams; the slot is reused by other streams
+            self.work[slot] = None
+
+    def submit(self, pipe, framebuffers, count):
+        """Copies `count` finished frames into the next slot and starts gathering it."""
+        import torch.distributed as dist
+        if self.world == 1:
+            return
+        slot = self.count % self.depth
+        self._finish(slot)
+        frames_to_tensor(pipe, framebuffers, count, self.slots[slot])      # returns when the copies are complete
+        self.work[slot] = dist.gather(self.slots[slot], self.inbox[slot], dst=0, async_op=True)
+        self.count += 1
+
+    def drain(self):
+        if self.world > 1:
+            for slot in range(self.depth):
+                self._finish(slot)
+
+    def received(self, slot):
+        return self.inbox[slot]
+
+
 def assemble(gathered, total, world):
     """Rank-major gathered blocks (each padded to the largest block) -> frames in view order."""
     frames = []
