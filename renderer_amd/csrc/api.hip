@@ -117,7 +117,7 @@ struct Lane {
     DevBuf<uint2> bbox;
     DevBuf<uint32_t> clip_list, ref;
     DevBuf<uint2> bin_range;
-    DevBuf<uint32_t> bin_counts, queue, queue_counts;
+    DevBuf<uint32_t> bin_counts, queue, queue_counts, tile_listed;
     DevBuf<BinEntry> bin_list;
 };
 
@@ -971,6 +971,7 @@ static void check_passes_in_flight() {
         const uint32_t *c = (const uint32_t*)(g.ring_host + at);
         if (c[2] & RZ_ERR_FAN_OVERFLOW) fatal("clipped-triangle buffer overflow (%u blocks needed)", c[0]);
         if (c[2] & RZ_ERR_BIN_OVERFLOW) fatal("bin list overflow (%u entries needed)", c[1]);
+        if (c[2] & RZ_ERR_QUEUE_OVERFLOW) fatal("shade work list overflow");
         g.host_counters[3] += c[1];
     }
     g.control_slots.clear();
@@ -1090,9 +1091,11 @@ static void prepare_batch(const Batch &b, const std::vector<PassPlan> &plans, ch
     reserve(L.fan_vary, fans * RZ_MAX_POLY * RZ_VARY_STRIDE, st);
     reserve(L.bin_range, bins, st);
     reserve(L.bin_counts, matrix, st);
+    /* tiles are dealt to the parts of a list by their index: a part holds at most its even share */
     const size_t queue_capacity = (tiles + RZ_QUEUE_WAYS - 1) / RZ_QUEUE_WAYS;
-    reserve(L.queue, 3 * RZ_QUEUE_WAYS * queue_capacity, st);
-    reserve(L.queue_counts, 3 * RZ_QUEUE_WAYS * RZ_QUEUE_PAD, st);
+    reserve(L.tile_listed, tiles, st);
+    reserve(L.queue, 2 * RZ_QUEUE_WAYS * queue_capacity, st);
+    reserve(L.queue_counts, 2 * RZ_QUEUE_WAYS * RZ_QUEUE_PAD, st);
     reserve(L.bin_list, lists, st);
     if (!b.has_blend) reserve(L.ref, pixels, st);
     if (reserve_only) return;
@@ -1138,6 +1141,7 @@ static void prepare_batch(const Batch &b, const std::vector<PassPlan> &plans, ch
         P.debug_skip = dbg ? atoi(dbg) : 0;
         P.tiles_x = (W + RZ_TILE_W - 1) / RZ_TILE_W;
         P.tiles_y = (H + RZ_TILE_H - 1) / RZ_TILE_H;
+        P.tile_listed = L.tile_listed.ptr + tile_off;
         P.queue = L.queue.ptr;
         P.queue_counts = L.queue_counts.ptr;
         P.queue_capacity = (uint32_t)queue_capacity;
@@ -1229,16 +1233,15 @@ static void launch_batch(const Batch &b, const std::vector<PassPlan> &plans, cha
             passes, L.tri.ptr, L.fan_tri.ptr, L.bin_list.ptr, L.vary.ptr, L.fan_vary.ptr, db, L.bin_range.ptr);
         stamp();
         if (b.families & (1 << RZ_FAMILY_SKYBOX))
-            rz_shade_kernel<2><<<shade_grid, dim3(256), 0, st>>>(passes, L.tri.ptr, L.fan_tri.ptr, L.vary.ptr, L.fan_vary.ptr, db, L.ref.ptr,
-                                                                 L.queue.ptr, L.queue_counts.ptr, queue_capacity);
+            rz_shade_kernel<2><<<tiles, dim3(256), 0, st>>>(passes, L.tri.ptr, L.fan_tri.ptr, L.vary.ptr, L.fan_vary.ptr, db, L.ref.ptr);
         stamp();
         if (b.families & (1 << RZ_FAMILY_BLINN))
-            rz_shade_kernel<0><<<shade_grid, dim3(256), 0, st>>>(passes, L.tri.ptr, L.fan_tri.ptr, L.vary.ptr, L.fan_vary.ptr, db, L.ref.ptr,
-                                                                 L.queue.ptr, L.queue_counts.ptr, queue_capacity);
+            rz_shade_list_kernel<0><<<shade_grid, dim3(256), 0, st>>>(passes, L.tri.ptr, L.fan_tri.ptr, L.vary.ptr, L.fan_vary.ptr, db, L.ref.ptr,
+                                                                      L.queue.ptr, L.queue_counts.ptr, queue_capacity);
         stamp();
         if (b.families & (1 << RZ_FAMILY_PBR))
-            rz_shade_kernel<1><<<shade_grid, dim3(256), 0, st>>>(passes, L.tri.ptr, L.fan_tri.ptr, L.vary.ptr, L.fan_vary.ptr, db, L.ref.ptr,
-                                                                 L.queue.ptr, L.queue_counts.ptr, queue_capacity);
+            rz_shade_list_kernel<1><<<shade_grid, dim3(256), 0, st>>>(passes, L.tri.ptr, L.fan_tri.ptr, L.vary.ptr, L.fan_vary.ptr, db, L.ref.ptr,
+                                                                      L.queue.ptr, L.queue_counts.ptr, queue_capacity);
         stamp();
     }
     HIP_OK(hipGetLastError());

@@ -62,7 +62,11 @@ __global__ void __launch_bounds__(256) rz_vertex_kernel(const PassParams *__rest
     const PassParams &P = passes[blockIdx.y];
     uint32_t gv = blockIdx.x * 256u + threadIdx.x;
     if (gv < 8u) P.control[gv] = 0;             /* the pass's device-written scalars start at zero */
-    if (blockIdx.y == 0 && gv < 3u * RZ_QUEUE_WAYS) P.queue_counts[gv * RZ_QUEUE_PAD] = 0;    /* ... and the batch's work-list lengths */
+    if (blockIdx.y == 0 && gv < 2u * RZ_QUEUE_WAYS) P.queue_counts[gv * RZ_QUEUE_PAD] = 0;    /* ... and the batch's work-list lengths */
+    if (gv < (uint32_t)(P.tiles_x * P.tiles_y)) P.tile_listed[gv] = 0;         /* (3 vertices per triangle: more threads than tiles
+                                                                                  for any pass that fills its framebuffer; the rest below) */
+    if (gv == 0)
+        for (uint32_t t = 3u * (uint32_t)P.num_tris; t < (uint32_t)(P.tiles_x * P.tiles_y); t++) P.tile_listed[t] = 0;
     if (gv >= 3u * (uint32_t)P.num_tris) return;
     int d = find_draw(P.first_tri, P.num_draws, gv / 3u);
     const DrawRec &D = P.draws[d];
@@ -989,42 +993,90 @@ __global__ void __launch_bounds__(256) rz_raster_kernel(const PassParams *__rest
         }
     }
     if (SPLIT) {
-        /* The tile goes on the work list of every shader family it holds fragments of.  A list is
-         * kept in RZ_QUEUE_WAYS parts, chosen by the tile's index, so that the appends of a whole
-         * batch do not pile up on one counter. */
-        __shared__ uint32_t s_families;
-        if (threadIdx.x == 0) s_families = 0;
-        __syncthreads();
+        /* Blinn and pbr fragments usually cover a small part of the screen: every tile that holds
+         * some goes on that family's work list (all passes of the batch together), and the shade
+         * kernel of the family walks the list.  The first wave of a tile to find such a fragment
+         * appends the tile (tile_listed keeps who was first); waves without any pay nothing.  A
+         * list is kept in RZ_QUEUE_WAYS parts, chosen by the tile's index, with counters a cache
+         * line apart, so that the appends of a whole batch do not pile up on one counter.  Skybox
+         * fragments are found by scanning the tiles. */
         const uint32_t family = (ref0 >> 28) & 3u;                  /* 3 = no fragment */
-        uint32_t mask = 0;
-        for (uint32_t f = 0; f < 3; f++) if (__any(depth_of_stack && family == f)) mask |= 1u << f;
-        if (lane == 0 && mask) atomicOr(&s_families, mask);
-        __syncthreads();
-        if (threadIdx.x < 3 && (s_families >> threadIdx.x & 1u)) {
-            const uint32_t tile = P.tile_off + blockIdx.y * (uint32_t)P.tiles_x + blockIdx.x;
-            const uint32_t part = threadIdx.x * RZ_QUEUE_WAYS + (tile & (RZ_QUEUE_WAYS - 1u));
-            const uint32_t at = atomicAdd(&P.queue_counts[part * RZ_QUEUE_PAD], 1u);
-            P.queue[(size_t)part * P.queue_capacity + at] = ((uint32_t)blockIdx.z << 20) | ((uint32_t)blockIdx.y << 9) | (uint32_t)blockIdx.x;
+        for (uint32_t f = 0; f < 2; f++) {
+            if (!__any(depth_of_stack && family == f)) continue;
+            if (lane == 0) {
+                const uint32_t tile = blockIdx.y * (uint32_t)P.tiles_x + blockIdx.x;
+                const uint32_t before = atomicOr(&P.tile_listed[tile], 1u << f);
+                if (!(before >> f & 1u)) {
+                    /* by the tile's index in the batch: no part can get more than its even share */
+                    const uint32_t part = f * RZ_QUEUE_WAYS + ((P.tile_off + tile) & (RZ_QUEUE_WAYS - 1u));
+                    const uint32_t at = atomicAdd(&P.queue_counts[part * RZ_QUEUE_PAD], 1u);
+                    if (at < P.queue_capacity)
+                        P.queue[(size_t)part * P.queue_capacity + at] = ((uint32_t)blockIdx.z << 20) | ((uint32_t)blockIdx.y << 9) | (uint32_t)blockIdx.x;
+                    else
+                        atomicOr(&P.control[2], (uint32_t)RZ_ERR_QUEUE_OVERFLOW);
+                }
+            }
         }
     }
 }
 
 /* K5  per-family fragment kernels for passes rasterised with SPLIT = true:
- * every lane shades the one fragment its pixel refers to.  The rasteriser
- * left, per family, work lists of the tiles that hold such fragments (all
- * passes of the batch together); a fixed number of workgroups strides over
- * them, so no wave is spent on a tile without work.  Pixels are independent
- * here, so a wave takes two 32-pixel rows of the tile: reference and colour
- * planes are read and written as whole 128-byte lines. */
+ * every lane shades the one fragment its pixel refers to. */
+template <int FAMILY>
+RZ_DEV void shade_pixel(const PassParams &P, const TriRec *__restrict__ tri_base, const TriRec *__restrict__ fan_base,
+                        const float *__restrict__ vary_base, const float *__restrict__ fan_vary_base,
+                        const char *__restrict__ upload_base, const uint32_t *__restrict__ ref_base,
+                        int px, int py) {
+    const TriRec *tri_table = tri_base + P.tri_off;
+    const TriRec *fan_table = fan_base + (size_t)P.fan_off * RZ_MAX_FAN;
+    const float *vary_table = vary_base + (size_t)P.tri_off * 3 * RZ_VARY_STRIDE;
+    const float *fan_vary_table = fan_vary_base + (size_t)P.fan_off * RZ_MAX_POLY * RZ_VARY_STRIDE;
+    const DrawRec *draw_table = (const DrawRec*)(upload_base + P.draws_off);
+    const uint32_t *ref_table = ref_base + P.ref_off;
+    const bool valid = px < P.width && py < P.height;
+    const uint32_t pixel = (uint32_t)py * (uint32_t)P.width + (uint32_t)px;
+    uint32_t myref = valid ? ref_table[pixel] : RZ_REF_NONE;
+    if (P.debug_skip) myref = RZ_REF_NONE;
+    /* the rasteriser tagged the reference with the fragment's family (RZ_REF_NONE reads as family 3) */
+    const bool want = ((myref >> 28) & 3u) == (uint32_t)FAMILY;
+    if (!__any(want)) return;
+    myref &= ~RZ_REF_FAMILY_BITS;
+    TriRec m;
+    const float *m0 = vary_table, *m1 = vary_table, *m2 = vary_table;
+    if (want) fetch_ref(myref, tri_table, fan_table, vary_table, fan_vary_table, m, m0, m1, m2);
+    /* the colour below only lends its alpha byte; under a pending clear it is the clear colour */
+    uint32_t ccur = P.clear_color;
+    if (want && !P.clear_color_pending) ccur = P.color[pixel];
+    shade_lanes<FAMILY>(P, draw_table, want, m, m0, m1, m2, px, py, ccur);
+    if (want) P.color[pixel] = ccur;
+}
+
+/* over every tile of every pass (grid x, y = tile, z = pass): for a family that fills most of the
+ * screen (the skybox).  Pixels are independent here, so a wave takes two 32-pixel rows of the tile:
+ * reference and colour planes are read and written as whole 128-byte lines. */
 template <int FAMILY>
 __global__ void __launch_bounds__(256) rz_shade_kernel(const PassParams *__restrict__ passes,
+        const TriRec *__restrict__ tri_base, const TriRec *__restrict__ fan_base,
+        const float *__restrict__ vary_base, const float *__restrict__ fan_vary_base,
+        const char *__restrict__ upload_base, const uint32_t *__restrict__ ref_base) {
+    const PassParams &P = passes[blockIdx.z];
+    if ((int)blockIdx.x >= P.tiles_x || (int)blockIdx.y >= P.tiles_y) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    shade_pixel<FAMILY>(P, tri_base, fan_base, vary_base, fan_vary_base, upload_base, ref_base,
+                        (int)blockIdx.x * RZ_TILE_W + (lane & 31), (int)blockIdx.y * RZ_TILE_H + wave * 2 + (lane >> 5));
+}
+
+/* over the family's work list of tiles: a fixed number of workgroups strides over it, so no wave
+ * is spent on a tile without work */
+template <int FAMILY>
+__global__ void __launch_bounds__(256) rz_shade_list_kernel(const PassParams *__restrict__ passes,
         const TriRec *__restrict__ tri_base, const TriRec *__restrict__ fan_base,
         const float *__restrict__ vary_base, const float *__restrict__ fan_vary_base,
         const char *__restrict__ upload_base, const uint32_t *__restrict__ ref_base,
         const uint32_t *__restrict__ queue_base, const uint32_t *__restrict__ queue_counts, uint32_t queue_capacity) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     /* lane q holds the length of part q of this family's list */
-    const uint32_t my_count = queue_counts[(FAMILY * RZ_QUEUE_WAYS + lane) * RZ_QUEUE_PAD];
+    const uint32_t my_count = min(queue_counts[(FAMILY * RZ_QUEUE_WAYS + lane) * RZ_QUEUE_PAD], queue_capacity);
     uint32_t longest = my_count;
     for (int off = 32; off > 0; off >>= 1) longest = max(longest, (uint32_t)__shfl_xor((int)longest, off));
     longest = (uint32_t)__builtin_amdgcn_readfirstlane((int)longest);
@@ -1033,31 +1085,8 @@ __global__ void __launch_bounds__(256) rz_shade_kernel(const PassParams *__restr
         if (index >= (uint32_t)__builtin_amdgcn_readlane((int)my_count, (int)part)) continue;
         const uint32_t item = queue_base[(size_t)(FAMILY * RZ_QUEUE_WAYS + part) * queue_capacity + index];
         const PassParams &P = passes[item >> 20];
-        const int tile_x = (int)(item & 511u), tile_y = (int)((item >> 9) & 2047u);
-        const TriRec *tri_table = tri_base + P.tri_off;
-        const TriRec *fan_table = fan_base + (size_t)P.fan_off * RZ_MAX_FAN;
-        const float *vary_table = vary_base + (size_t)P.tri_off * 3 * RZ_VARY_STRIDE;
-        const float *fan_vary_table = fan_vary_base + (size_t)P.fan_off * RZ_MAX_POLY * RZ_VARY_STRIDE;
-        const DrawRec *draw_table = (const DrawRec*)(upload_base + P.draws_off);
-        const uint32_t *ref_table = ref_base + P.ref_off;
-        const int px = tile_x * RZ_TILE_W + (lane & 31);
-        const int py = tile_y * RZ_TILE_H + wave * 2 + (lane >> 5);
-        const bool valid = px < P.width && py < P.height;
-        const uint32_t pixel = (uint32_t)py * (uint32_t)P.width + (uint32_t)px;
-        uint32_t myref = valid ? ref_table[pixel] : RZ_REF_NONE;
-        if (P.debug_skip) myref = RZ_REF_NONE;
-        /* the rasteriser tagged the reference with the fragment's family (RZ_REF_NONE reads as family 3) */
-        const bool want = ((myref >> 28) & 3u) == (uint32_t)FAMILY;
-        if (!__any(want)) continue;
-        myref &= ~RZ_REF_FAMILY_BITS;
-        TriRec m;
-        const float *m0 = vary_table, *m1 = vary_table, *m2 = vary_table;
-        if (want) fetch_ref(myref, tri_table, fan_table, vary_table, fan_vary_table, m, m0, m1, m2);
-        /* the colour below only lends its alpha byte; under a pending clear it is the clear colour */
-        uint32_t ccur = P.clear_color;
-        if (want && !P.clear_color_pending) ccur = P.color[pixel];
-        shade_lanes<FAMILY>(P, draw_table, want, m, m0, m1, m2, px, py, ccur);
-        if (want) P.color[pixel] = ccur;
+        shade_pixel<FAMILY>(P, tri_base, fan_base, vary_base, fan_vary_base, upload_base, ref_base,
+                            (int)(item & 511u) * RZ_TILE_W + (lane & 31), (int)((item >> 9) & 2047u) * RZ_TILE_H + wave * 2 + (lane >> 5));
     }
 }
 

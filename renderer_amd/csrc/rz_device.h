@@ -166,8 +166,11 @@ struct PassParams {
      * and the shade kernels address the batch-wide tables through restrict
      * kernel arguments plus these per-pass offsets. */
     int32_t tiles_x, tiles_y;       /* 32x8 tiles of this framebuffer */
-    /* per batch and shader family: a work list of tiles (pass << 20 | tile y << 9 | tile x) in
-     * RZ_QUEUE_WAYS parts of queue_capacity entries; lengths in queue_counts[family][part] */
+    /* per batch, for the blinn and pbr families: a work list of tiles (pass << 20 | tile y << 9 |
+     * tile x) in RZ_QUEUE_WAYS parts of queue_capacity entries; lengths in
+     * queue_counts[(family * RZ_QUEUE_WAYS + part) * RZ_QUEUE_PAD]; tile_listed[tile of this pass]:
+     * bit f set = the tile is on family f's list */
+    uint32_t *tile_listed;
     uint32_t *queue;
     uint32_t *queue_counts;
     uint32_t queue_capacity;
@@ -180,6 +183,6 @@ struct PassParams {
     uint64_t draws_off;             /* byte offset of draws[] in the flush's upload region */
 };
 
-enum { RZ_ERR_FAN_OVERFLOW = 1, RZ_ERR_BIN_OVERFLOW = 2 };
+enum { RZ_ERR_FAN_OVERFLOW = 1, RZ_ERR_BIN_OVERFLOW = 2, RZ_ERR_QUEUE_OVERFLOW = 4 };
 
 #endif
