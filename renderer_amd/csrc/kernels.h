@@ -833,7 +833,7 @@ __global__ void __launch_bounds__(256) rz_raster_kernel(const PassParams *__rest
         const float *__restrict__ vary_base, const float *__restrict__ fan_vary_base,
         const char *__restrict__ upload_base, const uint2 *__restrict__ bin_range_base) {
     /* grid: x, y = tile column / row, z = pass of the batch */
-    const PassParams &P = passes[blockIdx.z];
+    const PassParams P = passes[blockIdx.z];          /* by value: one burst of scalar loads up front, not one wait per field */
     if ((int)blockIdx.x >= P.tiles_x || (int)blockIdx.y >= P.tiles_y) return;
     /* this pass's slices of the batch-wide tables */
     const TriRec *tri_table = tri_base + P.tri_off;
@@ -1059,7 +1059,7 @@ __global__ void __launch_bounds__(256) rz_shade_kernel(const PassParams *__restr
         const TriRec *__restrict__ tri_base, const TriRec *__restrict__ fan_base,
         const float *__restrict__ vary_base, const float *__restrict__ fan_vary_base,
         const char *__restrict__ upload_base, const uint32_t *__restrict__ ref_base) {
-    const PassParams &P = passes[blockIdx.z];
+    const PassParams P = passes[blockIdx.z];          /* by value: one burst of scalar loads up front, not one wait per field */
     if ((int)blockIdx.x >= P.tiles_x || (int)blockIdx.y >= P.tiles_y) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     shade_pixel<FAMILY>(P, tri_base, fan_base, vary_base, fan_vary_base, upload_base, ref_base,
@@ -1084,7 +1084,7 @@ __global__ void __launch_bounds__(256) rz_shade_list_kernel(const PassParams *__
         const uint32_t part = k & (RZ_QUEUE_WAYS - 1u), index = k / RZ_QUEUE_WAYS;
         if (index >= (uint32_t)__builtin_amdgcn_readlane((int)my_count, (int)part)) continue;
         const uint32_t item = queue_base[(size_t)(FAMILY * RZ_QUEUE_WAYS + part) * queue_capacity + index];
-        const PassParams &P = passes[item >> 20];
+        const PassParams P = passes[item >> 20];
         shade_pixel<FAMILY>(P, tri_base, fan_base, vary_base, fan_vary_base, upload_base, ref_base,
                             (int)(item & 511u) * RZ_TILE_W + (lane & 31), (int)((item >> 9) & 2047u) * RZ_TILE_H + wave * 2 + (lane >> 5));
     }
