@@ -30,9 +30,9 @@ WIDTH, HEIGHT = 1920, 1080
 SCENE = "helmet"
 ORBIT = 64                  # views on the orbit circle
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E
-KERNEL_SYMBOL = {"vertex": "rz_vertex_kernel", "setup": "rz_setup_kernel", "bin": "rz_bin_kernel",
+KERNEL_SYMBOL = {"vertex": "rz_vertex_kernel", "setup": "rz_setup_kernel", "bin": "rz_bin_fill_kernel",
                  "raster": "rz_raster_kernel<true>", "shade_skybox": "rz_shade_kernel<2>",
-                 "shade_blinn": "rz_shade_kernel<0>", "shade_pbr": "rz_shade_kernel<1>"}
+                 "shade_blinn": "rz_shade_list_kernel<0>", "shade_pbr": "rz_shade_list_kernel<1>"}
 
 
 def reference_frame_bytes(counters, frames, faces):
@@ -81,16 +81,16 @@ def cpu_baseline(frames_wanted):
                       f"(gcc -O3 -flto -ffast-math), {os.cpu_count()} host cores available"}
 
 
-def measured_traffic(symbol, frames_per_launch):
-    """HBM bytes per launch of `symbol` from the committed PMC passes (tools/profile.sh), if they
-    were taken with the same number of frames per launch; else None."""
+def measured_counters(symbol, frames_per_launch, key):
+    """A per-launch figure of `symbol` from the committed PMC passes (tools/profile.sh ->
+    profiles/traffic.json), if they were taken with the same number of frames per launch; else None."""
     path = os.path.join(REPO, "profiles", "traffic.json")
     if not os.path.exists(path):
         return None
     t = json.load(open(path))
     if t.get("frames_per_launch") != frames_per_launch or symbol not in t.get("kernels", {}):
         return None
-    return t["kernels"][symbol]["hbm_bytes_per_launch"]
+    return t["kernels"][symbol].get(key)
 
 
 def main():
@@ -217,7 +217,8 @@ def main():
             "kernel_ms_per_frame": per_frame_ms,
             "roofline": {"bound": "hbm", "kernel": KERNEL_SYMBOL[dominant], "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": measured_traffic(KERNEL_SYMBOL[dominant], frames_per_launch),
+                         "traffic": measured_counters(KERNEL_SYMBOL[dominant], frames_per_launch, "hbm_bytes_per_launch"),
+                         "valu_issue_frac": measured_counters(KERNEL_SYMBOL[dominant], frames_per_launch, "valu_issue_frac"),
                          "algorithmic_bytes_per_launch": bytes_per_launch, "launch_ms": launch_ms,
                          "frames_per_launch": frames_per_launch},
             "frame_roofline": {"bound": "hbm", "achieved": frame_achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -820,6 +820,12 @@ static void snapshot_uniforms(rz_program *p, Pending &pd, int num_joints) {
         copy_floats(r.camera_vp, &u->vp_matrix, 16);
         r.skybox = dev_cube(u->skybox);
         if (!r.skybox) fatal("skybox draw without a cube map");
+        bool uniform = true;
+        for (int i = 0; i < 6; i++) {
+            r.maps[i] = dev_tex(u->skybox->faces[i]);
+            uniform = uniform && r.maps[i].w == r.maps[0].w && r.maps[i].h == r.maps[0].h && r.maps[i].flags == r.maps[0].flags;
+        }
+        if (uniform) r.flags |= RZ_DRAW_UNIFORM_CUBE;
     } else if (p->family == RZ_FAMILY_BLINN) {
         const rz_blinn_uniforms *u = (const rz_blinn_uniforms*)p->uniforms;
         r.num_varyings = 11;

@@ -1041,12 +1041,23 @@ RZ_DEV void shade_pixel(const PassParams &P, const TriRec *__restrict__ tri_base
     const bool want = ((myref >> 28) & 3u) == (uint32_t)FAMILY;
     if (!__any(want)) return;
     myref &= ~RZ_REF_FAMILY_BITS;
-    TriRec m;
-    const float *m0 = vary_table, *m1 = vary_table, *m2 = vary_table;
-    if (want) fetch_ref(myref, tri_table, fan_table, vary_table, fan_vary_table, m, m0, m1, m2);
     /* the colour below only lends its alpha byte; under a pending clear it is the clear colour */
     uint32_t ccur = P.clear_color;
     if (want && !P.clear_color_pending) ccur = P.color[pixel];
+    TriRec m;
+    const float *m0 = vary_table, *m1 = vary_table, *m2 = vary_table;
+    if (FAMILY == 2) {
+        /* a sky triangle usually spans the whole wave: then its record and varyings are the same
+         * for every lane and come through scalar loads */
+        const uint32_t first = (uint32_t)__builtin_amdgcn_readlane((int)myref, __ffsll((long long)__ballot(want)) - 1);
+        if (__all(!want || myref == first)) {
+            fetch_ref(first, tri_table, fan_table, vary_table, fan_vary_table, m, m0, m1, m2);
+            shade_lanes<FAMILY>(P, draw_table, want, m, m0, m1, m2, px, py, ccur);
+            if (want) P.color[pixel] = ccur;
+            return;
+        }
+    }
+    if (want) fetch_ref(myref, tri_table, fan_table, vary_table, fan_vary_table, m, m0, m1, m2);
     shade_lanes<FAMILY>(P, draw_table, want, m, m0, m1, m2, px, py, ccur);
     if (want) P.color[pixel] = ccur;
 }

@@ -63,7 +63,8 @@ enum {
     RZ_DRAW_DOUBLE_SIDED = 1,
     RZ_DRAW_BLEND = 2,
     RZ_DRAW_SHADOW_PASS = 4,
-    RZ_DRAW_SKINNED = 8
+    RZ_DRAW_SKINNED = 8,
+    RZ_DRAW_UNIFORM_CUBE = 16       /* skybox: the six faces have one size and format */
 };
 
 struct DrawRec {
@@ -95,7 +96,7 @@ struct DrawRec {
      *      normal, occlusion, emission} */
     DevTex maps[6];
     const DevIbl *ibl;
-    const DevTex *skybox;           /* 6 faces */
+    const DevTex *skybox;           /* 6 faces (the same six are in maps[] of a skybox draw) */
     int32_t workflow;               /* 0 metal-rough, 1 spec-gloss */
     float alpha_cutoff;
     int32_t layer_view;

@@ -513,9 +513,19 @@ RZ_DEV f4 fs_pbr(const DrawRec &D, const float *v, bool backface, bool *discard)
     }
 }
 
-/* ---- skybox: varyings = direction[3] (skybox_shader.c:21-29) -------------- */
+/* ---- skybox: varyings = direction[3] (skybox_shader.c:21-29); the six face descriptors sit in
+ *      the draw's own maps[] (a skybox has no material maps), so the face a lane needs is one load
+ *      away; when all faces share size and format only the image address differs per lane -------- */
 RZ_DEV f4 fs_skybox(const DrawRec &D, const float *v) {
-    return cube_repeat(D.skybox, mk3(v[0], v[1], v[2]));
+    float s, t;
+    const int face = cube_face(mk3(v[0], v[1], v[2]), &s, &t);
+    if (D.flags & RZ_DRAW_UNIFORM_CUBE) {
+        DevTex f = D.maps[0];
+        f.data = D.maps[face].data;
+        return sample_repeat(f, s, 1 - t);                      /* texture.c:257 */
+    }
+    const DevTex f = D.maps[face];
+    return sample_repeat(f, s, 1 - t);
 }
 
 #endif

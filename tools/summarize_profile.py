@@ -63,7 +63,16 @@ for k in stats:
     if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
         fetch = sum(c["FETCH_SIZE"]) / len(c["FETCH_SIZE"]) * 1024
         write = sum(c["WRITE_SIZE"]) / len(c["WRITE_SIZE"]) * 1024
-        traffic["kernels"][k] = {"fetch_size_bytes_raw": fetch, "write_size_bytes": write,
-                                 "hbm_bytes_per_launch": 2 * fetch + write,
-                                 "median_us": median(durations.get(k, []))}
+        entry = {"fetch_size_bytes_raw": fetch, "write_size_bytes": write,
+                 "hbm_bytes_per_launch": 2 * fetch + write,
+                 "median_us": median(durations.get(k, []))}
+        # VALU issue utilisation: wave-level VALU instructions x 4 cycles (a wave64 op on a 16-lane SIMD)
+        # over the cycles the 1024 SIMDs had during the launch, at the 2.4 GHz peak engine clock
+        if "SQ_INSTS_VALU" in c and entry["median_us"] == entry["median_us"]:
+            valu = sum(c["SQ_INSTS_VALU"]) / len(c["SQ_INSTS_VALU"])
+            salu = sum(c["SQ_INSTS_SALU"]) / len(c["SQ_INSTS_SALU"]) if "SQ_INSTS_SALU" in c else 0.0
+            entry["valu_insts_per_launch"] = valu
+            entry["salu_insts_per_launch"] = salu
+            entry["valu_issue_frac"] = valu * 4 / (1024 * entry["median_us"] * 2400.0)
+        traffic["kernels"][k] = entry
 json.dump(traffic, open(os.path.join(out, "traffic.json"), "w"), indent=1)
