@@ -133,6 +133,7 @@ struct Context {
     int num_lanes = 1, next_lane = 0;
     size_t max_batch = 16;                  /* passes per launch sequence */
     bool pack_textures = true;              /* MI355R_PACK=0: keep every image as float4 */
+    bool narrow_raster = false;             /* MI355R_NARROW_RASTER=1: one pixel per lane in the visibility pass */
     int shade_workgroups = 4096;            /* 256-thread workgroups per shade launch (compute units x 16) */
     std::vector<hipEvent_t> events;     /* recorded since the last full sync */
     std::vector<Tex*> current_gpu_textures;
@@ -221,6 +222,8 @@ extern "C" int mi355r_init(int device) {
         g.num_lanes = env ? atoi(env) : 4;
         if (g.num_lanes < 1) g.num_lanes = 1;
         if (g.num_lanes > MAX_LANES) g.num_lanes = MAX_LANES;
+        env = getenv("MI355R_NARROW_RASTER");
+        if (env) g.narrow_raster = atoi(env) != 0;
         env = getenv("MI355R_PACK");
         if (env) g.pack_textures = atoi(env) != 0;
         env = getenv("MI355R_BATCH");
@@ -1235,8 +1238,11 @@ static void launch_batch(const Batch &b, const std::vector<PassPlan> &plans, cha
             passes, L.tri.ptr, L.fan_tri.ptr, L.bin_list.ptr, L.vary.ptr, L.fan_vary.ptr, db, L.bin_range.ptr);
         stamp(); stamp(); stamp(); stamp();
     } else {
-        rz_raster_kernel<true><<<tiles, dim3(256), 0, st>>>(
-            passes, L.tri.ptr, L.fan_tri.ptr, L.bin_list.ptr, L.vary.ptr, L.fan_vary.ptr, db, L.bin_range.ptr);
+        if (g.narrow_raster)
+            rz_raster_kernel<true><<<tiles, dim3(256), 0, st>>>(
+                passes, L.tri.ptr, L.fan_tri.ptr, L.bin_list.ptr, L.vary.ptr, L.fan_vary.ptr, db, L.bin_range.ptr);
+        else
+            rz_visibility_kernel<<<tiles, dim3(128), 0, st>>>(passes, L.bin_list.ptr, L.vary.ptr, L.fan_vary.ptr, db, L.bin_range.ptr);
         stamp();
         if (b.families & (1 << RZ_FAMILY_SKYBOX))
             rz_shade_kernel<2><<<tiles, dim3(256), 0, st>>>(passes, L.tri.ptr, L.fan_tri.ptr, L.vary.ptr, L.fan_vary.ptr, db, L.ref.ptr);

@@ -1020,6 +1020,159 @@ __global__ void __launch_bounds__(256) rz_raster_kernel(const PassParams *__rest
     }
 }
 
+/* K4b  visibility only, for passes without blending (what rz_raster_kernel<true> computes), two
+ * pixels per lane: a wave owns a 16x8 block (lane = the pixel at (lane & 7, lane >> 3) and the one
+ * 8 to its right), a workgroup of two waves a 32x8 tile.  Half as many waves walk the lists, cull
+ * candidates and fetch survivors as with one pixel per lane; only the per-pixel arithmetic is the
+ * same.  Leaves depth, the tagged reference of the visible fragment and the shade work lists. */
+__global__ void __launch_bounds__(128) rz_visibility_kernel(const PassParams *__restrict__ passes,
+        const BinEntry *__restrict__ list_base,
+        const float *__restrict__ vary_base, const float *__restrict__ fan_vary_base,
+        const char *__restrict__ upload_base, const uint2 *__restrict__ bin_range_base) {
+    const PassParams P = passes[blockIdx.z];
+    if ((int)blockIdx.x >= P.tiles_x || (int)blockIdx.y >= P.tiles_y) return;
+    if (P.debug_skip == 3) return;
+    const BinEntry *list_table = list_base + P.list_off;
+    const float *vary_table = vary_base + (size_t)P.tri_off * 3 * RZ_VARY_STRIDE;
+    const float *fan_vary_table = fan_vary_base + (size_t)P.fan_off * RZ_MAX_POLY * RZ_VARY_STRIDE;
+    const DrawRec *draw_table = (const DrawRec*)(upload_base + P.draws_off);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int tx0 = (int)blockIdx.x * RZ_TILE_W, ty0 = (int)blockIdx.y * RZ_TILE_H;
+    const int bx0 = tx0 + wave * 16, by0 = ty0, bx1 = bx0 + 15, by1 = by0 + 7;
+    const int py = by0 + (lane >> 3);
+    int px[2];
+    bool valid[2];
+    uint32_t pixel[2];
+    for (int q = 0; q < 2; q++) {
+        px[q] = bx0 + 8 * q + (lane & 7);
+        valid[q] = px[q] < P.width && py < P.height;
+        pixel[q] = (uint32_t)py * (uint32_t)P.width + (uint32_t)px[q];
+    }
+    const int bin = (ty0 / RZ_BIN) * P.bins_x + tx0 / RZ_BIN;
+    const uint2 range = (bin_range_base + P.bin_off)[bin];          /* {first entry, entries} */
+    const uint32_t count = range.y;
+    if (count == 0 && !P.clear_color_pending && !P.clear_depth_pending) {   /* uniform over the workgroup */
+        for (int q = 0; q < 2; q++) if (valid[q]) P.ref[pixel[q]] = RZ_REF_NONE;
+        return;
+    }
+    float zcur[2];
+    uint32_t ref_of[2] = {RZ_REF_NONE, RZ_REF_NONE};               /* tagged with the family; NONE = no fragment */
+    for (int q = 0; q < 2; q++) {
+        zcur[q] = P.clear_depth;
+        if (valid[q] && !P.clear_depth_pending) zcur[q] = P.depth[pixel[q]];
+    }
+    const BinEntry *list = list_table + range.x;
+
+    /* this lane's candidate of the NEXT group of 64 entries, loaded one group ahead */
+    float4 n0 = make_float4(0, 0, 0, 0), n1 = n0;
+    float2 nbox = make_float2(0, 0);
+    if ((uint32_t)lane < count) {
+        const float4 *e = (const float4*)&list[lane];              /* reference + record, 80 bytes */
+        n0 = e[1]; n1 = e[2]; nbox = *(const float2*)((const char*)e + 72);
+    }
+    /* block corners at pixel centres, for the conservative triangle/block test */
+    const float cx0 = (float)bx0 + 0.5f, cx1 = (float)bx0 + 15.5f, cy0 = (float)by0 + 0.5f, cy1 = (float)by0 + 7.5f;
+
+    for (uint32_t base = 0; base < count && P.debug_skip != 4;) {
+        const float4 c0 = n0, c1 = n1;
+        const float2 cbox = nbox;
+        const bool present = base + lane < count;
+        const BinEntry *group = list + base;
+        base += 64u;
+        if (base + lane < count) {
+            const float4 *e = (const float4*)&list[base + lane];
+            n0 = e[1]; n1 = e[2]; nbox = *(const float2*)((const char*)e + 72);
+        }
+        bool hit = false;
+        if (present) {
+            hit = box_overlaps(make_uint2(__float_as_uint(cbox.x), __float_as_uint(cbox.y)), bx0, by0, bx1, by1);
+            if (hit) hit = !block_outside(c0, c1, cx0, cx1, cy0, cy1);
+        }
+        unsigned long long todo = __ballot(hit);
+        while (todo) {
+            /* the wave-uniform entry index makes these scalar loads */
+            const BinEntry *e = &group[__ffsll((long long)todo) - 1];
+            todo &= todo - 1;
+            const uint32_t ref = e->tri;
+            const TriRec r = e->rec;
+            if (P.debug_skip >= 2) continue;
+            const int x0 = (int)(r.bx & 0xffffu), x1 = (int)(r.bx >> 16);
+            const int y0 = (int)(r.by & 0xffffu), y1 = (int)(r.by >> 16);
+            const bool row_in = py >= y0 && py <= y1;
+            float w[2][3], depth[2];
+            bool pass[2];
+            for (int q = 0; q < 2; q++) {
+                pixel_weights(r, px[q], py, w[q][0], w[q][1], w[q][2]);
+                const bool inside = valid[q] && row_in && px[q] >= x0 && px[q] <= x1 &&
+                                    w[q][0] > -RZ_EPS && w[q][1] > -RZ_EPS && w[q][2] > -RZ_EPS;     /* :516-519 */
+                depth[q] = r.z[0] * w[q][0] + r.z[1] * w[q][1] + r.z[2] * w[q][2];              /* :403-408 */
+                pass[q] = inside && depth[q] <= zcur[q];                                          /* :523 */
+            }
+            if (!__any(pass[0] || pass[1])) continue;
+            if (P.counters) {       /* fragments the reference would shade: [2] all, [6] skybox */
+                unsigned long long n = (unsigned long long)(__popcll(__ballot(pass[0])) + __popcll(__ballot(pass[1])));
+                if (lane == 0) {
+                    atomicAdd(P.counters + 2, n);
+                    if (RZ_META_FAMILY(r.meta) == 2) atomicAdd(P.counters + 6, n);
+                }
+            }
+            if (RZ_META_CUTOFF(r.meta)) {
+                /* the shaders' discard test (blinn_shader.c:104-113, 220; pbr_shader.c:116-134, 452):
+                 * alpha = base alpha * first map's alpha, from the interpolated texcoord */
+                const DrawRec &D = draw_table[RZ_META_DRAW(r.meta)];
+                const int tc = D.family == 0 ? 6 : 19;
+                const float *v0, *v1, *v2;
+                ref_varyings(ref, vary_table, fan_vary_table, v0, v1, v2);
+                for (int q = 0; q < 2; q++) {
+                    float q0 = r.rw[0] * w[q][0], q1 = r.rw[1] * w[q][1], q2 = r.rw[2] * w[q][2];
+                    float norm = 1 / (q0 + q1 + q2);
+                    float tu = (v0[tc] * q0 + v1[tc] * q1 + v2[tc] * q2) * norm;
+                    float tv = (v0[tc + 1] * q0 + v1[tc + 1] * q1 + v2[tc + 1] * q2) * norm;
+                    if (pass[q]) {
+                        float a = D.base[3];
+                        if (D.maps[0].data) a *= sample_repeat(D.maps[0], tu, tv).w;
+                        if (a < D.alpha_cutoff) pass[q] = false;
+                    }
+                }
+            }
+            const uint32_t tagged = ref | (RZ_META_FAMILY(r.meta) << 28);
+            for (int q = 0; q < 2; q++) if (pass[q]) { zcur[q] = depth[q]; ref_of[q] = tagged; }
+        }
+    }
+
+    if (P.debug_skip == 8 || P.debug_skip == 10) return;
+    for (int q = 0; q < 2; q++) {
+        if (!valid[q]) continue;
+        P.depth[pixel[q]] = zcur[q];
+        P.ref[pixel[q]] = ref_of[q];
+        /* the shade kernels write the colour of every pixel that has a fragment */
+        if (P.clear_color_pending && ref_of[q] == RZ_REF_NONE) P.color[pixel[q]] = P.clear_color;
+    }
+    /* Blinn and pbr fragments usually cover a small part of the screen: every tile that holds some
+     * goes on that family's work list (all passes of the batch together), and the shade kernel of
+     * the family walks the list.  The first wave of a tile to find such a fragment appends the tile
+     * (tile_listed keeps who was first); waves without any pay nothing.  A list is kept in
+     * RZ_QUEUE_WAYS parts, chosen by the tile's index, with counters a cache line apart, so that the
+     * appends of a whole batch do not pile up on one counter.  Skybox fragments are found by
+     * scanning the tiles. */
+    for (uint32_t f = 0; f < 2; f++) {
+        if (!__any(((ref_of[0] >> 28) & 3u) == f || ((ref_of[1] >> 28) & 3u) == f)) continue;
+        if (lane == 0) {
+            const uint32_t tile = blockIdx.y * (uint32_t)P.tiles_x + blockIdx.x;
+            const uint32_t before = atomicOr(&P.tile_listed[tile], 1u << f);
+            if (!(before >> f & 1u)) {
+                /* by the tile's index in the batch: no part can get more than its even share */
+                const uint32_t part = f * RZ_QUEUE_WAYS + ((P.tile_off + tile) & (RZ_QUEUE_WAYS - 1u));
+                const uint32_t at = atomicAdd(&P.queue_counts[part * RZ_QUEUE_PAD], 1u);
+                if (at < P.queue_capacity)
+                    P.queue[(size_t)part * P.queue_capacity + at] = ((uint32_t)blockIdx.z << 20) | ((uint32_t)blockIdx.y << 9) | (uint32_t)blockIdx.x;
+                else
+                    atomicOr(&P.control[2], (uint32_t)RZ_ERR_QUEUE_OVERFLOW);
+            }
+        }
+    }
+}
+
 /* K5  per-family fragment kernels for passes rasterised with SPLIT = true:
  * every lane shades the one fragment its pixel refers to. */
 template <int FAMILY>
