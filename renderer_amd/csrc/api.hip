@@ -134,6 +134,7 @@ struct Context {
     size_t max_batch = 16;                  /* passes per launch sequence */
     bool pack_textures = true;              /* MI355R_PACK=0: keep every image as float4 */
     bool narrow_raster = false;             /* MI355R_NARROW_RASTER=1: one pixel per lane in the visibility pass */
+    int pixels_per_lane = 2;                /* MI355R_PPL=4: a wave takes the whole 32x8 tile */
     int shade_workgroups = 4096;            /* 256-thread workgroups per shade launch (compute units x 16) */
     std::vector<hipEvent_t> events;     /* recorded since the last full sync */
     std::vector<Tex*> current_gpu_textures;
@@ -224,6 +225,8 @@ extern "C" int mi355r_init(int device) {
         if (g.num_lanes > MAX_LANES) g.num_lanes = MAX_LANES;
         env = getenv("MI355R_NARROW_RASTER");
         if (env) g.narrow_raster = atoi(env) != 0;
+        env = getenv("MI355R_PPL");
+        if (env) g.pixels_per_lane = atoi(env);
         env = getenv("MI355R_PACK");
         if (env) g.pack_textures = atoi(env) != 0;
         env = getenv("MI355R_BATCH");
@@ -1241,8 +1244,10 @@ static void launch_batch(const Batch &b, const std::vector<PassPlan> &plans, cha
         if (g.narrow_raster)
             rz_raster_kernel<true><<<tiles, dim3(256), 0, st>>>(
                 passes, L.tri.ptr, L.fan_tri.ptr, L.bin_list.ptr, L.vary.ptr, L.fan_vary.ptr, db, L.bin_range.ptr);
+        else if (g.pixels_per_lane == 4)
+            rz_visibility_kernel<4><<<tiles, dim3(64), 0, st>>>(passes, L.bin_list.ptr, L.vary.ptr, L.fan_vary.ptr, db, L.bin_range.ptr);
         else
-            rz_visibility_kernel<<<tiles, dim3(128), 0, st>>>(passes, L.bin_list.ptr, L.vary.ptr, L.fan_vary.ptr, db, L.bin_range.ptr);
+            rz_visibility_kernel<2><<<tiles, dim3(128), 0, st>>>(passes, L.bin_list.ptr, L.vary.ptr, L.fan_vary.ptr, db, L.bin_range.ptr);
         stamp();
         if (b.families & (1 << RZ_FAMILY_SKYBOX))
             rz_shade_kernel<2><<<tiles, dim3(256), 0, st>>>(passes, L.tri.ptr, L.fan_tri.ptr, L.vary.ptr, L.fan_vary.ptr, db, L.ref.ptr);

@@ -1021,11 +1021,12 @@ __global__ void __launch_bounds__(256) rz_raster_kernel(const PassParams *__rest
 }
 
 /* K4b  visibility only, for passes without blending (what rz_raster_kernel<true> computes), two
- * pixels per lane: a wave owns a 16x8 block (lane = the pixel at (lane & 7, lane >> 3) and the one
- * 8 to its right), a workgroup of two waves a 32x8 tile.  Half as many waves walk the lists, cull
- * candidates and fetch survivors as with one pixel per lane; only the per-pixel arithmetic is the
- * same.  Leaves depth, the tagged reference of the visible fragment and the shade work lists. */
-__global__ void __launch_bounds__(128) rz_visibility_kernel(const PassParams *__restrict__ passes,
+ * (PPL = 2) or four pixels per lane: a wave owns a block of 8*PPL x 8 pixels (lane = the pixel at
+ * (lane & 7, lane >> 3) and those 8, 16, .. to its right), a workgroup of 4/PPL waves a 32x8 tile.
+ * A fraction 1/PPL of the waves walk the lists, cull candidates and fetch survivors compared with
+ * one pixel per lane; only the per-pixel arithmetic is the same.  Leaves depth, the tagged reference of the visible fragment and the shade work lists. */
+template <int PPL>
+__global__ void __launch_bounds__(256 / PPL) rz_visibility_kernel(const PassParams *__restrict__ passes,
         const BinEntry *__restrict__ list_base,
         const float *__restrict__ vary_base, const float *__restrict__ fan_vary_base,
         const char *__restrict__ upload_base, const uint2 *__restrict__ bin_range_base) {
@@ -1038,12 +1039,12 @@ __global__ void __launch_bounds__(128) rz_visibility_kernel(const PassParams *__
     const DrawRec *draw_table = (const DrawRec*)(upload_base + P.draws_off);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int tx0 = (int)blockIdx.x * RZ_TILE_W, ty0 = (int)blockIdx.y * RZ_TILE_H;
-    const int bx0 = tx0 + wave * 16, by0 = ty0, bx1 = bx0 + 15, by1 = by0 + 7;
+    const int bx0 = tx0 + wave * 8 * PPL, by0 = ty0, bx1 = bx0 + 8 * PPL - 1, by1 = by0 + 7;
     const int py = by0 + (lane >> 3);
-    int px[2];
-    bool valid[2];
-    uint32_t pixel[2];
-    for (int q = 0; q < 2; q++) {
+    int px[PPL];
+    bool valid[PPL];
+    uint32_t pixel[PPL];
+    for (int q = 0; q < PPL; q++) {
         px[q] = bx0 + 8 * q + (lane & 7);
         valid[q] = px[q] < P.width && py < P.height;
         pixel[q] = (uint32_t)py * (uint32_t)P.width + (uint32_t)px[q];
@@ -1052,12 +1053,13 @@ __global__ void __launch_bounds__(128) rz_visibility_kernel(const PassParams *__
     const uint2 range = (bin_range_base + P.bin_off)[bin];          /* {first entry, entries} */
     const uint32_t count = range.y;
     if (count == 0 && !P.clear_color_pending && !P.clear_depth_pending) {   /* uniform over the workgroup */
-        for (int q = 0; q < 2; q++) if (valid[q]) P.ref[pixel[q]] = RZ_REF_NONE;
+        for (int q = 0; q < PPL; q++) if (valid[q]) P.ref[pixel[q]] = RZ_REF_NONE;
         return;
     }
-    float zcur[2];
-    uint32_t ref_of[2] = {RZ_REF_NONE, RZ_REF_NONE};               /* tagged with the family; NONE = no fragment */
-    for (int q = 0; q < 2; q++) {
+    float zcur[PPL];
+    uint32_t ref_of[PPL];                                           /* tagged with the family; NONE = no fragment */
+    for (int q = 0; q < PPL; q++) {
+        ref_of[q] = RZ_REF_NONE;
         zcur[q] = P.clear_depth;
         if (valid[q] && !P.clear_depth_pending) zcur[q] = P.depth[pixel[q]];
     }
@@ -1071,7 +1073,7 @@ __global__ void __launch_bounds__(128) rz_visibility_kernel(const PassParams *__
         n0 = e[1]; n1 = e[2]; nbox = *(const float2*)((const char*)e + 72);
     }
     /* block corners at pixel centres, for the conservative triangle/block test */
-    const float cx0 = (float)bx0 + 0.5f, cx1 = (float)bx0 + 15.5f, cy0 = (float)by0 + 0.5f, cy1 = (float)by0 + 7.5f;
+    const float cx0 = (float)bx0 + 0.5f, cx1 = (float)bx1 + 0.5f, cy0 = (float)by0 + 0.5f, cy1 = (float)by0 + 7.5f;
 
     for (uint32_t base = 0; base < count && P.debug_skip != 4;) {
         const float4 c0 = n0, c1 = n1;
@@ -1099,18 +1101,21 @@ __global__ void __launch_bounds__(128) rz_visibility_kernel(const PassParams *__
             const int x0 = (int)(r.bx & 0xffffu), x1 = (int)(r.bx >> 16);
             const int y0 = (int)(r.by & 0xffffu), y1 = (int)(r.by >> 16);
             const bool row_in = py >= y0 && py <= y1;
-            float w[2][3], depth[2];
-            bool pass[2];
-            for (int q = 0; q < 2; q++) {
+            float w[PPL][3], depth[PPL];
+            bool pass[PPL];
+            for (int q = 0; q < PPL; q++) {
                 pixel_weights(r, px[q], py, w[q][0], w[q][1], w[q][2]);
                 const bool inside = valid[q] && row_in && px[q] >= x0 && px[q] <= x1 &&
                                     w[q][0] > -RZ_EPS && w[q][1] > -RZ_EPS && w[q][2] > -RZ_EPS;     /* :516-519 */
                 depth[q] = r.z[0] * w[q][0] + r.z[1] * w[q][1] + r.z[2] * w[q][2];              /* :403-408 */
                 pass[q] = inside && depth[q] <= zcur[q];                                          /* :523 */
             }
-            if (!__any(pass[0] || pass[1])) continue;
+            bool any_pass = false;
+            for (int q = 0; q < PPL; q++) any_pass |= pass[q];
+            if (!__any(any_pass)) continue;
             if (P.counters) {       /* fragments the reference would shade: [2] all, [6] skybox */
-                unsigned long long n = (unsigned long long)(__popcll(__ballot(pass[0])) + __popcll(__ballot(pass[1])));
+                unsigned long long n = 0;
+                for (int q = 0; q < PPL; q++) n += (unsigned long long)__popcll(__ballot(pass[q]));
                 if (lane == 0) {
                     atomicAdd(P.counters + 2, n);
                     if (RZ_META_FAMILY(r.meta) == 2) atomicAdd(P.counters + 6, n);
@@ -1123,7 +1128,7 @@ __global__ void __launch_bounds__(128) rz_visibility_kernel(const PassParams *__
                 const int tc = D.family == 0 ? 6 : 19;
                 const float *v0, *v1, *v2;
                 ref_varyings(ref, vary_table, fan_vary_table, v0, v1, v2);
-                for (int q = 0; q < 2; q++) {
+                for (int q = 0; q < PPL; q++) {
                     float q0 = r.rw[0] * w[q][0], q1 = r.rw[1] * w[q][1], q2 = r.rw[2] * w[q][2];
                     float norm = 1 / (q0 + q1 + q2);
                     float tu = (v0[tc] * q0 + v1[tc] * q1 + v2[tc] * q2) * norm;
@@ -1136,12 +1141,12 @@ __global__ void __launch_bounds__(128) rz_visibility_kernel(const PassParams *__
                 }
             }
             const uint32_t tagged = ref | (RZ_META_FAMILY(r.meta) << 28);
-            for (int q = 0; q < 2; q++) if (pass[q]) { zcur[q] = depth[q]; ref_of[q] = tagged; }
+            for (int q = 0; q < PPL; q++) if (pass[q]) { zcur[q] = depth[q]; ref_of[q] = tagged; }
         }
     }
 
     if (P.debug_skip == 8 || P.debug_skip == 10) return;
-    for (int q = 0; q < 2; q++) {
+    for (int q = 0; q < PPL; q++) {
         if (!valid[q]) continue;
         P.depth[pixel[q]] = zcur[q];
         P.ref[pixel[q]] = ref_of[q];
@@ -1156,7 +1161,9 @@ __global__ void __launch_bounds__(128) rz_visibility_kernel(const PassParams *__
      * appends of a whole batch do not pile up on one counter.  Skybox fragments are found by
      * scanning the tiles. */
     for (uint32_t f = 0; f < 2; f++) {
-        if (!__any(((ref_of[0] >> 28) & 3u) == f || ((ref_of[1] >> 28) & 3u) == f)) continue;
+        bool mine = false;
+        for (int q = 0; q < PPL; q++) mine |= ((ref_of[q] >> 28) & 3u) == f;
+        if (!__any(mine)) continue;
         if (lane == 0) {
             const uint32_t tile = blockIdx.y * (uint32_t)P.tiles_x + blockIdx.x;
             const uint32_t before = atomicOr(&P.tile_listed[tile], 1u << f);
