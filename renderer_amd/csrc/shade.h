@@ -197,21 +197,46 @@ __device__ float4 rz_zero_texel;        /* what an absent map reads */
 
 #define RZ_TEX_NARROW (RZ_TEX_R32F | RZ_TEX_UNORM8 | RZ_TEX_SRGB8 | RZ_TEX_RGBE8)
 
-RZ_DEV Texel load_texel(const DevTex &t, float u, float v) {
-    const bool present = t.data != nullptr;
-    const int w = present ? t.w : 1, h = present ? t.h : 1, flags = present ? t.flags : 0;
-    const char *base = present ? (const char*)t.data : (const char*)&rz_zero_texel;
-    int c = (int)((float)(w - 1) * u);                  /* texture.c:160-176 */
+/* where a coordinate pair lands in an image of a given size and layout (texture.c:160-176) */
+RZ_DEV uint32_t texel_cell(int w, int h, int flags, float u, float v) {
+    int c = (int)((float)(w - 1) * u);
     int r = (int)((float)(h - 1) * v);
     c = c < 0 ? 0 : (c > w - 1 ? w - 1 : c);            /* never taken for finite coordinates */
     r = r < 0 ? 0 : (r > h - 1 ? h - 1 : r);
-    const uint32_t i = texel_index(w, flags, c, r);
+    return texel_index(w, flags, c, r);
+}
+
+RZ_DEV Texel load_cell(const void *data, int flags, uint32_t i) {
+    const char *base = data ? (const char*)data : (const char*)&rz_zero_texel;
     const size_t offset = (flags & RZ_TEX_NARROW) ? (((size_t)i << 2) & ~(size_t)15) : ((size_t)i << 4);
     Texel x;
     x.q = *(const float4*)(base + offset);
     x.sel = i & 3u;
     return x;
 }
+
+RZ_DEV Texel load_texel(const DevTex &t, float u, float v) {
+    const bool present = t.data != nullptr;
+    const int w = present ? t.w : 1, h = present ? t.h : 1, flags = present ? t.flags : 0;
+    return load_cell(t.data, flags, texel_cell(w, h, flags, u, v));
+}
+
+/* A material's maps usually share one size and layout, and all are sampled at the same
+ * coordinates: then the texel's place is worked out once (the comparison is wave-uniform). */
+struct MapCell { int w, h, tiled; uint32_t index; float u, v; };
+RZ_DEV MapCell first_cell(const DevTex &t, float x, float y) {
+    MapCell m;
+    m.u = x - floorf(x); m.v = y - floorf(y);                   /* repeat addressing, texture.c:160-167 */
+    m.w = t.data ? t.w : 1; m.h = t.data ? t.h : 1; m.tiled = t.data ? (t.flags & RZ_TEX_TILED) : 0;
+    m.index = texel_cell(m.w, m.h, m.tiled, m.u, m.v);
+    return m;
+}
+RZ_DEV Texel load_like(const DevTex &t, const MapCell &m) {
+    if (!t.data) return load_cell(nullptr, 0, 0u);
+    if (t.w == m.w && t.h == m.h && (t.flags & RZ_TEX_TILED) == m.tiled) return load_cell(t.data, t.flags, m.index);
+    return load_cell(t.data, t.flags, texel_cell(t.w, t.h, t.flags, m.u, m.v));
+}
+
 RZ_DEV Texel load_repeat(const DevTex &t, float x, float y) { return load_texel(t, x - floorf(x), y - floorf(y)); }
 RZ_DEV Texel load_clamp(const DevTex &t, float x, float y) { return load_texel(t, d_sat(x), d_sat(y)); }
 
@@ -294,7 +319,8 @@ RZ_DEV f4 fs_blinn(const DrawRec &D, const float *v, bool backface, bool *discar
         return mk4(0, 0, 0, 0);
     }
     /* every texel this fragment can need, in flight together */
-    const Texel t0 = load_repeat(D.maps[0], tu, tv), t1 = load_repeat(D.maps[1], tu, tv), t2 = load_repeat(D.maps[2], tu, tv);
+    const MapCell cell = first_cell(D.maps[0], tu, tv);
+    const Texel t0 = load_like(D.maps[0], cell), t1 = load_like(D.maps[1], cell), t2 = load_like(D.maps[2], cell);
     const Texel tshadow = load_shadow(D, mk3(v[3], v[4], v[5]));
     /* material (:126-169) */
     f3 diffuse = mk3(D.base[0], D.base[1], D.base[2]);
@@ -354,8 +380,9 @@ RZ_DEV Surface pbr_surface(const DrawRec &D, const float *v, bool backface) {
     Surface s;
     float tu = v[19], tv = v[20];
     /* the six material texels in flight together */
-    const Texel t0 = load_repeat(D.maps[0], tu, tv), t1 = load_repeat(D.maps[1], tu, tv), t2 = load_repeat(D.maps[2], tu, tv);
-    const Texel t3 = load_repeat(D.maps[3], tu, tv), t4 = load_repeat(D.maps[4], tu, tv), t5 = load_repeat(D.maps[5], tu, tv);
+    const MapCell cell = first_cell(D.maps[0].data ? D.maps[0] : D.maps[3], tu, tv);
+    const Texel t0 = load_like(D.maps[0], cell), t1 = load_like(D.maps[1], cell), t2 = load_like(D.maps[2], cell);
+    const Texel t3 = load_like(D.maps[3], cell), t4 = load_like(D.maps[4], cell), t5 = load_like(D.maps[5], cell);
     if (D.workflow == 0) {                                      /* metal-rough, :148-182 */
         f3 base = mk3(D.base[0], D.base[1], D.base[2]);
         float metal = D.metalness, rough = D.roughness;
