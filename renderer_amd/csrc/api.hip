@@ -121,6 +121,7 @@ struct Lane {
     DevBuf<BinEntry> bin_list;
 };
 
+static const int RZ_TEX_NARROW_FORMATS = RZ_TEX_R32F | RZ_TEX_UNORM8 | RZ_TEX_SRGB8 | RZ_TEX_RGBE8;
 static const size_t MAX_BATCH = 64;     /* passes per launch sequence, upper bound */
 static const int MAX_LANES = 8;
 
@@ -151,6 +152,7 @@ struct Context {
     std::unordered_map<const void*, Mesh> meshes;
     std::unordered_map<const void*, DevTex*> cubes;     /* rz_cubemap* -> DevTex[6] */
     std::unordered_map<const void*, DevIbl*> ibls;      /* rz_ibldata* -> DevIbl */
+    std::unordered_map<const void*, bool> ibl_narrow;   /* ... and whether all its images have 4-byte formats */
     struct Registered { void *vs, *fs; int family; };
     std::vector<Registered> families;
     /* measurement */
@@ -686,6 +688,11 @@ static const DevIbl *dev_ibl(rz_ibldata *ibl) {
     for (int f = 0; f < 6; f++) h->diffuse[f] = dev_tex(ibl->diffuse_map->faces[f]);
     for (int l = 0; l < ibl->mip_levels; l++)
         for (int f = 0; f < 6; f++) h->specular[l][f] = dev_tex(ibl->specular_maps[l]->faces[f]);
+    bool narrow = (h->lut.flags & RZ_TEX_NARROW_FORMATS) != 0;
+    for (int f = 0; f < 6; f++) narrow = narrow && (h->diffuse[f].flags & RZ_TEX_NARROW_FORMATS);
+    for (int l = 0; l < ibl->mip_levels; l++)
+        for (int f = 0; f < 6; f++) narrow = narrow && (h->specular[l][f].flags & RZ_TEX_NARROW_FORMATS);
+    g.ibl_narrow[ibl] = narrow;
     DevIbl *d;
     HIP_OK(hipMalloc((void**)&d, sizeof(DevIbl)));
     HIP_OK(hipMemcpy(d, h, sizeof(DevIbl), hipMemcpyHostToDevice));
@@ -701,6 +708,7 @@ static void drop_derived_handles() {
     for (auto &kv : g.ibls) HIP_OK(hipFree(kv.second));
     g.cubes.clear();
     g.ibls.clear();
+    g.ibl_narrow.clear();
 }
 
 /* ---------------------------------------------------------------- programs -- */
@@ -891,6 +899,12 @@ static void snapshot_uniforms(rz_program *p, Pending &pd, int num_joints) {
         r.layer_view = u->layer_view;
         if (u->shadow_pass) r.flags |= RZ_DRAW_SHADOW_PASS;
     }
+    if (p->family != RZ_FAMILY_SKYBOX) {
+        bool narrow = !r.shadow_map.data || (r.shadow_map.flags & RZ_TEX_NARROW_FORMATS);
+        for (int i = 0; i < 6; i++) narrow = narrow && (!r.maps[i].data || (r.maps[i].flags & RZ_TEX_NARROW_FORMATS));
+        if (r.ibl) narrow = narrow && g.ibl_narrow[((const rz_pbr_uniforms*)p->uniforms)->ibldata];
+        if (narrow) r.flags |= RZ_DRAW_NARROW_TEXELS;
+    }
     pd.gpu_textures = g.current_gpu_textures;
     /* joint matrices are rewritten in place by the skeleton every frame
      * (skeleton.c:336-337): copy them now */
@@ -996,6 +1010,7 @@ struct PassPlan {
     size_t off_draws, off_first;    /* offsets from the region start */
     std::vector<size_t> side_at, verts_at;
     bool has_blend, samples_gpu_texture;
+    bool narrow_texels;             /* every blinn / pbr draw samples 4-byte images only */
     int families;
     Fb *fb;
 };
@@ -1006,6 +1021,7 @@ static void plan_pass(PassPlan &pl, size_t &total) {
     const size_t D = pl.last - pl.first;
     pl.T = 0;
     pl.has_blend = pl.samples_gpu_texture = false;
+    pl.narrow_texels = true;
     pl.families = 0;
     pl.fb = g.pending[pl.first].fb;
     for (size_t i = pl.first; i < pl.last; i++) {
@@ -1014,6 +1030,7 @@ static void plan_pass(PassPlan &pl, size_t &total) {
         pl.has_blend |= (pd.rec.flags & RZ_DRAW_BLEND) != 0;
         pl.samples_gpu_texture |= !pd.gpu_textures.empty();
         pl.families |= 1 << pd.rec.family;
+        if (pd.rec.family != RZ_FAMILY_SKYBOX && !(pd.rec.flags & RZ_DRAW_NARROW_TEXELS)) pl.narrow_texels = false;
     }
     if (getenv("MI355R_MONOLITHIC")) pl.has_blend = true;
     if (D > 65535) fatal("%zu draws in one pass (limit 65535)", D);
@@ -1252,13 +1269,19 @@ static void launch_batch(const Batch &b, const std::vector<PassPlan> &plans, cha
         if (b.families & (1 << RZ_FAMILY_SKYBOX))
             rz_shade_kernel<2><<<tiles, dim3(256), 0, st>>>(passes, L.tri.ptr, L.fan_tri.ptr, L.vary.ptr, L.fan_vary.ptr, db, L.ref.ptr);
         stamp();
-        if (b.families & (1 << RZ_FAMILY_BLINN))
-            rz_shade_list_kernel<0><<<shade_grid, dim3(256), 0, st>>>(passes, L.tri.ptr, L.fan_tri.ptr, L.vary.ptr, L.fan_vary.ptr, db, L.ref.ptr,
-                                                                      L.queue.ptr, L.queue_counts.ptr, queue_capacity);
+        bool narrow = true;
+        for (size_t i : b.members) narrow = narrow && plans[i].narrow_texels;
+        if (b.families & (1 << RZ_FAMILY_BLINN)) {
+            auto kernel = narrow ? rz_shade_list_kernel<0, true> : rz_shade_list_kernel<0, false>;
+            kernel<<<shade_grid, dim3(256), 0, st>>>(passes, L.tri.ptr, L.fan_tri.ptr, L.vary.ptr, L.fan_vary.ptr, db, L.ref.ptr,
+                                                     L.queue.ptr, L.queue_counts.ptr, queue_capacity);
+        }
         stamp();
-        if (b.families & (1 << RZ_FAMILY_PBR))
-            rz_shade_list_kernel<1><<<shade_grid, dim3(256), 0, st>>>(passes, L.tri.ptr, L.fan_tri.ptr, L.vary.ptr, L.fan_vary.ptr, db, L.ref.ptr,
-                                                                      L.queue.ptr, L.queue_counts.ptr, queue_capacity);
+        if (b.families & (1 << RZ_FAMILY_PBR)) {
+            auto kernel = narrow ? rz_shade_list_kernel<1, true> : rz_shade_list_kernel<1, false>;
+            kernel<<<shade_grid, dim3(256), 0, st>>>(passes, L.tri.ptr, L.fan_tri.ptr, L.vary.ptr, L.fan_vary.ptr, db, L.ref.ptr,
+                                                     L.queue.ptr, L.queue_counts.ptr, queue_capacity);
+        }
         stamp();
     }
     HIP_OK(hipGetLastError());

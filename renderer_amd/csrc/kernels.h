@@ -710,7 +710,7 @@ RZ_DEV void pixel_weights(const TriRec &r, int px, int py, float &w0, float &w1,
  * draw are shaded together under that draw's (wave-uniform) record.
  * FAMILY >= 0 compiles only that family's shader (per-family kernels),
  * FAMILY < 0 all three. */
-template <int FAMILY>
+template <int FAMILY, bool NARROW = false>
 RZ_DEV void shade_lanes(const PassParams &P, const DrawRec *__restrict__ draw_table, bool want,
                         const TriRec &m, const float *m0, const float *m1, const float *m2,
                         int px, int py, uint32_t &ccur) {
@@ -738,11 +738,11 @@ RZ_DEV void shade_lanes(const PassParams &P, const DrawRec *__restrict__ draw_ta
             } else if ((FAMILY < 0 || FAMILY == 0) && D.family == 0) {
                 float v[12];
                 interpolate_lane<11>(m0, m1, m2, q0, q1, q2, norm, v);
-                color = fs_blinn(D, v, backface, &discard);
+                color = fs_blinn<NARROW>(D, v, backface, &discard);
             } else if ((FAMILY < 0 || FAMILY == 1) && D.family == 1) {
                 float v[24];
                 interpolate_lane<21>(m0, m1, m2, q0, q1, q2, norm, v);
-                color = fs_pbr(D, v, backface, &discard);
+                color = fs_pbr<NARROW>(D, v, backface, &discard);
             }
             /* draw_fragment (graphics.c:452-468); a discard was settled during rasterisation */
             color = mk4(d_sat(color.x), d_sat(color.y), d_sat(color.z), d_sat(color.w));
@@ -1182,7 +1182,7 @@ __global__ void __launch_bounds__(256 / PPL) rz_visibility_kernel(const PassPara
 
 /* K5  per-family fragment kernels for passes rasterised with SPLIT = true:
  * every lane shades the one fragment its pixel refers to. */
-template <int FAMILY>
+template <int FAMILY, bool NARROW = false>
 RZ_DEV void shade_pixel(const PassParams &P, const TriRec *__restrict__ tri_base, const TriRec *__restrict__ fan_base,
                         const float *__restrict__ vary_base, const float *__restrict__ fan_vary_base,
                         const char *__restrict__ upload_base, const uint32_t *__restrict__ ref_base,
@@ -1218,7 +1218,7 @@ RZ_DEV void shade_pixel(const PassParams &P, const TriRec *__restrict__ tri_base
         }
     }
     if (want) fetch_ref(myref, tri_table, fan_table, vary_table, fan_vary_table, m, m0, m1, m2);
-    shade_lanes<FAMILY>(P, draw_table, want, m, m0, m1, m2, px, py, ccur);
+    shade_lanes<FAMILY, NARROW>(P, draw_table, want, m, m0, m1, m2, px, py, ccur);
     if (want) P.color[pixel] = ccur;
 }
 
@@ -1239,7 +1239,7 @@ __global__ void __launch_bounds__(256) rz_shade_kernel(const PassParams *__restr
 
 /* over the family's work list of tiles: a fixed number of workgroups strides over it, so no wave
  * is spent on a tile without work */
-template <int FAMILY>
+template <int FAMILY, bool NARROW>
 __global__ void __launch_bounds__(256) rz_shade_list_kernel(const PassParams *__restrict__ passes,
         const TriRec *__restrict__ tri_base, const TriRec *__restrict__ fan_base,
         const float *__restrict__ vary_base, const float *__restrict__ fan_vary_base,
@@ -1256,8 +1256,8 @@ __global__ void __launch_bounds__(256) rz_shade_list_kernel(const PassParams *__
         if (index >= (uint32_t)__builtin_amdgcn_readlane((int)my_count, (int)part)) continue;
         const uint32_t item = queue_base[(size_t)(FAMILY * RZ_QUEUE_WAYS + part) * queue_capacity + index];
         const PassParams P = passes[item >> 20];
-        shade_pixel<FAMILY>(P, tri_base, fan_base, vary_base, fan_vary_base, upload_base, ref_base,
-                            (int)(item & 511u) * RZ_TILE_W + (lane & 31), (int)((item >> 9) & 2047u) * RZ_TILE_H + wave * 2 + (lane >> 5));
+        shade_pixel<FAMILY, NARROW>(P, tri_base, fan_base, vary_base, fan_vary_base, upload_base, ref_base,
+                                    (int)(item & 511u) * RZ_TILE_W + (lane & 31), (int)((item >> 9) & 2047u) * RZ_TILE_H + wave * 2 + (lane >> 5));
     }
 }
 

@@ -64,7 +64,8 @@ enum {
     RZ_DRAW_BLEND = 2,
     RZ_DRAW_SHADOW_PASS = 4,
     RZ_DRAW_SKINNED = 8,
-    RZ_DRAW_UNIFORM_CUBE = 16       /* skybox: the six faces have one size and format */
+    RZ_DRAW_UNIFORM_CUBE = 16,      /* skybox: the six faces have one size and format */
+    RZ_DRAW_NARROW_TEXELS = 32      /* blinn / pbr: every image the draw samples has a 4-byte format (or is absent) */
 };
 
 struct DrawRec {

@@ -191,7 +191,12 @@ __device__ float rz_srgb8_table[256];
  * (an absent map reads a dummy texel, a 4-byte format reads the aligned 16
  * bytes around its texel), decode_texel() turns the bits into the float RGBA
  * the reference's texture holds. */
-struct Texel { float4 q; uint32_t sel; };
+/* NARROW = the caller knows that every image it samples has a 4-byte format (or is absent): a
+ * pending texel is then one register instead of five and the load moves 4 bytes instead of 16. */
+template <bool NARROW> struct TexelT;
+template <> struct TexelT<false> { float4 q; uint32_t sel; };
+template <> struct TexelT<true> { uint32_t word; };
+typedef TexelT<false> Texel;
 
 __device__ float4 rz_zero_texel;        /* what an absent map reads */
 
@@ -206,19 +211,25 @@ RZ_DEV uint32_t texel_cell(int w, int h, int flags, float u, float v) {
     return texel_index(w, flags, c, r);
 }
 
-RZ_DEV Texel load_cell(const void *data, int flags, uint32_t i) {
+template <bool NARROW>
+RZ_DEV TexelT<NARROW> load_cell(const void *data, int flags, uint32_t i) {
     const char *base = data ? (const char*)data : (const char*)&rz_zero_texel;
-    const size_t offset = (flags & RZ_TEX_NARROW) ? (((size_t)i << 2) & ~(size_t)15) : ((size_t)i << 4);
-    Texel x;
-    x.q = *(const float4*)(base + offset);
-    x.sel = i & 3u;
+    TexelT<NARROW> x;
+    if constexpr (NARROW) {
+        x.word = *(const uint32_t*)(base + ((size_t)i << 2));
+    } else {
+        const size_t offset = (flags & RZ_TEX_NARROW) ? (((size_t)i << 2) & ~(size_t)15) : ((size_t)i << 4);
+        x.q = *(const float4*)(base + offset);
+        x.sel = i & 3u;
+    }
     return x;
 }
 
-RZ_DEV Texel load_texel(const DevTex &t, float u, float v) {
+template <bool NARROW>
+RZ_DEV TexelT<NARROW> load_texel(const DevTex &t, float u, float v) {
     const bool present = t.data != nullptr;
     const int w = present ? t.w : 1, h = present ? t.h : 1, flags = present ? t.flags : 0;
-    return load_cell(t.data, flags, texel_cell(w, h, flags, u, v));
+    return load_cell<NARROW>(t.data, flags, texel_cell(w, h, flags, u, v));
 }
 
 /* A material's maps usually share one size and layout, and all are sampled at the same
@@ -231,32 +242,42 @@ RZ_DEV MapCell first_cell(const DevTex &t, float x, float y) {
     m.index = texel_cell(m.w, m.h, m.tiled, m.u, m.v);
     return m;
 }
-RZ_DEV Texel load_like(const DevTex &t, const MapCell &m) {
-    if (!t.data) return load_cell(nullptr, 0, 0u);
-    if (t.w == m.w && t.h == m.h && (t.flags & RZ_TEX_TILED) == m.tiled) return load_cell(t.data, t.flags, m.index);
-    return load_cell(t.data, t.flags, texel_cell(t.w, t.h, t.flags, m.u, m.v));
+template <bool NARROW>
+RZ_DEV TexelT<NARROW> load_like(const DevTex &t, const MapCell &m) {
+    if (!t.data) return load_cell<NARROW>(nullptr, 0, 0u);
+    if (t.w == m.w && t.h == m.h && (t.flags & RZ_TEX_TILED) == m.tiled) return load_cell<NARROW>(t.data, t.flags, m.index);
+    return load_cell<NARROW>(t.data, t.flags, texel_cell(t.w, t.h, t.flags, m.u, m.v));
 }
 
-RZ_DEV Texel load_repeat(const DevTex &t, float x, float y) { return load_texel(t, x - floorf(x), y - floorf(y)); }
-RZ_DEV Texel load_clamp(const DevTex &t, float x, float y) { return load_texel(t, d_sat(x), d_sat(y)); }
+template <bool NARROW>
+RZ_DEV TexelT<NARROW> load_repeat(const DevTex &t, float x, float y) { return load_texel<NARROW>(t, x - floorf(x), y - floorf(y)); }
+template <bool NARROW>
+RZ_DEV TexelT<NARROW> load_clamp(const DevTex &t, float x, float y) { return load_texel<NARROW>(t, d_sat(x), d_sat(y)); }
 
-RZ_DEV f4 decode_texel(const DevTex &t, const Texel &x) {
-    if (t.flags & RZ_TEX_NARROW) {
-        const float word = x.sel == 0 ? x.q.x : (x.sel == 1 ? x.q.y : (x.sel == 2 ? x.q.z : x.q.w));
-        if (t.flags & RZ_TEX_R32F) return mk4(word, word, word, 1.0f);
-        const uint32_t p = __float_as_uint(word);
-        const uint32_t b0 = p & 0xffu, b1 = (p >> 8) & 0xffu, b2 = (p >> 16) & 0xffu, b3 = p >> 24;
-        if (t.flags & RZ_TEX_UNORM8) return mk4(d_unorm8(b0), d_unorm8(b1), d_unorm8(b2), d_unorm8(b3));
-        if (t.flags & RZ_TEX_SRGB8) return mk4(rz_srgb8_table[b0], rz_srgb8_table[b1], rz_srgb8_table[b2], d_unorm8(b3));
-        const float factor = ldexpf(1.0f, (int)b3 - 136);           /* image.c:329-347; a zero texel is stored as four zero bytes */
-        return mk4((float)b0 * factor, (float)b1 * factor, (float)b2 * factor, 1.0f);
+RZ_DEV f4 decode_word(int flags, float word) {
+    if (flags & RZ_TEX_R32F) return mk4(word, word, word, 1.0f);
+    const uint32_t p = __float_as_uint(word);
+    const uint32_t b0 = p & 0xffu, b1 = (p >> 8) & 0xffu, b2 = (p >> 16) & 0xffu, b3 = p >> 24;
+    if (flags & RZ_TEX_UNORM8) return mk4(d_unorm8(b0), d_unorm8(b1), d_unorm8(b2), d_unorm8(b3));
+    if (flags & RZ_TEX_SRGB8) return mk4(rz_srgb8_table[b0], rz_srgb8_table[b1], rz_srgb8_table[b2], d_unorm8(b3));
+    const float factor = ldexpf(1.0f, (int)b3 - 136);           /* image.c:329-347; a zero texel is stored as four zero bytes */
+    return mk4((float)b0 * factor, (float)b1 * factor, (float)b2 * factor, 1.0f);
+}
+
+template <bool NARROW>
+RZ_DEV f4 decode_texel(const DevTex &t, const TexelT<NARROW> &x) {
+    if constexpr (NARROW) {
+        return decode_word(t.flags, __uint_as_float(x.word));
+    } else {
+        if (t.flags & RZ_TEX_NARROW)
+            return decode_word(t.flags, x.sel == 0 ? x.q.x : (x.sel == 1 ? x.q.y : (x.sel == 2 ? x.q.z : x.q.w)));
+        return mk4(x.q.x, x.q.y, x.q.z, x.q.w);
     }
-    return mk4(x.q.x, x.q.y, x.q.z, x.q.w);
 }
 
 /* nearest texel, index = (int)((size - 1) * coordinate) (texture.c:160-176) */
-RZ_DEV f4 sample_repeat(const DevTex &t, float x, float y) { return decode_texel(t, load_repeat(t, x, y)); }
-RZ_DEV f4 sample_clamp(const DevTex &t, float x, float y) { return decode_texel(t, load_clamp(t, x, y)); }
+RZ_DEV f4 sample_repeat(const DevTex &t, float x, float y) { return decode_texel<false>(t, load_repeat<false>(t, x, y)); }
+RZ_DEV f4 sample_clamp(const DevTex &t, float x, float y) { return decode_texel<false>(t, load_clamp<false>(t, x, y)); }
 
 /* GL ES 2.0 3.7.5 face selection with strict comparisons (texture.c:210-255);
  * the face index differs per lane, so the six descriptors are read per lane */
@@ -289,17 +310,19 @@ RZ_DEV f4 cube_clamp(const DevTex *faces, f3 dir) {                   /* texture
 /* ---- shared by blinn and pbr --------------------------------------------- */
 
 /* blinn_shader.c:178-195 == pbr_shader.c:311-328; the map's texel is loaded ahead of need */
-RZ_DEV Texel load_shadow(const DrawRec &D, f3 depth_position) {
+template <bool NARROW>
+RZ_DEV TexelT<NARROW> load_shadow(const DrawRec &D, f3 depth_position) {
     float u = (depth_position.x + 1) * 0.5f;
     float v = (depth_position.y + 1) * 0.5f;
-    return load_repeat(D.shadow_map, u, v);
+    return load_repeat<NARROW>(D.shadow_map, u, v);
 }
-RZ_DEV bool in_shadow(const DrawRec &D, const Texel &texel, f3 depth_position, float n_dot_l) {
+template <bool NARROW>
+RZ_DEV bool in_shadow(const DrawRec &D, const TexelT<NARROW> &texel, f3 depth_position, float n_dot_l) {
     if (D.shadow_map.data) {
         float d = (depth_position.z + 1) * 0.5f;
         float bias = d_max(0.05f * (1 - n_dot_l), 0.005f);
         float current = d - bias;
-        float closest = decode_texel(D.shadow_map, texel).x;
+        float closest = decode_texel<NARROW>(D.shadow_map, texel).x;
         return current > closest;
     }
     return false;
@@ -308,6 +331,7 @@ RZ_DEV bool in_shadow(const DrawRec &D, const Texel &texel, f3 depth_position, f
 /* ---- blinn: varyings = world_position[3] depth_position[3] texcoord[2] normal[3]
  *      (blinn_shader.h:16-21) --------------------------------------------- */
 
+template <bool NARROW>
 RZ_DEV f4 fs_blinn(const DrawRec &D, const float *v, bool backface, bool *discard) {
     float tu = v[6], tv = v[7];
     if (D.flags & RZ_DRAW_SHADOW_PASS) {                        /* blinn_shader.c:101-115 */
@@ -320,22 +344,22 @@ RZ_DEV f4 fs_blinn(const DrawRec &D, const float *v, bool backface, bool *discar
     }
     /* every texel this fragment can need, in flight together */
     const MapCell cell = first_cell(D.maps[0], tu, tv);
-    const Texel t0 = load_like(D.maps[0], cell), t1 = load_like(D.maps[1], cell), t2 = load_like(D.maps[2], cell);
-    const Texel tshadow = load_shadow(D, mk3(v[3], v[4], v[5]));
+    const TexelT<NARROW> t0 = load_like<NARROW>(D.maps[0], cell), t1 = load_like<NARROW>(D.maps[1], cell), t2 = load_like<NARROW>(D.maps[2], cell);
+    const TexelT<NARROW> tshadow = load_shadow<NARROW>(D, mk3(v[3], v[4], v[5]));
     /* material (:126-169) */
     f3 diffuse = mk3(D.base[0], D.base[1], D.base[2]);
     float alpha = D.base[3];
     if (D.maps[0].data) {
-        f4 s = decode_texel(D.maps[0], t0);
+        f4 s = decode_texel<NARROW>(D.maps[0], t0);
         diffuse = mul3(diffuse, xyz(s));
         alpha *= s.w;
     }
     f3 specular = mk3(0, 0, 0);
-    if (D.maps[1].data) specular = xyz(decode_texel(D.maps[1], t1));
+    if (D.maps[1].data) specular = xyz(decode_texel<NARROW>(D.maps[1], t1));
     f3 normal = unit3(mk3(v[8], v[9], v[10]));
     if (backface) normal = neg3(normal);
     f3 emission = mk3(0, 0, 0);
-    if (D.maps[2].data) emission = xyz(decode_texel(D.maps[2], t2));
+    if (D.maps[2].data) emission = xyz(decode_texel<NARROW>(D.maps[2], t2));
 
     if (D.alpha_cutoff > 0 && alpha < D.alpha_cutoff) {         /* :220-222 */
         *discard = true;
@@ -346,7 +370,7 @@ RZ_DEV f4 fs_blinn(const DrawRec &D, const float *v, bool backface, bool *discar
     if (D.punctual > 0) {
         f3 light = neg3(mk3(D.light_dir[0], D.light_dir[1], D.light_dir[2]));
         float n_dot_l = dot3(normal, light);
-        if (n_dot_l > 0 && !in_shadow(D, tshadow, mk3(v[3], v[4], v[5]), n_dot_l)) {
+        if (n_dot_l > 0 && !in_shadow<NARROW>(D, tshadow, mk3(v[3], v[4], v[5]), n_dot_l)) {
             f3 cam = mk3(D.camera_pos[0], D.camera_pos[1], D.camera_pos[2]);
             f3 view = unit3(sub3(cam, mk3(v[0], v[1], v[2])));
             f3 spec = mk3(0, 0, 0);
@@ -376,24 +400,25 @@ struct Surface {
 
 RZ_DEV float largest3(f3 v) { return v.x > v.y && v.x > v.z ? v.x : (v.y > v.z ? v.y : v.z); }   /* pbr_shader.c:184 */
 
+template <bool NARROW>
 RZ_DEV Surface pbr_surface(const DrawRec &D, const float *v, bool backface) {
     Surface s;
     float tu = v[19], tv = v[20];
     /* the six material texels in flight together */
     const MapCell cell = first_cell(D.maps[0].data ? D.maps[0] : D.maps[3], tu, tv);
-    const Texel t0 = load_like(D.maps[0], cell), t1 = load_like(D.maps[1], cell), t2 = load_like(D.maps[2], cell);
-    const Texel t3 = load_like(D.maps[3], cell), t4 = load_like(D.maps[4], cell), t5 = load_like(D.maps[5], cell);
+    const TexelT<NARROW> t0 = load_like<NARROW>(D.maps[0], cell), t1 = load_like<NARROW>(D.maps[1], cell), t2 = load_like<NARROW>(D.maps[2], cell);
+    const TexelT<NARROW> t3 = load_like<NARROW>(D.maps[3], cell), t4 = load_like<NARROW>(D.maps[4], cell), t5 = load_like<NARROW>(D.maps[5], cell);
     if (D.workflow == 0) {                                      /* metal-rough, :148-182 */
         f3 base = mk3(D.base[0], D.base[1], D.base[2]);
         float metal = D.metalness, rough = D.roughness;
         s.alpha = D.base[3];
         if (D.maps[0].data) {
-            f4 t = decode_texel(D.maps[0], t0);
+            f4 t = decode_texel<NARROW>(D.maps[0], t0);
             base = mul3(base, xyz(t));
             s.alpha *= t.w;
         }
-        if (D.maps[1].data) metal *= decode_texel(D.maps[1], t1).x;
-        if (D.maps[2].data) rough *= decode_texel(D.maps[2], t2).x;
+        if (D.maps[1].data) metal *= decode_texel<NARROW>(D.maps[1], t1).x;
+        if (D.maps[2].data) rough *= decode_texel<NARROW>(D.maps[2], t2).x;
         s.diffuse = scale3(base, (1 - 0.04f) * (1 - metal));
         s.specular = mix3(mk3(0.04f, 0.04f, 0.04f), base, metal);
         s.roughness = rough;
@@ -403,18 +428,18 @@ RZ_DEV Surface pbr_surface(const DrawRec &D, const float *v, bool backface) {
         float gloss = D.glossiness;
         s.alpha = D.base[3];
         if (D.maps[0].data) {
-            f4 t = decode_texel(D.maps[0], t0);
+            f4 t = decode_texel<NARROW>(D.maps[0], t0);
             diff = mul3(diff, xyz(t));
             s.alpha *= t.w;
         }
-        if (D.maps[1].data) spec = mul3(spec, xyz(decode_texel(D.maps[1], t1)));
-        if (D.maps[2].data) gloss *= decode_texel(D.maps[2], t2).x;
+        if (D.maps[1].data) spec = mul3(spec, xyz(decode_texel<NARROW>(D.maps[1], t1)));
+        if (D.maps[2].data) gloss *= decode_texel<NARROW>(D.maps[2], t2).x;
         s.diffuse = scale3(diff, 1 - largest3(spec));
         s.specular = spec;
         s.roughness = 1 - gloss;
     }
     if (D.maps[3].data) {                                       /* normal map, :224-243 */
-        f4 t = decode_texel(D.maps[3], t3);
+        f4 t = decode_texel<NARROW>(D.maps[3], t3);
         f3 tn = mk3(t.x * 2 - 1, t.y * 2 - 1, t.z * 2 - 1);
         /* TBN has tangent, bitangent, normal as COLUMNS */
         f3 wn = mk3(v[13] * tn.x + v[16] * tn.y + v[10] * tn.z,
@@ -425,13 +450,14 @@ RZ_DEV Surface pbr_surface(const DrawRec &D, const float *v, bool backface) {
         s.normal = unit3(mk3(v[10], v[11], v[12]));
     }
     if (backface) s.normal = neg3(s.normal);
-    s.occlusion = D.maps[4].data ? decode_texel(D.maps[4], t4).x : 1.0f;           /* :259-264 */
-    s.emission = D.maps[5].data ? xyz(decode_texel(D.maps[5], t5)) : mk3(0, 0, 0);
+    s.occlusion = D.maps[4].data ? decode_texel<NARROW>(D.maps[4], t4).x : 1.0f;           /* :259-264 */
+    s.emission = D.maps[5].data ? xyz(decode_texel<NARROW>(D.maps[5], t5)) : mk3(0, 0, 0);
     return s;
 }
 
 /* image-based lighting (:281-309); face and prefiltered level differ per lane, so the two
  * face descriptors are read per lane -- together -- and then the three texels together */
+template <bool NARROW>
 RZ_DEV f3 pbr_ambient(const Surface &s, const DevIbl *ibl, f3 n, f3 view) {
     float n_dot_v = dot3(n, view);
     f3 reflected = sub3(scale3(n, 2 * n_dot_v), view);          /* :276-279 */
@@ -441,14 +467,14 @@ RZ_DEV f3 pbr_ambient(const Surface &s, const DevIbl *ibl, f3 n, f3 view) {
     float s1, t1, s2, t2;
     const int face1 = cube_face(n, &s1, &t1), face2 = cube_face(reflected, &s2, &t2);
     const DevTex d1 = ibl->diffuse[face1], d2 = ibl->specular[level][face2];
-    const Texel x1 = load_clamp(d1, s1, 1 - t1), x2 = load_clamp(d2, s2, 1 - t2);      /* texture.c:264 */
-    const Texel x3 = load_clamp(ibl->lut, n_dot_v, s.roughness);
+    const TexelT<NARROW> x1 = load_clamp<NARROW>(d1, s1, 1 - t1), x2 = load_clamp<NARROW>(d2, s2, 1 - t2);      /* texture.c:264 */
+    const TexelT<NARROW> x3 = load_clamp<NARROW>(ibl->lut, n_dot_v, s.roughness);
     f3 diffuse_color = scale3(s.diffuse, s.occlusion);
-    f3 irradiance = xyz(decode_texel(d1, x1));
+    f3 irradiance = xyz(decode_texel<NARROW>(d1, x1));
     f3 diffuse = mul3(irradiance, diffuse_color);
-    f4 lut = decode_texel(ibl->lut, x3);
+    f4 lut = decode_texel<NARROW>(ibl->lut, x3);
     f3 spec_color = mk3(s.specular.x * lut.x + lut.y, s.specular.y * lut.x + lut.y, s.specular.z * lut.x + lut.y);
-    f3 radiance = xyz(decode_texel(d2, x2));
+    f3 radiance = xyz(decode_texel<NARROW>(d2, x2));
     return add3(diffuse, mul3(radiance, spec_color));
 }
 
@@ -503,6 +529,7 @@ RZ_DEV f4 layer_color(int layer, const Surface &s) {
     return mk4(s.normal.x * 0.5f + 0.5f, s.normal.y * 0.5f + 0.5f, s.normal.z * 0.5f + 0.5f, s.alpha);
 }
 
+template <bool NARROW>
 RZ_DEV f4 fs_pbr(const DrawRec &D, const float *v, bool backface, bool *discard) {
     if (D.flags & RZ_DRAW_SHADOW_PASS) {                        /* pbr_shader.c:113-136 */
         if (D.alpha_cutoff > 0) {
@@ -512,8 +539,8 @@ RZ_DEV f4 fs_pbr(const DrawRec &D, const float *v, bool backface, bool *discard)
         }
         return mk4(0, 0, 0, 0);
     }
-    const Texel tshadow = load_shadow(D, mk3(v[3], v[4], v[5]));
-    Surface s = pbr_surface(D, v, backface);                    /* :446-490 */
+    const TexelT<NARROW> tshadow = load_shadow<NARROW>(D, mk3(v[3], v[4], v[5]));
+    Surface s = pbr_surface<NARROW>(D, v, backface);                    /* :446-490 */
     float sxn = v[6] / v[9] * 0.5f + 0.5f;
     float syn = v[7] / v[9] * 0.5f + 0.5f;
     if (D.alpha_cutoff > 0 && s.alpha < D.alpha_cutoff) {
@@ -531,9 +558,9 @@ RZ_DEV f4 fs_pbr(const DrawRec &D, const float *v, bool backface, bool *discard)
         f3 light = neg3(mk3(D.light_dir[0], D.light_dir[1], D.light_dir[2]));
         float n_dot_l = dot3(s.normal, light);
         f3 color = s.emission;
-        if (D.ambient > 0 && D.ibl) color = add3(color, scale3(pbr_ambient(s, D.ibl, s.normal, view), D.ambient));
+        if (D.ambient > 0 && D.ibl) color = add3(color, scale3(pbr_ambient<NARROW>(s, D.ibl, s.normal, view), D.ambient));
         if (D.punctual > 0 && n_dot_l > 0) {
-            if (!in_shadow(D, tshadow, mk3(v[3], v[4], v[5]), n_dot_l))
+            if (!in_shadow<NARROW>(D, tshadow, mk3(v[3], v[4], v[5]), n_dot_l))
                 color = add3(color, scale3(pbr_light(s, light, s.normal, view), D.punctual));
         }
         return display_encode(color, s.alpha);
