@@ -132,7 +132,7 @@ struct Context {
     hipStream_t copy_stream = nullptr;  /* table uploads / control read-back of a flush */
     Lane lanes[MAX_LANES];
     int num_lanes = 1, next_lane = 0;
-    size_t max_batch = 16;                  /* passes per launch sequence */
+    size_t max_batch = 32;                  /* passes per launch sequence */
     bool pack_textures = true;              /* MI355R_PACK=0: keep every image as float4 */
     bool narrow_raster = false;             /* MI355R_NARROW_RASTER=1: one pixel per lane in the visibility pass */
     int pixels_per_lane = 2;                /* MI355R_PPL=4: a wave takes the whole 32x8 tile */

@@ -7,7 +7,7 @@ TAG=${1:-run}
 OUT=gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-BENCH="python3 bench.py --steps 3 --warmup 1 --frames 16 --no-cpu"
+BENCH="python3 bench.py --steps 3 --warmup 1 --frames 32 --no-cpu"
 timeout -s KILL 240 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- $BENCH > "$OUT/trace.log" 2>&1 || { echo "trace pass failed"; tail -5 "$OUT/trace.log"; exit 1; }
 pass() {
     name=$1; shift
@@ -17,5 +17,5 @@ pass sq1 SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_
 pass sq2 SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_WAIT_INST_LDS SQ_INST_CYCLES_VMEM
 pass fetch FETCH_SIZE GRBM_GUI_ACTIVE
 pass write WRITE_SIZE TCC_HIT_sum TCC_MISS_sum
-python3 tools/summarize_profile.py "$OUT" 16 > "$OUT/summary.txt" 2>&1
+python3 tools/summarize_profile.py "$OUT" 32 > "$OUT/summary.txt" 2>&1
 cat "$OUT/summary.txt"
