@@ -65,6 +65,7 @@ class Pipeline:
         lib.rzs_default_view.argtypes = [C.POINTER(View)]
         lib.rzs_orbit_view.argtypes = [C.POINTER(View), C.c_int, C.c_int]
         lib.rzs_scene_draw.argtypes = [P, FB, C.POINTER(View)]
+        lib.rzs_scene_draw_no_clear.argtypes = [P, FB, C.POINTER(View)]
         lib.rzs_scene_info.argtypes = [P, C.POINTER(C.c_int)]
         lib.rzs_scene_shadow_buffer.restype = FB
         lib.rzs_scene_shadow_buffer.argtypes = [P]

@@ -623,7 +623,12 @@ static void sort_models(rzs_scene *scene, rz_mat4 view) {
     qsort(scene->models, scene->num_models, sizeof(model_t*), model_order);
 }
 
-void rzs_scene_draw(rzs_scene *scene, rz_framebuffer *fb, const rzs_view *view) {
+static void scene_draw(rzs_scene *scene, rz_framebuffer *fb, const rzs_view *view, int clear);
+
+void rzs_scene_draw(rzs_scene *scene, rz_framebuffer *fb, const rzs_view *view) { scene_draw(scene, fb, view, 1); }
+void rzs_scene_draw_no_clear(rzs_scene *scene, rz_framebuffer *fb, const rzs_view *view) { scene_draw(scene, fb, view, 0); }
+
+static void scene_draw(rzs_scene *scene, rz_framebuffer *fb, const rzs_view *view, int clear) {
     frame_t f;
     rz_vec3 eye = hm_v3(view->eye[0], view->eye[1], view->eye[2]);
     rz_vec3 target = hm_v3(view->target[0], view->target[1], view->target[2]);
@@ -658,8 +663,10 @@ void rzs_scene_draw(rzs_scene *scene, rz_framebuffer *fb, const rzs_view *view) 
     }
 
     sort_models(scene, f.camera_view);
-    framebuffer_clear_color(fb, scene->background);
-    framebuffer_clear_depth(fb, 1);
+    if (clear) {
+        framebuffer_clear_color(fb, scene->background);
+        framebuffer_clear_depth(fb, 1);
+    }
     if (scene->skybox == NULL || f.layer_view >= 0) {
         for (i = 0; i < scene->num_models; i++) model_draw(scene->models[i], fb, 0);
     } else {

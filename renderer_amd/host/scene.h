@@ -48,6 +48,8 @@ void rzs_orbit_view(rzs_view *view, int index, int count);
  * blocks, graphics_draw_triangle), e.g. pbr_shader.c:561-577. */
 void rzs_set_per_triangle(int on);
 void rzs_scene_draw(rzs_scene *scene, rz_framebuffer *framebuffer, const rzs_view *view);
+/* the same without clearing the framebuffer first: the frame is drawn over what is there */
+void rzs_scene_draw_no_clear(rzs_scene *scene, rz_framebuffer *framebuffer, const rzs_view *view);
 
 /* info: [0] models, [1] faces, [2] has skybox, [3] shadow width, [4] shadow
  * height, [5] blended models, [6] skinned models, [7] node-attached models */

@@ -8,6 +8,8 @@ The pipeline keeps the reference's f32 expression order with FMA contraction
 off, so the expected result is much tighter: identical coverage and depth, and
 colour differing only where the device's double-precision pow() rounds
 differently from glibc's."""
+import ctypes as C
+
 import numpy as np
 import pytest
 
@@ -146,3 +148,35 @@ def test_gpu_counters_match_oracle_workload(gpu, oracle):
     oracle.close_scene(scene)
     assert got[0] == want[0] and got[1] == want[1] and got[2] == want[4]
     assert got[8] <= got[2]           # deferred shading never shades more than the reference
+
+
+def test_gpu_passes_into_one_framebuffer_stay_ordered(gpu, oracle):
+    """Several frames recorded into the SAME framebuffer before anything is read: with a clear in
+    between the last one must win, without a clear they pile up in call order (the second frame's
+    depth test sees the first frame's depth).  Independent frames into other framebuffers are
+    recorded in between, so the scheduler has something to batch them with."""
+    w, h = 320, 180
+    results = []
+    for pipe in (gpu, oracle):
+        scene = pipe.open_scene("helmet")
+        other = pipe.open_scene("azura")
+        fb = pipe.framebuffer(w, h)
+        side = [pipe.framebuffer(w, h) for _ in range(3)]
+        views = [pipe.orbit_view(i, 8) for i in range(4)]
+        pipe.draw(scene, fb, views[0])
+        pipe.draw(other, side[0], views[1])
+        pipe.draw(scene, fb, views[2])                  # rzs_scene_draw clears first: replaces frame 0
+        pipe.draw(other, side[1], views[3])
+        cleared = pipe.read(fb)
+        # now without a clear: the blinn scene's models are drawn over the finished pbr frame
+        pipe.lib.rzs_scene_draw_no_clear(other, fb, C.byref(views[1]))
+        pipe.draw(scene, side[2], views[0])
+        piled = pipe.read(fb)
+        sides = [pipe.read(f) for f in side]
+        for f in side + [fb]:
+            pipe.release(f)
+        pipe.close_scene(scene)
+        pipe.close_scene(other)
+        results.append([cleared, piled] + sides)
+    for got, want in zip(*results):
+        assert_same(got, want, w * h)

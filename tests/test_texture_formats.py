@@ -108,7 +108,7 @@ def test_every_loaded_scene_texture_round_trips(pack, oracle):
     assert seen == {0, 4, 8, 16}       # tone-mapped sky face, data map, colour map, radiance maps
 
 
-PACK_OFF_SCRIPT = r"""
+VARIANT_SCRIPT = r"""
 import sys, numpy as np
 sys.path.insert(0, %r)
 sys.path.insert(0, %r)
@@ -117,7 +117,7 @@ from renderer_amd.binding import Pipeline, GPU_LIB
 gpu = Pipeline(GPU_LIB)
 bad = 0
 for case in golden_cases():
-    if case["name"] not in ("helmet_default", "azura_shadow", "drone_specgloss"):
+    if case["name"] not in ("helmet_default", "helmet_cutoff", "azura_shadow", "kgirl_blend", "drone_specgloss"):
         continue
     want = load_golden(case["name"]); got = render_case(gpu, case)
     bad += int((got[0] != want[0]).sum()) + int((got[1] != want[1]).sum())
@@ -127,10 +127,14 @@ sys.exit(0 if bad == 0 else 1)
 
 
 @pytest.mark.gpu
-def test_gpu_float4_and_packed_images_give_the_same_frames(gpu):
-    """The default run (packed images) is what every other GPU test checks against the goldens;
-    here the same goldens with packing switched off (MI355R_PACK=0, read when the library starts)."""
-    env = dict(os.environ, MI355R_PACK="0")
-    r = subprocess.run([sys.executable, "-c", PACK_OFF_SCRIPT % (REPO, os.path.join(REPO, "tests"))],
-                       env=env, capture_output=True, text=True, timeout=300)
+@pytest.mark.parametrize("env", [{"MI355R_PACK": "0"}, {"MI355R_NARROW_RASTER": "1"}, {"MI355R_PPL": "4"},
+                                 {"MI355R_LANES": "1", "MI355R_BATCH": "1"}, {"MI355R_MONOLITHIC": "1"}],
+                         ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()))
+def test_gpu_alternative_code_paths_give_the_same_frames(gpu, env):
+    """The default configuration is what every other GPU test checks against the goldens; here the
+    same goldens through the other code paths the library keeps (chosen by environment variables
+    read when it starts): float4 images only, one or four pixels per lane in the visibility
+    kernel, no batching, and in-kernel shading for every pass."""
+    r = subprocess.run([sys.executable, "-c", VARIANT_SCRIPT % (REPO, os.path.join(REPO, "tests"))],
+                       env=dict(os.environ, **env), capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "DIFFS 0" in r.stdout, r.stdout + r.stderr
