@@ -28,7 +28,7 @@ sys.path.insert(0, REPO)
 
 WIDTH, HEIGHT = 1920, 1080
 SCENE = "helmet"
-ORBIT = 64                  # views on the orbit circle
+ORBIT = 128                 # views on the orbit circle
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E
 KERNEL_SYMBOL = {"vertex": "rz_vertex_kernel", "setup": "rz_setup_kernel", "bin": "rz_bin_fill_kernel",
                  "raster": "rz_visibility_kernel<2>", "shade_skybox": "rz_shade_kernel<2>",
@@ -98,7 +98,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--frames", type=int, default=64, help="frames per step and rank (default: one 64-view orbit)")
+    ap.add_argument("--frames", type=int, default=128, help="frames per step and rank (default: one 128-view orbit)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (gloo: CPU rehearsal of the gather)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     args = ap.parse_args()
