@@ -63,10 +63,8 @@ __global__ void __launch_bounds__(256) rz_vertex_kernel(const PassParams *__rest
     uint32_t gv = blockIdx.x * 256u + threadIdx.x;
     if (gv < 8u) P.control[gv] = 0;             /* the pass's device-written scalars start at zero */
     if (blockIdx.y == 0 && gv < 2u * RZ_QUEUE_WAYS) P.queue_counts[gv * RZ_QUEUE_PAD] = 0;    /* ... and the batch's work-list lengths */
-    if (gv < (uint32_t)(P.tiles_x * P.tiles_y)) P.tile_listed[gv] = 0;         /* (3 vertices per triangle: more threads than tiles
-                                                                                  for any pass that fills its framebuffer; the rest below) */
-    if (gv == 0)
-        for (uint32_t t = 3u * (uint32_t)P.num_tris; t < (uint32_t)(P.tiles_x * P.tiles_y); t++) P.tile_listed[t] = 0;
+    /* the grid is sized for the largest pass of the batch: all of its threads share the clearing */
+    for (uint32_t t = gv; t < (uint32_t)(P.tiles_x * P.tiles_y); t += gridDim.x * 256u) P.tile_listed[t] = 0;
     if (gv >= 3u * (uint32_t)P.num_tris) return;
     int d = find_draw(P.first_tri, P.num_draws, gv / 3u);
     const DrawRec &D = P.draws[d];
