@@ -1056,19 +1056,78 @@ __global__ void __launch_bounds__(256 / PPL) rz_visibility_kernel(const PassPara
     }
     float zcur[PPL];
     uint32_t ref_of[PPL];                                           /* tagged with the family; NONE = no fragment */
+    int ord_of[PPL];                                                /* its position in the bin's list; -1 = what the buffer held */
     for (int q = 0; q < PPL; q++) {
         ref_of[q] = RZ_REF_NONE;
+        ord_of[q] = -1;
         zcur[q] = P.clear_depth;
         if (valid[q] && !P.clear_depth_pending) zcur[q] = P.depth[pixel[q]];
     }
     const BinEntry *list = list_table + range.x;
 
+    /* Small triangles.  Which fragment a pixel ends up with does not depend on the order the
+     * triangles are taken in: it is the one of least depth, the latest in submission order among
+     * equals (graphics.c:523 keeps a fragment when depth <= the stored depth).  Candidates whose
+     * box covers at most micro_area pixels of this wave's block are therefore set aside in a ring,
+     * and each time 64 have come together every lane rasterises one of them, pixel by pixel,
+     * into a per-pixel key in LDS: depth (as an order-preserving integer) above the complement of
+     * the list position, so that an atomic minimum keeps exactly that fragment.  The keys meet the
+     * registers of the one-triangle-per-step path when the list ends.  Triangles with an alpha
+     * cutoff and passes that count fragments stay on the ordered path. */
+    __shared__ unsigned long long micro_keys[256];
+    __shared__ uint32_t micro_ring[4 / PPL][128];
+    unsigned long long *keys = micro_keys + wave * 64 * PPL;
+    uint32_t *ring = micro_ring[wave];
+    const int micro_area = P.counters ? 0 : P.micro_area;
+    uint32_t ring_head = 0, ring_tail = 0;                          /* wave-uniform */
+    if (micro_area)
+        for (int q = 0; q < PPL; q++) keys[q * 64 + lane] = ~0ull;
+    const int sx1 = min(bx1, P.width - 1), sy1 = min(by1, P.height - 1);
+    auto rasterise_ring = [&](uint32_t n) {                         /* one triangle per lane, the ring's oldest n <= 64 */
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        const bool on = (uint32_t)lane < n;
+        const uint32_t ord = on ? ring[(ring_head + (uint32_t)lane) & 127u] : 0u;
+        ring_head += n;
+        TriRec r;
+        int x0 = 0, x1 = -1, y0 = 0, y1 = -1;
+        if (on) {
+            const float4 *e = (const float4*)&list[ord];
+            const float4 a = e[1], b = e[2], c = e[3], d = e[4];
+            r.ax = a.x; r.ay = a.y; r.abx = a.z; r.aby = a.w;
+            r.acx = b.x; r.acy = b.y; r.factor = b.z; r.z[0] = b.w;
+            r.z[1] = c.x; r.z[2] = c.y;
+            const uint32_t bx = __float_as_uint(d.z), by = __float_as_uint(d.w);
+            x0 = max((int)(bx & 0xffffu), bx0); x1 = min((int)(bx >> 16), sx1);
+            y0 = max((int)(by & 0xffffu), by0); y1 = min((int)(by >> 16), sy1);
+        }
+        int x = x0, y = y0;
+        const uint32_t low = ~ord;
+        if (P.debug_skip == 11) return;
+        while (__any(y <= y1)) {
+            if (y <= y1) {
+                float w0, w1, w2;
+                pixel_weights(r, x, y, w0, w1, w2);
+                const float depth = r.z[0] * w0 + r.z[1] * w1 + r.z[2] * w2;                       /* :403-408 */
+                if (w0 > -RZ_EPS && w1 > -RZ_EPS && w2 > -RZ_EPS && depth == depth) {             /* :516-519 */
+                    const uint32_t bits = __float_as_uint(depth + 0.0f);
+                    const uint32_t up = bits ^ ((uint32_t)((int32_t)bits >> 31) | 0x80000000u);
+                    const int lx = x - bx0, ly = y - by0;
+                    if (P.debug_skip != 12) atomicMin(&keys[(lx >> 3) * 64 + (ly << 3) + (lx & 7)], ((unsigned long long)up << 32) | low);
+                }
+                if (++x > x1) { x = x0; y++; }
+            }
+        }
+    };
+
     /* this lane's candidate of the NEXT group of 64 entries, loaded one group ahead */
     float4 n0 = make_float4(0, 0, 0, 0), n1 = n0;
     float2 nbox = make_float2(0, 0);
+    uint32_t nmeta = 0;
     if ((uint32_t)lane < count) {
         const float4 *e = (const float4*)&list[lane];              /* reference + record, 80 bytes */
-        n0 = e[1]; n1 = e[2]; nbox = *(const float2*)((const char*)e + 72);
+        n0 = e[1]; n1 = e[2];
+        const float4 tail = e[4];
+        nmeta = __float_as_uint(tail.y); nbox = make_float2(tail.z, tail.w);
     }
     /* block corners at pixel centres, for the conservative triangle/block test */
     const float cx0 = (float)bx0 + 0.5f, cx1 = (float)bx1 + 0.5f, cy0 = (float)by0 + 0.5f, cy1 = (float)by0 + 7.5f;
@@ -1076,22 +1135,43 @@ __global__ void __launch_bounds__(256 / PPL) rz_visibility_kernel(const PassPara
     for (uint32_t base = 0; base < count && P.debug_skip != 4;) {
         const float4 c0 = n0, c1 = n1;
         const float2 cbox = nbox;
+        const uint32_t cmeta = nmeta;
         const bool present = base + lane < count;
         const BinEntry *group = list + base;
+        const uint32_t group_at = base;
         base += 64u;
         if (base + lane < count) {
             const float4 *e = (const float4*)&list[base + lane];
-            n0 = e[1]; n1 = e[2]; nbox = *(const float2*)((const char*)e + 72);
+            n0 = e[1]; n1 = e[2];
+            const float4 tail = e[4];
+            nmeta = __float_as_uint(tail.y); nbox = make_float2(tail.z, tail.w);
         }
         bool hit = false;
         if (present) {
             hit = box_overlaps(make_uint2(__float_as_uint(cbox.x), __float_as_uint(cbox.y)), bx0, by0, bx1, by1);
             if (hit) hit = !block_outside(c0, c1, cx0, cx1, cy0, cy1);
         }
+        if (micro_area) {
+            bool small = false;
+            if (hit) {
+                const uint32_t bx = __float_as_uint(cbox.x), by = __float_as_uint(cbox.y);
+                const int w = min((int)(bx >> 16), sx1) - max((int)(bx & 0xffffu), bx0) + 1;
+                const int h = min((int)(by >> 16), sy1) - max((int)(by & 0xffffu), by0) + 1;
+                small = w * h <= micro_area && !RZ_META_CUTOFF(cmeta);
+            }
+            const unsigned long long smalls = __ballot(small);
+            if (smalls) {
+                if (small) ring[(ring_tail + __builtin_amdgcn_mbcnt_hi((uint32_t)(smalls >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)smalls, 0u))) & 127u] = group_at + (uint32_t)lane;
+                ring_tail += (uint32_t)__popcll(smalls);
+                hit = hit && !small;
+                if (ring_tail - ring_head >= 64u) rasterise_ring(64u);
+            }
+        }
         unsigned long long todo = __ballot(hit);
         while (todo) {
             /* the wave-uniform entry index makes these scalar loads */
-            const BinEntry *e = &group[__ffsll((long long)todo) - 1];
+            const uint32_t at = (uint32_t)__ffsll((long long)todo) - 1u;
+            const BinEntry *e = &group[at];
             todo &= todo - 1;
             const uint32_t ref = e->tri;
             const TriRec r = e->rec;
@@ -1139,7 +1219,23 @@ __global__ void __launch_bounds__(256 / PPL) rz_visibility_kernel(const PassPara
                 }
             }
             const uint32_t tagged = ref | (RZ_META_FAMILY(r.meta) << 28);
-            for (int q = 0; q < PPL; q++) if (pass[q]) { zcur[q] = depth[q]; ref_of[q] = tagged; }
+            for (int q = 0; q < PPL; q++) if (pass[q]) { zcur[q] = depth[q]; ref_of[q] = tagged; ord_of[q] = (int)(group_at + at); }
+        }
+    }
+    if (micro_area) {
+        if (ring_tail != ring_head) rasterise_ring(ring_tail - ring_head);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        for (int q = 0; q < PPL; q++) {
+            const unsigned long long key = keys[q * 64 + lane];
+            if (key == ~0ull) continue;
+            const uint32_t up = (uint32_t)(key >> 32);
+            const float depth = __uint_as_float(up ^ ((up >> 31) ? 0x80000000u : 0xffffffffu));
+            const int ord = (int)~(uint32_t)key;
+            if (depth < zcur[q] || (depth == zcur[q] && ord > ord_of[q])) {
+                const BinEntry *e = &list[ord];
+                zcur[q] = depth;
+                ref_of[q] = e->tri | (RZ_META_FAMILY(e->rec.meta) << 28);
+            }
         }
     }
 
