@@ -136,6 +136,7 @@ struct Context {
     bool pack_textures = true;              /* MI355R_PACK=0: keep every image as float4 */
     bool narrow_raster = false;             /* MI355R_NARROW_RASTER=1: one pixel per lane in the visibility pass */
     int pixels_per_lane = 2;                /* MI355R_PPL=4: a wave takes the whole 32x8 tile */
+    int micro_min_list = 256;               /* MI355R_MICRO_MIN_LIST: ... only in bins with at least this many list entries */
     int micro_area = 32;                    /* MI355R_MICRO_AREA: largest box (pixels of a block) rasterised one triangle per lane; 0 = off */
     int shade_workgroups = 4096;            /* 256-thread workgroups per shade launch (compute units x 16) */
     std::vector<hipEvent_t> events;     /* recorded since the last full sync */
@@ -232,6 +233,8 @@ extern "C" int mi355r_init(int device) {
         if (env) g.pixels_per_lane = atoi(env);
         env = getenv("MI355R_MICRO_AREA");
         if (env) g.micro_area = std::max(0, std::min(atoi(env), 128));
+        env = getenv("MI355R_MICRO_MIN_LIST");
+        if (env) g.micro_min_list = std::max(0, atoi(env));
         env = getenv("MI355R_PACK");
         if (env) g.pack_textures = atoi(env) != 0;
         env = getenv("MI355R_BATCH");
@@ -1172,6 +1175,7 @@ static void prepare_batch(const Batch &b, const std::vector<PassPlan> &plans, ch
         P.counters = g.counting ? g.d_counters : nullptr;
         P.debug_skip = dbg ? atoi(dbg) : 0;
         P.micro_area = g.micro_area;
+        P.micro_min_list = g.micro_min_list;
         P.tiles_x = (W + RZ_TILE_W - 1) / RZ_TILE_W;
         P.tiles_y = (H + RZ_TILE_H - 1) / RZ_TILE_H;
         P.tile_listed = L.tile_listed.ptr + tile_off;

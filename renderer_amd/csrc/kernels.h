@@ -1078,7 +1078,8 @@ __global__ void __launch_bounds__(256 / PPL) rz_visibility_kernel(const PassPara
     __shared__ uint32_t micro_ring[4 / PPL][128];
     unsigned long long *keys = micro_keys + wave * 64 * PPL;
     uint32_t *ring = micro_ring[wave];
-    const int micro_area = P.counters ? 0 : P.micro_area;
+    /* short lists are not worth the keys' set-up and the final merge */
+    const int micro_area = (P.counters || count < (uint32_t)P.micro_min_list) ? 0 : P.micro_area;
     uint32_t ring_head = 0, ring_tail = 0;                          /* wave-uniform */
     if (micro_area)
         for (int q = 0; q < PPL; q++) keys[q * 64 + lane] = ~0ull;

@@ -166,6 +166,7 @@ struct PassParams {
     int32_t debug_skip;             /* measurement only: 1 skip shading, 2 skip coverage too */
     int32_t micro_area;             /* triangles whose box covers at most this many pixels of a wave's block
                                      * are rasterised one per lane; 0 = none */
+    int32_t micro_min_list;         /* ... in bins whose list has at least this many entries */
     /* A launch covers a batch of passes (blockIdx.y = pass).  The rasteriser
      * and the shade kernels address the batch-wide tables through restrict
      * kernel arguments plus these per-pass offsets. */
