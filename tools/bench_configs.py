@@ -17,6 +17,8 @@ CONFIGS = [
     ("C3 kgirl skinned + blend 1080p", os.path.join(SCENES, "kgirl_blend.scn"), "kgirl", (1920, 1080)),
     ("C4 dieselpunk + 2048^2 shadow 4K", os.path.join(SCENES, "dieselpunk_shadow.scn"), "dieselpunk", (3840, 2160)),
     ("C5 buster animated 1080p", "buster", None, (1920, 1080)),
+    # procedural meshes and seeded textures only (tools/make_synthetic.py): no third-party asset involved
+    ("S1 synthetic blinn + shadow + cutoff + blend 1080p", os.path.join(SCENES, "synthetic_blinn.scn"), None, (1920, 1080)),
 ]
 
 
