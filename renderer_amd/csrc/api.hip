@@ -73,6 +73,10 @@ struct Tex {
     int write_lane;
     hipEvent_t write_event;
     std::vector<hipEvent_t> read_events;
+    /* a copy from a framebuffer that is recorded but not launched yet will fill the image; and
+     * the flush (Context::flush_epoch) during whose recording a draw last referred to it */
+    bool pending_write = false;
+    unsigned long long used_epoch = ~0ull;
 };
 
 struct rz_program {
@@ -96,6 +100,7 @@ struct Pending {
     int num_joints;
     size_t joints_at, joint_normals_at;     /* offsets into Context::side */
     std::vector<Tex*> gpu_textures; /* sampled textures that a GPU pass wrote */
+    std::vector<Tex*> pending_textures;     /* sampled textures that a recorded copy of this flush will fill */
     bool transient;                 /* vertices recorded by graphics_draw_triangle */
     std::vector<rz_vertex> verts;
     std::vector<char> uniform_bytes;        /* for merging per-triangle calls */
@@ -137,10 +142,15 @@ struct Context {
     bool narrow_raster = false;             /* MI355R_NARROW_RASTER=1: one pixel per lane in the visibility pass */
     int pixels_per_lane = 2;                /* MI355R_PPL=4: a wave takes the whole 32x8 tile */
     int micro_min_list = 256;               /* MI355R_MICRO_MIN_LIST: ... only in bins with at least this many list entries */
+    bool record_copies = true;              /* MI355R_RECORD_COPIES=0: texture_from_*buffer always flushes first */
     int micro_area = 32;                    /* MI355R_MICRO_AREA: largest box (pixels of a block) rasterised one triangle per lane; 0 = off */
     int shade_workgroups = 4096;            /* 256-thread workgroups per shade launch (compute units x 16) */
     std::vector<hipEvent_t> events;     /* recorded since the last full sync */
-    std::vector<Tex*> current_gpu_textures;
+    std::vector<Tex*> current_gpu_textures, current_pending_textures;
+    /* framebuffer -> texture copies recorded between draws: run behind the pass that ends at draw `after` */
+    struct TexWrite { Tex *tex; Fb *fb; bool depth; size_t after; };
+    std::vector<TexWrite> tex_writes;
+    unsigned long long flush_epoch = 0;     /* counts the flushes that had something to submit */
     /* upload ring: pinned host memory mirrored 1:1 in device memory */
     char *ring_host = nullptr, *ring_dev = nullptr;
     size_t ring_size = 0, ring_at = 0;
@@ -231,6 +241,8 @@ extern "C" int mi355r_init(int device) {
         if (env) g.narrow_raster = atoi(env) != 0;
         env = getenv("MI355R_PPL");
         if (env) g.pixels_per_lane = atoi(env);
+        env = getenv("MI355R_RECORD_COPIES");
+        if (env) g.record_copies = atoi(env) != 0;
         env = getenv("MI355R_MICRO_AREA");
         if (env) g.micro_area = std::max(0, std::min(atoi(env), 128));
         env = getenv("MI355R_MICRO_MIN_LIST");
@@ -564,7 +576,9 @@ static DevTex dev_tex(rz_texture *p) {
     if (!p) return d;
     Tex *t = as_tex(p);
     if (t->device_stale) upload_texture(t);
-    if (t->write_lane >= 0) g.current_gpu_textures.push_back(t);
+    t->used_epoch = g.flush_epoch;
+    if (t->pending_write) g.current_pending_textures.push_back(t);
+    else if (t->write_lane >= 0) g.current_gpu_textures.push_back(t);
     d.data = t->d_data;
     d.w = t->pub.width;
     d.h = t->pub.height;
@@ -608,34 +622,50 @@ static void end_texture_write(Tex *t, Fb *fb) {
     t->host_stale = true;
 }
 
-extern "C" void texture_from_depthbuffer(rz_texture *tp, rz_framebuffer *fp) {   /* texture.c:147 */
-    Tex *t = as_tex(tp);
-    Fb *fb = as_fb(fp);
-    if (t->pub.width != fb->pub.width || t->pub.height != fb->pub.height) fatal("texture_from_depthbuffer: size mismatch");
-    graphics_flush();
-    apply_pending_clear(fb);
-    device_image(t, RZ_TEX_R32F, sizeof(float));
-    int w = t->pub.width, h = t->pub.height;
+static void launch_texture_write(Tex *t, Fb *fb, bool depth) {
+    const int w = t->pub.width, h = t->pub.height;
     hipStream_t st = begin_texture_write(t, fb);
-    rz_depth_to_texture_kernel<<<dim3((w + 15) / 16, (h + 15) / 16), dim3(256), 0, st>>>(
-        fb->d_depth, (float*)t->d_data, w, h, t->flags, t->mbits);
+    if (depth)
+        rz_depth_to_texture_kernel<<<dim3((w + 15) / 16, (h + 15) / 16), dim3(256), 0, st>>>(
+            fb->d_depth, (float*)t->d_data, w, h, t->flags, t->mbits);
+    else
+        rz_color_to_texture_kernel<<<dim3((w + 15) / 16, (h + 15) / 16), dim3(256), 0, st>>>(
+            fb->d_color, (float4*)t->d_data, w, h, t->flags, t->mbits);
     HIP_OK(hipGetLastError());
     end_texture_write(t, fb);
 }
 
+/* texture.c:130-158.  When the framebuffer still has recorded draws the copy is recorded too, behind
+ * them, and runs at the next flush between the passes on either side of it: a frame made of a
+ * shadow pass, this copy and a main pass that samples the texture then needs no flush of its own,
+ * and a caller that alternates between several shadow buffers gets several frames into one
+ * flush.  A texture that recorded draws already refer to is never overwritten behind their back:
+ * that case flushes first. */
+static void texture_from_buffer(Tex *t, Fb *fb, bool depth, const char *who) {
+    if (t->pub.width != fb->pub.width || t->pub.height != fb->pub.height) fatal("%s: size mismatch", who);
+    const bool in_use = t->pending_write || (!g.pending.empty() && t->used_epoch == g.flush_epoch);
+    if (!has_pending_for(fb) || in_use || !g.record_copies) {
+        graphics_flush();
+        apply_pending_clear(fb);
+        if (depth) device_image(t, RZ_TEX_R32F, sizeof(float));
+        else device_image(t, 0, sizeof(float4));
+        launch_texture_write(t, fb, depth);
+        return;
+    }
+    if (depth) device_image(t, RZ_TEX_R32F, sizeof(float));
+    else device_image(t, 0, sizeof(float4));
+    g.tex_writes.push_back({t, fb, depth, g.pending.size()});
+    t->pending_write = true;
+    t->device_stale = false;
+    t->host_stale = true;
+}
+
+extern "C" void texture_from_depthbuffer(rz_texture *tp, rz_framebuffer *fp) {   /* texture.c:147 */
+    texture_from_buffer(as_tex(tp), as_fb(fp), true, "texture_from_depthbuffer");
+}
+
 extern "C" void texture_from_colorbuffer(rz_texture *tp, rz_framebuffer *fp) {   /* texture.c:130 */
-    Tex *t = as_tex(tp);
-    Fb *fb = as_fb(fp);
-    if (t->pub.width != fb->pub.width || t->pub.height != fb->pub.height) fatal("texture_from_colorbuffer: size mismatch");
-    graphics_flush();
-    apply_pending_clear(fb);
-    device_image(t, 0, sizeof(float4));
-    int w = t->pub.width, h = t->pub.height;
-    hipStream_t st = begin_texture_write(t, fb);
-    rz_color_to_texture_kernel<<<dim3((w + 15) / 16, (h + 15) / 16), dim3(256), 0, st>>>(
-        fb->d_color, (float4*)t->d_data, w, h, t->flags, t->mbits);
-    HIP_OK(hipGetLastError());
-    end_texture_write(t, fb);
+    texture_from_buffer(as_tex(tp), as_fb(fp), false, "texture_from_colorbuffer");
 }
 
 /* Host-side accessors with the reference's addressing (texture.c:160-273).
@@ -826,10 +856,26 @@ extern "C" void mesh_invalidate(const rz_vertex *verts) {
 static void copy_floats(float *dst, const void *src, int n) { memcpy(dst, src, sizeof(float) * n); }
 
 /* uniform block (host layout, host pointers) -> DrawRec (device form) */
+static void snapshot_uniforms_once(rz_program *p, Pending &pd, int num_joints);
+
+/* Resolving a texture can upload it, and an upload flushes what is recorded -- recorded
+ * framebuffer copies included, which changes how a texture resolved a moment ago has to be waited
+ * for.  A snapshot during which a flush happened is therefore taken again (nothing is left to
+ * upload the second time). */
 static void snapshot_uniforms(rz_program *p, Pending &pd, int num_joints) {
+    for (int attempt = 0; attempt < 3; attempt++) {
+        const unsigned long long epoch = g.flush_epoch;
+        snapshot_uniforms_once(p, pd, num_joints);
+        if (g.flush_epoch == epoch) return;
+    }
+    fatal("textures keep being uploaded while a draw is recorded");
+}
+
+static void snapshot_uniforms_once(rz_program *p, Pending &pd, int num_joints) {
     DrawRec &r = pd.rec;
     memset(&r, 0, sizeof r);
     g.current_gpu_textures.clear();
+    g.current_pending_textures.clear();
     r.family = p->family;
     r.flags = (p->double_sided ? RZ_DRAW_DOUBLE_SIDED : 0) | (p->blend ? RZ_DRAW_BLEND : 0);
     const rz_mat4 *joints = nullptr;
@@ -859,7 +905,7 @@ static void snapshot_uniforms(rz_program *p, Pending &pd, int num_joints) {
         joint_normals = u->joint_n_matrices;
         r.ambient = u->ambient_intensity;
         r.punctual = u->punctual_intensity;
-        r.shadow_map = dev_tex(u->shadow_map);
+        if (!u->shadow_pass) r.shadow_map = dev_tex(u->shadow_map);     /* the shadow pass renders it, it does not sample it */
         copy_floats(r.base, &u->basecolor, 4);
         r.shininess = u->shininess;
         r.maps[0] = dev_tex(u->diffuse_map);
@@ -880,7 +926,7 @@ static void snapshot_uniforms(rz_program *p, Pending &pd, int num_joints) {
         joint_normals = u->joint_n_matrices;
         r.ambient = u->ambient_intensity;
         r.punctual = u->punctual_intensity;
-        r.shadow_map = dev_tex(u->shadow_map);
+        if (!u->shadow_pass) r.shadow_map = dev_tex(u->shadow_map);     /* the shadow pass renders it, it does not sample it */
         r.workflow = u->workflow;
         if (u->workflow == 0) {
             copy_floats(r.base, &u->basecolor_factor, 4);
@@ -912,6 +958,7 @@ static void snapshot_uniforms(rz_program *p, Pending &pd, int num_joints) {
         if (narrow) r.flags |= RZ_DRAW_NARROW_TEXELS;
     }
     pd.gpu_textures = g.current_gpu_textures;
+    pd.pending_textures = g.current_pending_textures;
     /* joint matrices are rewritten in place by the skeleton every frame
      * (skeleton.c:336-337): copy them now */
     pd.num_joints = 0;
@@ -965,7 +1012,8 @@ extern "C" void graphics_draw_triangle(rz_framebuffer *fp, rz_program *program) 
     const char *ub = (const char*)program->uniforms;
     if (!g.pending.empty()) {
         Pending &last = g.pending.back();
-        if (last.transient && last.fb == fb && last.program == program && last.num_joints == 0 &&
+        const bool copy_between = !g.tex_writes.empty() && g.tex_writes.back().after == g.pending.size();
+        if (!copy_between && last.transient && last.fb == fb && last.program == program && last.num_joints == 0 &&
             last.uniform_bytes.size() == (size_t)program->uniform_bytes &&
             memcmp(last.uniform_bytes.data(), ub, program->uniform_bytes) == 0) {
             last.verts.insert(last.verts.end(), tri, tri + 3);
@@ -1317,7 +1365,11 @@ extern "C" void graphics_flush(void) {
          * the draws before it need no colour below them and go through the split rasteriser and
          * the per-family shade kernels, only the rest needs ordered in-kernel shading. */
         const bool starts_blended = (g.pending[first].rec.flags & RZ_DRAW_BLEND) != 0;
-        while (last < n && g.pending[last].fb == g.pending[first].fb &&
+        auto copy_point = [&](size_t at) {      /* a recorded copy of this framebuffer sits in front of draw `at` */
+            for (auto &w : g.tex_writes) if (w.after == at && w.fb == g.pending[first].fb) return true;
+            return false;
+        };
+        while (last < n && g.pending[last].fb == g.pending[first].fb && !copy_point(last) &&
                (starts_blended || !(g.pending[last].rec.flags & RZ_DRAW_BLEND))) last++;
         PassPlan pl;
         pl.first = first;
@@ -1339,13 +1391,34 @@ extern "C" void graphics_flush(void) {
      * are taken level by level: level = number of earlier passes into the same framebuffer.  A
      * batch holds passes of one level and one kind of rasteriser, in submission order. */
     std::vector<Batch> batches;
+    std::unordered_map<size_t, std::vector<Context::TexWrite*>> copies_after;   /* pass -> the recorded copies it feeds */
     {
-        std::unordered_map<Fb*, int> depth_of;
+        /* a recorded copy runs behind the last pass into its framebuffer that ends at or before it;
+         * a pass that samples the copied texture comes one level after that pass */
+        std::unordered_map<Tex*, size_t> producer;
+        for (auto &w : g.tex_writes) {
+            size_t found = plans.size();
+            for (size_t i = 0; i < plans.size(); i++)
+                if (plans[i].fb == w.fb && plans[i].last <= w.after) found = i;
+            if (found == plans.size()) fatal("a recorded framebuffer copy has no pass to follow");
+            producer[w.tex] = found;
+            copies_after[found].push_back(&w);
+        }
+        std::unordered_map<Fb*, int> last_level;
         std::vector<int> level(plans.size());
         int levels = 0;
         for (size_t i = 0; i < plans.size(); i++) {
-            level[i] = depth_of[plans[i].fb]++;
-            levels = std::max(levels, level[i] + 1);
+            auto seen = last_level.find(plans[i].fb);
+            int l = seen == last_level.end() ? 0 : seen->second + 1;
+            for (size_t d = plans[i].first; d < plans[i].last; d++)
+                for (Tex *t : g.pending[d].pending_textures) {
+                    auto from = producer.find(t);
+                    if (from == producer.end() || from->second >= i) fatal("a draw samples a texture whose copy is not recorded before it");
+                    l = std::max(l, level[from->second] + 1);
+                }
+            level[i] = l;
+            last_level[plans[i].fb] = l;
+            levels = std::max(levels, l + 1);
         }
         size_t params_used = 0;
         for (int l = 0; l < levels; l++) {
@@ -1392,9 +1465,12 @@ extern "C" void graphics_flush(void) {
             if (pl.fb->lane >= 0 && pl.fb->lane != b.lane)      /* last touched on another lane */
                 HIP_OK(hipStreamWaitEvent(L.stream, new_event(g.lanes[pl.fb->lane].stream), 0));
             pl.fb->lane = b.lane;
-            for (size_t d = pl.first; d < pl.last; d++)
+            for (size_t d = pl.first; d < pl.last; d++) {
                 for (Tex *t : g.pending[d].gpu_textures)
                     if (std::find(sampled.begin(), sampled.end(), t) == sampled.end()) sampled.push_back(t);
+                for (Tex *t : g.pending[d].pending_textures)    /* its copy followed a batch of a lower level: launched by now */
+                    if (std::find(sampled.begin(), sampled.end(), t) == sampled.end()) sampled.push_back(t);
+            }
         }
         for (Tex *t : sampled)
             if (t->write_event && t->write_lane != b.lane) HIP_OK(hipStreamWaitEvent(L.stream, t->write_event, 0));
@@ -1402,6 +1478,14 @@ extern "C" void graphics_flush(void) {
         if (!sampled.empty()) {
             hipEvent_t done = new_event(L.stream);
             for (Tex *t : sampled) t->read_events.push_back(done);
+        }
+        for (size_t i : b.members) {
+            auto copies = copies_after.find(i);
+            if (copies == copies_after.end()) continue;
+            for (Context::TexWrite *w : copies->second) {
+                launch_texture_write(w->tex, w->fb, w->depth);      /* on the framebuffer's lane = this batch's */
+                w->tex->pending_write = false;
+            }
         }
     }
     /* control blocks come back once every lane of this flush has finished */
@@ -1411,6 +1495,8 @@ extern "C" void graphics_flush(void) {
     for (size_t i = 0; i < plans.size(); i++) g.control_slots.push_back(at + CONTROL_BYTES * i);
     g.pending.clear();
     g.side.clear();
+    g.tex_writes.clear();
+    g.flush_epoch++;
 }
 
 /* --------------------------------------------------------------- inspection -- */

@@ -55,14 +55,21 @@ typedef struct {                /* renderer/core/scene.h:25-40 */
     float distance;
 } model_t;
 
+#define RZS_SHADOW_RING 16
+
 struct rzs_scene {              /* renderer/core/scene.h:42-52 */
     rz_vec4 background;
     model_t *skybox;
     model_t **models;
     int num_models;
     float ambient, punctual;
-    rz_framebuffer *shadow_buffer;
-    rz_texture *shadow_map;
+    /* Shadow buffer and map, RZS_SHADOW_RING of each, taken in turn by successive frames: a frame
+     * then never overwrites what the frames before it still sample, so the GPU library can keep
+     * several frames (shadow pass, copy, main pass each) in one flush (scene.c:10-27 has one of
+     * each, and with one the library has to finish every frame before the next starts). */
+    rz_framebuffer *shadow_buffer, *shadow_buffers[RZS_SHADOW_RING];
+    rz_texture *shadow_map, *shadow_maps[RZS_SHADOW_RING];
+    int shadow_turn;
 };
 
 /* ======================= models ========================================= */
@@ -446,8 +453,13 @@ static rzs_scene *scene_from_scn(const char *filename, rz_mat4 root) {
     scene->ambient = ambient;
     scene->punctual = punctual;
     if (shadow_w > 0 && shadow_h > 0) {
-        scene->shadow_buffer = framebuffer_create(shadow_w, shadow_h);
-        scene->shadow_map = texture_create(shadow_w, shadow_h);
+        int k;
+        for (k = 0; k < RZS_SHADOW_RING; k++) {
+            scene->shadow_buffers[k] = framebuffer_create(shadow_w, shadow_h);
+            scene->shadow_maps[k] = texture_create(shadow_w, shadow_h);
+        }
+        scene->shadow_buffer = scene->shadow_buffers[0];
+        scene->shadow_map = scene->shadow_maps[0];
     }
     return scene;
 }
@@ -549,8 +561,13 @@ void rzs_scene_close(rzs_scene *scene) {            /* scene.c:29-48 */
     model_free(scene->skybox);
     for (i = 0; i < scene->num_models; i++) model_free(scene->models[i]);
     free(scene->models);
-    if (scene->shadow_buffer) framebuffer_release(scene->shadow_buffer);
-    if (scene->shadow_map) texture_release(scene->shadow_map);
+    if (scene->shadow_buffer) {
+        int k;
+        for (k = 0; k < RZS_SHADOW_RING; k++) {
+            framebuffer_release(scene->shadow_buffers[k]);
+            texture_release(scene->shadow_maps[k]);
+        }
+    }
     free(scene);
 }
 
@@ -644,6 +661,11 @@ static void scene_draw(rzs_scene *scene, rz_framebuffer *fb, const rzs_view *vie
     f.light_proj = hm_m4_orthographic(1, 1, 0, 2);
     f.camera_view = hm_m4_lookat(eye, target, up);
     f.camera_proj = hm_m4_perspective(RZ_RADIANS(60), aspect, 0.1f, 10000);
+    if (scene->shadow_buffer) {
+        const int slot = scene->shadow_turn++ % RZS_SHADOW_RING;
+        scene->shadow_buffer = scene->shadow_buffers[slot];
+        scene->shadow_map = scene->shadow_maps[slot];
+    }
     f.ambient = scene->ambient;
     f.punctual = scene->punctual;
     f.shadow_map = scene->shadow_map;

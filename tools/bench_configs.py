@@ -53,7 +53,7 @@ def main():
         orbit.render_views(gpu, scene, fbs, views)
         passes, sequences, ms = gpu.kernel_times()
         gpu.lib.mi355r_enable_timing(0)
-        print(json.dumps({"config": label, "fps": round(steps * frames / dt, 1), "fps_with_readback": round(steps * frames / dt_host, 1), "passes_per_frame": passes / frames,
+        print(json.dumps({"config": label, "fps": round(steps * frames / dt, 1), "fps_with_readback": round(steps * frames / dt_host, 1), "passes_per_frame": passes / frames, "launch_sequences_per_frame": round(sequences / frames, 2),
                           "kernel_us_per_frame": {k: round(v / frames * 1e3, 1) for k, v in ms.items()}}))
         for fb in fbs:
             gpu.release(fb)

@@ -5,11 +5,15 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 import torch
 from renderer_amd import orbit
-from renderer_amd.binding import Pipeline, GPU_LIB
+from renderer_amd.binding import Pipeline, GPU_LIB, SCENES
 gpu = Pipeline(GPU_LIB)
-scene = gpu.open_scene("helmet")
+# usage: host_cost.py [scene or .scn under scenes/] [catalogue name for its root transform] [width height]
+name = sys.argv[1] if len(sys.argv) > 1 else "helmet"
+like = sys.argv[2] if len(sys.argv) > 2 and sys.argv[2] != "-" else None
+W, H = (int(sys.argv[3]), int(sys.argv[4])) if len(sys.argv) > 4 else (1920, 1080)
+scene = gpu.open_scene(os.path.join(SCENES, name) if name.endswith(".scn") else name, like)
 B = 32
-fbs = [gpu.framebuffer(1920, 1080) for _ in range(B)]
+fbs = [gpu.framebuffer(W, H) for _ in range(B)]
 views = [gpu.orbit_view(i, 64) for i in range(B)]
 for _ in range(3):
     orbit.render_views(gpu, scene, fbs, views)
