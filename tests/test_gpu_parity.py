@@ -129,6 +129,40 @@ def test_gpu_batched_frames_equal_single_frames(gpu):
     assert np.all(single[0][0][..., 3] == 255)
 
 
+@pytest.mark.parametrize("name,like,size", [("azura_shadow.scn", "azura", (200, 150)), ("synthetic_blinn.scn", None, (224, 126)),
+                                            ("kgirl_blend.scn", "kgirl", (192, 108))])
+def test_gpu_shadowed_frames_recorded_together_match_oracle(gpu, oracle, name, like, size):
+    """Frames with a shadow pass, a framebuffer -> texture copy and a main (+ blended) pass each,
+    recorded one after the other and read only at the end: the copies are recorded between the
+    draws and the frames share launch sequences.  20 frames, more than the scene layer has shadow
+    buffers to alternate between, so the case where a shadow map comes round again while recorded
+    draws still sample it (which has to flush) is part of it.  Every frame against the oracle's."""
+    import os
+    from renderer_amd.binding import SCENES
+    path = os.path.join(SCENES, name)
+    n = 20
+    scene = gpu.open_scene(path, like)
+    views = [gpu.orbit_view(i, n) for i in range(n)]
+    gpu.render(scene, size[0], size[1], views[0])       # uploads
+    fbs = [gpu.framebuffer(*size) for _ in range(n)]
+    gpu.lib.mi355r_enable_timing(1)
+    gpu.kernel_times()                                  # start counting from here
+    for fb, v in zip(fbs, views):
+        gpu.draw(scene, fb, v)
+    got = [gpu.read(fb) for fb in fbs]
+    passes, sequences, _ = gpu.kernel_times()
+    gpu.lib.mi355r_enable_timing(0)
+    for fb in fbs:
+        gpu.release(fb)
+    gpu.close_scene(scene)
+    assert passes >= 2 * n and sequences <= passes // 4, (passes, sequences)     # frames did share launches
+    scene = oracle.open_scene(path, like)
+    for i in (0, 1, 7, 15, 16, 17, 19):
+        want = oracle.render(scene, size[0], size[1], oracle.orbit_view(i, n))
+        assert_same(got[i], want, size[0] * size[1])
+    oracle.close_scene(scene)
+
+
 def test_gpu_counters_match_oracle_workload(gpu, oracle):
     """Triangles in, triangles rasterised and fragments shaded (graphics.c:437 calls) of one frame."""
     size = (480, 270)

@@ -129,7 +129,7 @@ sys.exit(0 if bad == 0 else 1)
 @pytest.mark.gpu
 @pytest.mark.parametrize("env", [{"MI355R_PACK": "0"}, {"MI355R_NARROW_RASTER": "1"}, {"MI355R_PPL": "4"},
                                  {"MI355R_LANES": "1", "MI355R_BATCH": "1"}, {"MI355R_MONOLITHIC": "1"},
-                                 {"MI355R_MICRO_AREA": "0"}, {"MI355R_MICRO_MIN_LIST": "0"},
+                                 {"MI355R_MICRO_AREA": "0"}, {"MI355R_MICRO_MIN_LIST": "0"}, {"MI355R_RECORD_COPIES": "0"},
                                  {"MI355R_MICRO_MIN_LIST": "0", "MI355R_MICRO_AREA": "128", "MI355R_PPL": "4"}],
                          ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()))
 def test_gpu_alternative_code_paths_give_the_same_frames(gpu, env):
@@ -137,7 +137,8 @@ def test_gpu_alternative_code_paths_give_the_same_frames(gpu, env):
     same goldens through the other code paths the library keeps (chosen by environment variables
     read when it starts): float4 images only, one or four pixels per lane in the visibility
     kernel, no batching, in-kernel shading for every pass, and the one-triangle-per-lane
-    rasteriser for no triangle / in every bin / for every triangle a block can hold."""
+    rasteriser for no triangle / in every bin / for every triangle a block can hold, and a flush
+    in front of every framebuffer -> texture copy."""
     r = subprocess.run([sys.executable, "-c", VARIANT_SCRIPT % (REPO, os.path.join(REPO, "tests"))],
                        env=dict(os.environ, **env), capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "DIFFS 0" in r.stdout, r.stdout + r.stderr
