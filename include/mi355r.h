@@ -193,6 +193,9 @@ void graphics_draw_triangle(rz_framebuffer *framebuffer, rz_program *program);
 rz_texture *texture_create(int width, int height);                  /* texture.c:12 */
 void texture_release(rz_texture *texture);                          /* texture.c:27 */
 rz_texture *texture_from_file(const char *filename, rz_usage usage);        /* texture.c:108 */
+/* The two copies below run on the device.  While the framebuffer has recorded draws the copy is
+ * recorded behind them and runs at the next flush point, between the passes on either side of it;
+ * texture->buffer on the host is valid only after texture_sync. */
 void texture_from_colorbuffer(rz_texture *texture, rz_framebuffer *framebuffer);  /* texture.c:130 */
 void texture_from_depthbuffer(rz_texture *texture, rz_framebuffer *framebuffer);  /* texture.c:147 */
 rz_vec4 texture_repeat_sample(rz_texture *texture, rz_vec2 texcoord);       /* texture.c:160 */
