@@ -142,6 +142,7 @@ struct Context {
     bool narrow_raster = false;             /* MI355R_NARROW_RASTER=1: one pixel per lane in the visibility pass */
     int pixels_per_lane = 2;                /* MI355R_PPL=4: a wave takes the whole 32x8 tile */
     int micro_min_list = 256;               /* MI355R_MICRO_MIN_LIST: ... only in bins with at least this many list entries */
+    int sky_pixels_per_lane = 2;            /* MI355R_SKY_PPL=1: the one-pixel-per-lane skybox kernel */
     bool record_copies = true;              /* MI355R_RECORD_COPIES=0: texture_from_*buffer always flushes first */
     int micro_area = 32;                    /* MI355R_MICRO_AREA: largest box (pixels of a block) rasterised one triangle per lane; 0 = off */
     int shade_workgroups = 4096;            /* 256-thread workgroups per shade launch (compute units x 16) */
@@ -241,6 +242,8 @@ extern "C" int mi355r_init(int device) {
         if (env) g.narrow_raster = atoi(env) != 0;
         env = getenv("MI355R_PPL");
         if (env) g.pixels_per_lane = atoi(env);
+        env = getenv("MI355R_SKY_PPL");
+        if (env) g.sky_pixels_per_lane = atoi(env) == 1 ? 1 : 2;
         env = getenv("MI355R_RECORD_COPIES");
         if (env) g.record_copies = atoi(env) != 0;
         env = getenv("MI355R_MICRO_AREA");
@@ -1322,8 +1325,12 @@ static void launch_batch(const Batch &b, const std::vector<PassPlan> &plans, cha
         else
             rz_visibility_kernel<2><<<tiles, dim3(128), 0, st>>>(passes, L.bin_list.ptr, L.vary.ptr, L.fan_vary.ptr, db, L.bin_range.ptr);
         stamp();
-        if (b.families & (1 << RZ_FAMILY_SKYBOX))
-            rz_shade_kernel<2><<<tiles, dim3(256), 0, st>>>(passes, L.tri.ptr, L.fan_tri.ptr, L.vary.ptr, L.fan_vary.ptr, db, L.ref.ptr);
+        if (b.families & (1 << RZ_FAMILY_SKYBOX)) {
+            if (g.sky_pixels_per_lane == 2)     /* four per lane: 11.9 us per frame against 11.1 */
+                rz_sky_kernel<2><<<tiles, dim3(128), 0, st>>>(passes, L.tri.ptr, L.fan_tri.ptr, L.vary.ptr, L.fan_vary.ptr, db, L.ref.ptr);
+            else
+                rz_shade_kernel<2><<<tiles, dim3(256), 0, st>>>(passes, L.tri.ptr, L.fan_tri.ptr, L.vary.ptr, L.fan_vary.ptr, db, L.ref.ptr);
+        }
         stamp();
         bool narrow = true;
         for (size_t i : b.members) narrow = narrow && plans[i].narrow_texels;

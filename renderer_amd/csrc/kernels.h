@@ -1332,6 +1332,88 @@ __global__ void __launch_bounds__(256) rz_shade_kernel(const PassParams *__restr
                         (int)blockIdx.x * RZ_TILE_W + (lane & 31), (int)blockIdx.y * RZ_TILE_H + wave * 2 + (lane >> 5));
 }
 
+/* The same for the skybox family with PPL pixels per lane: a wave takes 2 * PPL rows of the tile
+ * (lane = the pixel at (lane & 31, lane >> 5) of its rows and those 2, 4, .. rows below), so the
+ * per-wave work -- the pass's parameters, the triangle's record and varyings, the draw's face
+ * descriptors, all through scalar loads when one sky triangle spans the wave -- is paid once per
+ * 64 * PPL pixels. */
+template <int PPL>
+__global__ void __launch_bounds__(256 / PPL) rz_sky_kernel(const PassParams *__restrict__ passes,
+        const TriRec *__restrict__ tri_base, const TriRec *__restrict__ fan_base,
+        const float *__restrict__ vary_base, const float *__restrict__ fan_vary_base,
+        const char *__restrict__ upload_base, const uint32_t *__restrict__ ref_base) {
+    const PassParams P = passes[blockIdx.z];
+    if ((int)blockIdx.x >= P.tiles_x || (int)blockIdx.y >= P.tiles_y) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const TriRec *tri_table = tri_base + P.tri_off;
+    const TriRec *fan_table = fan_base + (size_t)P.fan_off * RZ_MAX_FAN;
+    const float *vary_table = vary_base + (size_t)P.tri_off * 3 * RZ_VARY_STRIDE;
+    const float *fan_vary_table = fan_vary_base + (size_t)P.fan_off * RZ_MAX_POLY * RZ_VARY_STRIDE;
+    const DrawRec *draw_table = (const DrawRec*)(upload_base + P.draws_off);
+    const uint32_t *ref_table = ref_base + P.ref_off;
+    const int px = (int)blockIdx.x * RZ_TILE_W + (lane & 31);
+    int py[PPL];
+    uint32_t pixel[PPL], myref[PPL];
+    bool want[PPL];
+    bool any_want = false;
+    for (int q = 0; q < PPL; q++) {
+        py[q] = (int)blockIdx.y * RZ_TILE_H + wave * 2 * PPL + 2 * q + (lane >> 5);
+        pixel[q] = (uint32_t)py[q] * (uint32_t)P.width + (uint32_t)px;
+        myref[q] = (px < P.width && py[q] < P.height && !P.debug_skip) ? ref_table[pixel[q]] : RZ_REF_NONE;
+    }
+    for (int q = 0; q < PPL; q++) {
+        want[q] = ((myref[q] >> 28) & 3u) == 2u;        /* RZ_REF_NONE reads as family 3 */
+        any_want |= want[q];
+        myref[q] &= ~RZ_REF_FAMILY_BITS;
+    }
+    if (!__any(any_want)) return;
+    /* the colour below only lends its alpha byte; under a pending clear it is the clear colour */
+    uint32_t ccur[PPL];
+    for (int q = 0; q < PPL; q++) {
+        ccur[q] = P.clear_color;
+        if (want[q] && !P.clear_color_pending) ccur[q] = P.color[pixel[q]];
+    }
+    uint32_t first = 0;
+    bool uniform = true;
+    {
+        uint32_t mine = RZ_REF_NONE;                    /* a reference this lane wants, if any */
+        for (int q = PPL - 1; q >= 0; q--) if (want[q]) mine = myref[q];
+        first = (uint32_t)__builtin_amdgcn_readlane((int)mine, __ffsll((long long)__ballot(any_want)) - 1);
+        for (int q = 0; q < PPL; q++) uniform = uniform && (!want[q] || myref[q] == first);
+    }
+    if (__all(uniform)) {
+        TriRec m;
+        const float *m0, *m1, *m2;
+        fetch_ref(first, tri_table, fan_table, vary_table, fan_vary_table, m, m0, m1, m2);
+        const DrawRec &D = draw_table[RZ_META_DRAW(m.meta)];
+        for (int q = 0; q < PPL; q++) {
+            if (!want[q]) continue;
+            float w0, w1, w2, v[4];
+            pixel_weights(m, px, py[q], w0, w1, w2);
+            const float q0 = m.rw[0] * w0, q1 = m.rw[1] * w1, q2 = m.rw[2] * w2;    /* graphics.c:426-429 */
+            const float norm = 1 / (q0 + q1 + q2);
+            interpolate_lane<3>(m0, m1, m2, q0, q1, q2, norm, v);
+            f4 color = fs_skybox(D, v);
+            color = mk4(d_sat(color.x), d_sat(color.y), d_sat(color.z), d_sat(color.w));     /* graphics.c:452-468; no blending in these passes */
+            P.color[pixel[q]] = pack_rgb(color, ccur[q]);
+        }
+        if (P.counters) {       /* [8] fragments shaded on the device, [9] of those, skybox */
+            unsigned long long n = 0;
+            for (int q = 0; q < PPL; q++) n += (unsigned long long)__popcll(__ballot(want[q]));
+            if (lane == 0) { atomicAdd(P.counters + 8, n); atomicAdd(P.counters + 9, n); }
+        }
+        return;
+    }
+    for (int q = 0; q < PPL; q++) {                     /* an edge of the sky box crosses the wave */
+        if (!__any(want[q])) continue;
+        TriRec m;
+        const float *m0 = vary_table, *m1 = vary_table, *m2 = vary_table;
+        if (want[q]) fetch_ref(myref[q], tri_table, fan_table, vary_table, fan_vary_table, m, m0, m1, m2);
+        shade_lanes<2>(P, draw_table, want[q], m, m0, m1, m2, px, py[q], ccur[q]);
+        if (want[q]) P.color[pixel[q]] = ccur[q];
+    }
+}
+
 /* over the family's work list of tiles: a fixed number of workgroups strides over it, so no wave
  * is spent on a tile without work */
 template <int FAMILY, bool NARROW>

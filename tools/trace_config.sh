@@ -3,7 +3,7 @@
 OUT=gpurun_out/trace_$1
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-timeout -s KILL 240 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 tools/bench_configs.py 4 $1 > "$OUT/trace.log" 2>&1 || { echo "trace failed"; tail -5 "$OUT/trace.log"; exit 1; }
+timeout -s KILL 240 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 tools/bench_configs.py 32 $1 > "$OUT/trace.log" 2>&1 || { echo "trace failed"; tail -5 "$OUT/trace.log"; exit 1; }
 python3 tools/summarize_profile.py "$OUT" 1 > "$OUT/summary.txt" 2>&1
 grep -v "^    " "$OUT/summary.txt"
 python3 - "$OUT" <<'PY'
