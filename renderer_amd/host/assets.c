@@ -426,6 +426,7 @@ void rzh_mesh_free(rzh_mesh *mesh) {
 
 typedef struct {
     int count;
+    int ascending;              /* key times strictly increase: the segment can be found by bisection */
     float *times;
     float *values;              /* count * width floats */
 } track_t;
@@ -452,6 +453,7 @@ static void read_track(FILE *f, const char *label, int width, track_t *t, const 
     snprintf(fmt, sizeof fmt, " %s %%d:", label);
     if (fscanf(f, fmt, &t->count) != 1 || t->count < 0) die("bad ani track", filename);
     t->times = NULL; t->values = NULL;
+    t->ascending = 0;
     if (t->count == 0) return;
     t->times = (float*)xmalloc(sizeof(float) * t->count);
     t->values = (float*)xmalloc(sizeof(float) * t->count * width);
@@ -462,6 +464,8 @@ static void read_track(FILE *f, const char *label, int width, track_t *t, const 
         else got = fscanf(f, " time: %f, value: [%f, %f, %f, %f]", &t->times[i], &v[0], &v[1], &v[2], &v[3]);
         if (got != width + 1) die("bad ani key", filename);
     }
+    t->ascending = 1;
+    for (i = 1; i < t->count; i++) if (!(t->times[i - 1] < t->times[i])) t->ascending = 0;
 }
 
 /* skeleton.c:142-200 */
@@ -520,6 +524,17 @@ static int track_segment(const track_t *t, float time, float *param) {
     int i;
     if (time <= t->times[0]) return -1;
     if (time >= t->times[t->count - 1]) return -2;
+    if (t->ascending) {
+        /* the one segment with times[i] <= time < times[i + 1] (which is what the scan below finds
+         * first): animations have hundreds of keys per track and an orbit evaluates them per view */
+        int lo = 0, hi = t->count - 1;              /* times[lo] <= time < times[hi] */
+        while (hi - lo > 1) {
+            int mid = (lo + hi) / 2;
+            if (time >= t->times[mid]) lo = mid; else hi = mid;
+        }
+        *param = (time - t->times[lo]) / (t->times[lo + 1] - t->times[lo]);
+        return lo;
+    }
     for (i = 0; i < t->count - 1; i++) {
         float a = t->times[i], b = t->times[i + 1];
         if (time >= a && time < b) { *param = (time - a) / (b - a); return i; }
@@ -572,6 +587,21 @@ void rzh_skeleton_update(rzh_skeleton *sk, float frame_time) {
         sk->normal_matrices[i] = hm_m3_inverse_transpose(hm_m3_from_m4(jm));
     }
     sk->cached_time = frame_time;
+}
+
+void rzh_skeleton_use_bisection(rzh_skeleton *sk, int on) {
+    int i, k;
+    for (i = 0; i < sk->num_joints; i++) {
+        track_t *tracks[3];
+        tracks[0] = &sk->joints[i].translation; tracks[1] = &sk->joints[i].rotation; tracks[2] = &sk->joints[i].scale;
+        for (k = 0; k < 3; k++) {
+            track_t *t = tracks[k];
+            int j;
+            t->ascending = on && t->count > 0;
+            for (j = 1; j < t->count; j++) if (!(t->times[j - 1] < t->times[j])) t->ascending = 0;
+        }
+    }
+    sk->cached_time = -1;
 }
 
 rz_mat4 *rzh_skeleton_joint_matrices(rzh_skeleton *sk) { return sk->joint_matrices; }

@@ -211,3 +211,40 @@ def test_per_triangle_submission_equals_mesh_submission(oracle, case):
         oracle.lib.rzs_set_per_triangle(0)
     b = render_case(oracle, case)
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+
+
+@pytest.mark.parametrize("name", ["kgirl/kgirl.ani", "buster/buster.ani", "phoenix/phoenix.ani", "drone/drone.ani", "drone/fire.ani"])
+def test_skeleton_key_bisection_equals_linear_scan(oracle, name):
+    """Host side of the path's caller: joint and normal matrices of a pose are the same bytes whether
+    the key segment of a track is found by bisection (what the scene layer does) or by the
+    reference's linear scan (skeleton.c:231-313), over times inside, between and beyond the keys."""
+    lib = oracle.lib
+    lib.rzh_acquire_skeleton.restype = C.c_void_p
+    lib.rzh_acquire_skeleton.argtypes = [C.c_char_p]
+    lib.rzh_release_skeleton.argtypes = [C.c_void_p]
+    lib.rzh_skeleton_update.argtypes = [C.c_void_p, C.c_float]
+    lib.rzh_skeleton_use_bisection.argtypes = [C.c_void_p, C.c_int]
+    lib.rzh_skeleton_num_joints.argtypes = [C.c_void_p]
+    lib.rzh_skeleton_joint_matrices.restype = C.POINTER(C.c_float)
+    lib.rzh_skeleton_joint_matrices.argtypes = [C.c_void_p]
+    lib.rzh_skeleton_normal_matrices.restype = C.POINTER(C.c_float)
+    lib.rzh_skeleton_normal_matrices.argtypes = [C.c_void_p]
+    sk = lib.rzh_acquire_skeleton(name.encode())
+    n = lib.rzh_skeleton_num_joints(sk)
+    rng = np.random.default_rng(7)
+    times = np.concatenate([rng.uniform(0, 12, 150), np.arange(0, 4, 1 / 30.0), [0.0, 1e-6, 1000.25]]).astype(np.float32)
+
+    def poses():
+        out = []
+        for t in times:
+            lib.rzh_skeleton_update(sk, C.c_float(float(t)))
+            out.append(np.ctypeslib.as_array(lib.rzh_skeleton_joint_matrices(sk), (n * 16,)).copy().view(np.uint32))
+            out.append(np.ctypeslib.as_array(lib.rzh_skeleton_normal_matrices(sk), (n * 9,)).copy().view(np.uint32))
+        return out
+    lib.rzh_skeleton_use_bisection(sk, 1)
+    fast = poses()
+    lib.rzh_skeleton_use_bisection(sk, 0)
+    slow = poses()
+    lib.rzh_skeleton_use_bisection(sk, 1)
+    lib.rzh_release_skeleton(sk)
+    assert all(np.array_equal(a, b) for a, b in zip(fast, slow))
