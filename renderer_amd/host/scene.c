@@ -55,7 +55,7 @@ typedef struct {                /* renderer/core/scene.h:25-40 */
     float distance;
 } model_t;
 
-#define RZS_SHADOW_RING 16
+#define RZS_SHADOW_RING 32
 
 struct rzs_scene {              /* renderer/core/scene.h:42-52 */
     rz_vec4 background;
