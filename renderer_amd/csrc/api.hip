@@ -1313,7 +1313,13 @@ static void launch_batch(const Batch &b, const std::vector<PassPlan> &plans, cha
     stamp();
     if (b.has_blend) {
         /* blended fragments read the colour below them: visibility and shading stay in one kernel */
-        rz_raster_kernel<false><<<tiles, dim3(256), 0, st>>>(
+        bool narrow = true;
+        for (size_t i : b.members) narrow = narrow && plans[i].narrow_texels;
+        auto kernel = rz_raster_kernel<false>;
+        if (b.families == (1 << RZ_FAMILY_BLINN)) kernel = narrow ? rz_raster_kernel<false, 0, true> : rz_raster_kernel<false, 0, false>;
+        if (b.families == (1 << RZ_FAMILY_PBR)) kernel = narrow ? rz_raster_kernel<false, 1, true> : rz_raster_kernel<false, 1, false>;
+        if (getenv("MI355R_GENERIC_BLEND")) kernel = rz_raster_kernel<false>;
+        kernel<<<tiles, dim3(256), 0, st>>>(
             passes, L.tri.ptr, L.fan_tri.ptr, L.bin_list.ptr, L.vary.ptr, L.fan_vary.ptr, db, L.bin_range.ptr);
         stamp(); stamp(); stamp(); stamp();
     } else {

@@ -818,13 +818,15 @@ RZ_DEV bool block_outside(float4 c0, float4 c1, float x0, float x1, float y0, fl
 /* Rasteriser.  SPLIT = true: the pass has no blended draw, so one reference per
  * pixel is enough; the kernel resolves visibility only and leaves depth plus the
  * reference of the visible fragment for the per-family shade kernels.
- * SPLIT = false: general form with the two-level stack, shading in-kernel.
+ * SPLIT = false: general form with the two-level stack, shading in-kernel; FAMILY >= 0 when every
+ * draw of every pass of the batch is of that one family (only its shader is compiled in, which
+ * halves the registers of a blinn-only kernel), NARROW when all their images are 4-byte formats.
  *
  * The read-only tables come in as separate const __restrict__ arguments so
  * that wave-uniform reads of them are issued as scalar loads.  Per 64 list
  * entries the candidates' records are fetched lane-parallel (one memory round
  * trip for all of them) and then broadcast one at a time in list order. */
-template <bool SPLIT>
+template <bool SPLIT, int FAMILY = -1, bool NARROW = false>
 __global__ void __launch_bounds__(256) rz_raster_kernel(const PassParams *__restrict__ passes,
         const TriRec *__restrict__ tri_base, const TriRec *__restrict__ fan_base,
         const BinEntry *__restrict__ list_base,
@@ -973,7 +975,7 @@ __global__ void __launch_bounds__(256) rz_raster_kernel(const PassParams *__rest
             TriRec m;
             const float *m0 = vary_table, *m1 = vary_table, *m2 = vary_table;
             if (want) fetch_ref(level == 0 ? ref0 : ref1, tri_table, fan_table, vary_table, fan_vary_table, m, m0, m1, m2);
-            shade_lanes<-1>(P, draw_table, want, m, m0, m1, m2, px, py, ccur);
+            shade_lanes<FAMILY, NARROW>(P, draw_table, want, m, m0, m1, m2, px, py, ccur);
         }
         ref0 = ref1 = RZ_REF_NONE;
         depth_of_stack = 0;
