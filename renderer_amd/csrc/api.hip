@@ -143,6 +143,10 @@ struct Context {
     int pixels_per_lane = 2;                /* MI355R_PPL=4: a wave takes the whole 32x8 tile */
     int micro_min_list = 256;               /* MI355R_MICRO_MIN_LIST: ... only in bins with at least this many list entries */
     int sky_pixels_per_lane = 2;            /* MI355R_SKY_PPL=1: the one-pixel-per-lane skybox kernel */
+    /* passes with blended draws: 0 = whole through the ordered kernel, 1 = visibility first and the ordered kernel only for
+     * the tiles that need it, 2 = the latter for large framebuffers (MI355R_SPLIT_BLEND=0 / 1; measured: 4K frames gain 8 %,
+     * 1080p frames lose as much to the three extra launches) */
+    int split_blend = 2;
     bool record_copies = true;              /* MI355R_RECORD_COPIES=0: texture_from_*buffer always flushes first */
     int micro_area = 32;                    /* MI355R_MICRO_AREA: largest box (pixels of a block) rasterised one triangle per lane; 0 = off */
     int shade_workgroups = 4096;            /* 256-thread workgroups per shade launch (compute units x 16) */
@@ -244,6 +248,9 @@ extern "C" int mi355r_init(int device) {
         if (env) g.pixels_per_lane = atoi(env);
         env = getenv("MI355R_SKY_PPL");
         if (env) g.sky_pixels_per_lane = atoi(env) == 1 ? 1 : 2;
+        env = getenv("MI355R_SPLIT_BLEND");
+        if (env) g.split_blend = atoi(env) != 0 ? 1 : 0;
+        if (getenv("MI355R_MONOLITHIC")) g.split_blend = 0;        /* every pass through the ordered kernel */
         env = getenv("MI355R_RECORD_COPIES");
         if (env) g.record_copies = atoi(env) != 0;
         env = getenv("MI355R_MICRO_AREA");
@@ -1151,6 +1158,12 @@ struct Batch {
     int families;
 };
 
+/* whether a batch of passes with blended draws takes the visibility-first route */
+static bool splits_blend(size_t batch_tiles, size_t passes) {
+    if (g.counting || g.split_blend == 0) return false;
+    return g.split_blend == 1 || batch_tiles >= 16384 * passes;
+}
+
 /* sizes the lane's scratch for the batch and (second call) writes the PassParams array */
 static void prepare_batch(const Batch &b, const std::vector<PassPlan> &plans, char *hb, char *db, size_t controls_at,
                           bool reserve_only) {
@@ -1180,10 +1193,10 @@ static void prepare_batch(const Batch &b, const std::vector<PassPlan> &plans, ch
     /* tiles are dealt to the parts of a list by their index: a part holds at most its even share */
     const size_t queue_capacity = (tiles + RZ_QUEUE_WAYS - 1) / RZ_QUEUE_WAYS;
     reserve(L.tile_listed, tiles, st);
-    reserve(L.queue, 2 * RZ_QUEUE_WAYS * queue_capacity, st);
-    reserve(L.queue_counts, 2 * RZ_QUEUE_WAYS * RZ_QUEUE_PAD, st);
+    reserve(L.queue, 3 * RZ_QUEUE_WAYS * queue_capacity, st);           /* blinn, pbr, RZ_ORDERED_LIST */
+    reserve(L.queue_counts, 3 * RZ_QUEUE_WAYS * RZ_QUEUE_PAD, st);
     reserve(L.bin_list, lists, st);
-    if (!b.has_blend) reserve(L.ref, pixels, st);
+    if (!b.has_blend || splits_blend(tiles, b.members.size())) reserve(L.ref, pixels, st);
     if (reserve_only) return;
 
     size_t tri_off = 0, fan_off = 0, list_off = 0, bin_off = 0, ref_off = 0, matrix_off = 0, tile_off = 0;
@@ -1292,6 +1305,15 @@ static void launch_batch(const Batch &b, const std::vector<PassPlan> &plans, cha
         batch_tiles += (size_t)((plans[i].fb->pub.width + RZ_TILE_W - 1) / RZ_TILE_W) * ((plans[i].fb->pub.height + RZ_TILE_H - 1) / RZ_TILE_H);
     const uint32_t queue_capacity = (uint32_t)((batch_tiles + RZ_QUEUE_WAYS - 1) / RZ_QUEUE_WAYS);
     const dim3 shade_grid((unsigned)std::min<size_t>(max_tiles_x * max_tiles_y * n, (size_t)g.shade_workgroups));
+    {
+        /* what the kernels below index without a check of their own: wrong sizes here must stop the host, not fault the GPU */
+        size_t pixels = 0, tris = 0;
+        for (size_t i : b.members) { pixels += (size_t)plans[i].fb->pub.width * plans[i].fb->pub.height; tris += plans[i].T; }
+        const bool uses_ref = !(b.has_blend && !splits_blend(batch_tiles, n));
+        if (L.queue_counts.cap < 3 * RZ_QUEUE_WAYS * RZ_QUEUE_PAD || L.queue.cap < 3 * RZ_QUEUE_WAYS * (size_t)queue_capacity ||
+            L.tile_listed.cap < batch_tiles || (uses_ref && (!L.ref.ptr || L.ref.cap < pixels)) || L.tri.cap < tris || L.bbox.cap < tris)
+            fatal("scratch of lane %d is smaller than the batch it is about to run", b.lane);
+    }
     stamp();
     rz_vertex_kernel<<<vgrid, dim3(256), 0, st>>>(passes);
     stamp();
@@ -1311,19 +1333,30 @@ static void launch_batch(const Batch &b, const std::vector<PassPlan> &plans, cha
     rz_bin_scan_kernel<<<dim3((unsigned)((max_bins + 63) / 64), n), dim3(64 * RZ_SCAN_SEGMENTS), 0, st>>>(passes);
     rz_bin_fill_kernel<<<dim3((unsigned)((max_T + 63) / 64), n), dim3(64 * RZ_FILL_WAVES), 0, st>>>(passes);
     stamp();
-    if (b.has_blend) {
-        /* blended fragments read the colour below them: visibility and shading stay in one kernel */
-        bool narrow = true;
-        for (size_t i : b.members) narrow = narrow && plans[i].narrow_texels;
+    bool narrow = true;
+    for (size_t i : b.members) narrow = narrow && plans[i].narrow_texels;
+    /* a pass with blended draws: either everything in the ordered kernel (visibility and shading
+     * together, fragment stacks), or visibility first, the ordered kernel for the tiles where
+     * blended fragments pile up and the shade kernels for the rest */
+    const bool one_family = !getenv("MI355R_GENERIC_BLEND");
+    const int only = !one_family ? -1 : b.families == (1 << RZ_FAMILY_BLINN) ? 0 : b.families == (1 << RZ_FAMILY_PBR) ? 1 : -1;
+    if (b.has_blend && !splits_blend(batch_tiles, n)) {
         auto kernel = rz_raster_kernel<false>;
-        if (b.families == (1 << RZ_FAMILY_BLINN)) kernel = narrow ? rz_raster_kernel<false, 0, true> : rz_raster_kernel<false, 0, false>;
-        if (b.families == (1 << RZ_FAMILY_PBR)) kernel = narrow ? rz_raster_kernel<false, 1, true> : rz_raster_kernel<false, 1, false>;
-        if (getenv("MI355R_GENERIC_BLEND")) kernel = rz_raster_kernel<false>;
+        if (only == 0) kernel = narrow ? rz_raster_kernel<false, 0, true> : rz_raster_kernel<false, 0, false>;
+        if (only == 1) kernel = narrow ? rz_raster_kernel<false, 1, true> : rz_raster_kernel<false, 1, false>;
         kernel<<<tiles, dim3(256), 0, st>>>(
             passes, L.tri.ptr, L.fan_tri.ptr, L.bin_list.ptr, L.vary.ptr, L.fan_vary.ptr, db, L.bin_range.ptr);
         stamp(); stamp(); stamp(); stamp();
     } else {
-        if (g.narrow_raster)
+        if (b.has_blend) {
+            rz_visibility_kernel<2, true><<<tiles, dim3(128), 0, st>>>(passes, L.bin_list.ptr, L.vary.ptr, L.fan_vary.ptr, db, L.bin_range.ptr);
+            auto kernel = rz_raster_list_kernel<-1, false>;
+            if (only == 0) kernel = narrow ? rz_raster_list_kernel<0, true> : rz_raster_list_kernel<0, false>;
+            if (only == 1) kernel = narrow ? rz_raster_list_kernel<1, true> : rz_raster_list_kernel<1, false>;
+            kernel<<<shade_grid, dim3(256), 0, st>>>(
+                passes, L.tri.ptr, L.fan_tri.ptr, L.bin_list.ptr, L.vary.ptr, L.fan_vary.ptr, db, L.bin_range.ptr,
+                L.queue.ptr, L.queue_counts.ptr, queue_capacity);
+        } else if (g.narrow_raster)
             rz_raster_kernel<true><<<tiles, dim3(256), 0, st>>>(
                 passes, L.tri.ptr, L.fan_tri.ptr, L.bin_list.ptr, L.vary.ptr, L.fan_vary.ptr, db, L.bin_range.ptr);
         else if (g.pixels_per_lane == 4)
@@ -1338,8 +1371,6 @@ static void launch_batch(const Batch &b, const std::vector<PassPlan> &plans, cha
                 rz_shade_kernel<2><<<tiles, dim3(256), 0, st>>>(passes, L.tri.ptr, L.fan_tri.ptr, L.vary.ptr, L.fan_vary.ptr, db, L.ref.ptr);
         }
         stamp();
-        bool narrow = true;
-        for (size_t i : b.members) narrow = narrow && plans[i].narrow_texels;
         if (b.families & (1 << RZ_FAMILY_BLINN)) {
             auto kernel = narrow ? rz_shade_list_kernel<0, true> : rz_shade_list_kernel<0, false>;
             kernel<<<shade_grid, dim3(256), 0, st>>>(passes, L.tri.ptr, L.fan_tri.ptr, L.vary.ptr, L.fan_vary.ptr, db, L.ref.ptr,

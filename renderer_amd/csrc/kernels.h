@@ -62,7 +62,7 @@ __global__ void __launch_bounds__(256) rz_vertex_kernel(const PassParams *__rest
     const PassParams &P = passes[blockIdx.y];
     uint32_t gv = blockIdx.x * 256u + threadIdx.x;
     if (gv < 8u) P.control[gv] = 0;             /* the pass's device-written scalars start at zero */
-    if (blockIdx.y == 0 && gv < 2u * RZ_QUEUE_WAYS) P.queue_counts[gv * RZ_QUEUE_PAD] = 0;    /* ... and the batch's work-list lengths */
+    if (blockIdx.y == 0 && gv < 3u * RZ_QUEUE_WAYS) P.queue_counts[gv * RZ_QUEUE_PAD] = 0;    /* ... and the batch's work-list lengths */
     /* the grid is sized for the largest pass of the batch: all of its threads share the clearing */
     for (uint32_t t = gv; t < (uint32_t)(P.tiles_x * P.tiles_y); t += gridDim.x * 256u) P.tile_listed[t] = 0;
     if (gv >= 3u * (uint32_t)P.num_tris) return;
@@ -826,15 +826,13 @@ RZ_DEV bool block_outside(float4 c0, float4 c1, float x0, float x1, float y0, fl
  * that wave-uniform reads of them are issued as scalar loads.  Per 64 list
  * entries the candidates' records are fetched lane-parallel (one memory round
  * trip for all of them) and then broadcast one at a time in list order. */
-template <bool SPLIT, int FAMILY = -1, bool NARROW = false>
-__global__ void __launch_bounds__(256) rz_raster_kernel(const PassParams *__restrict__ passes,
+template <bool SPLIT, int FAMILY, bool NARROW>
+RZ_DEV void raster_tile(const PassParams &P, const uint32_t pass_index, const uint32_t tile_x, const uint32_t tile_y,
         const TriRec *__restrict__ tri_base, const TriRec *__restrict__ fan_base,
         const BinEntry *__restrict__ list_base,
         const float *__restrict__ vary_base, const float *__restrict__ fan_vary_base,
         const char *__restrict__ upload_base, const uint2 *__restrict__ bin_range_base) {
-    /* grid: x, y = tile column / row, z = pass of the batch */
-    const PassParams P = passes[blockIdx.z];          /* by value: one burst of scalar loads up front, not one wait per field */
-    if ((int)blockIdx.x >= P.tiles_x || (int)blockIdx.y >= P.tiles_y) return;
+    if ((int)tile_x >= P.tiles_x || (int)tile_y >= P.tiles_y) return;
     /* this pass's slices of the batch-wide tables */
     const TriRec *tri_table = tri_base + P.tri_off;
     const TriRec *fan_table = fan_base + (size_t)P.fan_off * RZ_MAX_FAN;
@@ -846,7 +844,7 @@ __global__ void __launch_bounds__(256) rz_raster_kernel(const PassParams *__rest
     /* A workgroup owns a 32x8-pixel tile, wave w its w-th 8x8 block, lane = pixel. */
     if (P.debug_skip == 3) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int tx0 = (int)blockIdx.x * RZ_TILE_W, ty0 = (int)blockIdx.y * RZ_TILE_H;
+    const int tx0 = (int)tile_x * RZ_TILE_W, ty0 = (int)tile_y * RZ_TILE_H;
     const int bx0 = tx0 + wave * 8, by0 = ty0;
     const int px = bx0 + (lane & 7), py = by0 + (lane >> 3);
     const bool valid = px < P.width && py < P.height;
@@ -1004,14 +1002,14 @@ __global__ void __launch_bounds__(256) rz_raster_kernel(const PassParams *__rest
         for (uint32_t f = 0; f < 2; f++) {
             if (!__any(depth_of_stack && family == f)) continue;
             if (lane == 0) {
-                const uint32_t tile = blockIdx.y * (uint32_t)P.tiles_x + blockIdx.x;
+                const uint32_t tile = tile_y * (uint32_t)P.tiles_x + tile_x;
                 const uint32_t before = atomicOr(&P.tile_listed[tile], 1u << f);
                 if (!(before >> f & 1u)) {
                     /* by the tile's index in the batch: no part can get more than its even share */
                     const uint32_t part = f * RZ_QUEUE_WAYS + ((P.tile_off + tile) & (RZ_QUEUE_WAYS - 1u));
                     const uint32_t at = atomicAdd(&P.queue_counts[part * RZ_QUEUE_PAD], 1u);
                     if (at < P.queue_capacity)
-                        P.queue[(size_t)part * P.queue_capacity + at] = ((uint32_t)blockIdx.z << 20) | ((uint32_t)blockIdx.y << 9) | (uint32_t)blockIdx.x;
+                        P.queue[(size_t)part * P.queue_capacity + at] = (pass_index << 20) | (tile_y << 9) | tile_x;
                     else
                         atomicOr(&P.control[2], (uint32_t)RZ_ERR_QUEUE_OVERFLOW);
                 }
@@ -1020,12 +1018,48 @@ __global__ void __launch_bounds__(256) rz_raster_kernel(const PassParams *__rest
     }
 }
 
+/* over every tile of every pass: grid x, y = tile column / row, z = pass of the batch */
+template <bool SPLIT, int FAMILY = -1, bool NARROW = false>
+__global__ void __launch_bounds__(256) rz_raster_kernel(const PassParams *__restrict__ passes,
+        const TriRec *__restrict__ tri_base, const TriRec *__restrict__ fan_base,
+        const BinEntry *__restrict__ list_base,
+        const float *__restrict__ vary_base, const float *__restrict__ fan_vary_base,
+        const char *__restrict__ upload_base, const uint2 *__restrict__ bin_range_base) {
+    const PassParams P = passes[blockIdx.z];          /* by value: one burst of scalar loads up front, not one wait per field */
+    raster_tile<SPLIT, FAMILY, NARROW>(P, blockIdx.z, blockIdx.x, blockIdx.y, tri_base, fan_base, list_base, vary_base, fan_vary_base,
+                                       upload_base, bin_range_base);
+}
+
+/* over the batch's list of tiles that need ordered shading (RZ_ORDERED_LIST, filled by
+ * rz_visibility_kernel<.., true>): a fixed number of workgroups strides over it */
+template <int FAMILY, bool NARROW>
+__global__ void __launch_bounds__(256) rz_raster_list_kernel(const PassParams *__restrict__ passes,
+        const TriRec *__restrict__ tri_base, const TriRec *__restrict__ fan_base,
+        const BinEntry *__restrict__ list_base,
+        const float *__restrict__ vary_base, const float *__restrict__ fan_vary_base,
+        const char *__restrict__ upload_base, const uint2 *__restrict__ bin_range_base,
+        const uint32_t *__restrict__ queue_base, const uint32_t *__restrict__ queue_counts, uint32_t queue_capacity) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t my_count = min(queue_counts[(RZ_ORDERED_LIST * RZ_QUEUE_WAYS + lane) * RZ_QUEUE_PAD], queue_capacity);
+    uint32_t longest = my_count;
+    for (int off = 32; off > 0; off >>= 1) longest = max(longest, (uint32_t)__shfl_xor((int)longest, off));
+    longest = (uint32_t)__builtin_amdgcn_readfirstlane((int)longest);
+    for (uint32_t k = blockIdx.x; k < longest * RZ_QUEUE_WAYS; k += gridDim.x) {
+        const uint32_t part = k & (RZ_QUEUE_WAYS - 1u), index = k / RZ_QUEUE_WAYS;
+        if (index >= (uint32_t)__builtin_amdgcn_readlane((int)my_count, (int)part)) continue;
+        const uint32_t item = queue_base[(size_t)(RZ_ORDERED_LIST * RZ_QUEUE_WAYS + part) * queue_capacity + index];
+        const PassParams P = passes[item >> 20];
+        raster_tile<false, FAMILY, NARROW>(P, item >> 20, item & 511u, (item >> 9) & 2047u, tri_base, fan_base, list_base, vary_base,
+                                           fan_vary_base, upload_base, bin_range_base);
+    }
+}
+
 /* K4b  visibility only, for passes without blending (what rz_raster_kernel<true> computes), two
  * (PPL = 2) or four pixels per lane: a wave owns a block of 8*PPL x 8 pixels (lane = the pixel at
  * (lane & 7, lane >> 3) and those 8, 16, .. to its right), a workgroup of 4/PPL waves a 32x8 tile.
  * A fraction 1/PPL of the waves walk the lists, cull candidates and fetch survivors compared with
  * one pixel per lane; only the per-pixel arithmetic is the same.  Leaves depth, the tagged reference of the visible fragment and the shade work lists. */
-template <int PPL>
+template <int PPL, bool BLEND = false>
 __global__ void __launch_bounds__(256 / PPL) rz_visibility_kernel(const PassParams *__restrict__ passes,
         const BinEntry *__restrict__ list_base,
         const float *__restrict__ vary_base, const float *__restrict__ fan_vary_base,
@@ -1080,8 +1114,18 @@ __global__ void __launch_bounds__(256 / PPL) rz_visibility_kernel(const PassPara
     __shared__ uint32_t micro_ring[4 / PPL][128];
     unsigned long long *keys = micro_keys + wave * 64 * PPL;
     uint32_t *ring = micro_ring[wave];
-    /* short lists are not worth the keys' set-up and the final merge */
-    const int micro_area = (P.counters || count < (uint32_t)P.micro_min_list) ? 0 : P.micro_area;
+    /* short lists are not worth the keys' set-up and the final merge; blending needs the order */
+    const int micro_area = (BLEND || P.counters || count < (uint32_t)P.micro_min_list) ? 0 : P.micro_area;
+    /* BLEND: the pass has blended draws.  A blended fragment over nothing else of this pass blends
+     * with the colour the framebuffer holds, which the shade kernels can do; one over another
+     * pending fragment of the pass needs them shaded in order: such a tile is left untouched and
+     * handed to rz_raster_list_kernel. */
+    __shared__ int s_ordered;
+    bool needs_order = false;
+    if (BLEND) {
+        if (threadIdx.x == 0) s_ordered = 0;
+        __syncthreads();
+    }
     uint32_t ring_head = 0, ring_tail = 0;                          /* wave-uniform */
     if (micro_area)
         for (int q = 0; q < PPL; q++) keys[q * 64 + lane] = ~0ull;
@@ -1222,6 +1266,8 @@ __global__ void __launch_bounds__(256 / PPL) rz_visibility_kernel(const PassPara
                 }
             }
             const uint32_t tagged = ref | (RZ_META_FAMILY(r.meta) << 28);
+            if (BLEND && RZ_META_BLEND(r.meta))
+                for (int q = 0; q < PPL; q++) needs_order |= pass[q] && ord_of[q] >= 0;
             for (int q = 0; q < PPL; q++) if (pass[q]) { zcur[q] = depth[q]; ref_of[q] = tagged; ord_of[q] = (int)(group_at + at); }
         }
     }
@@ -1243,6 +1289,23 @@ __global__ void __launch_bounds__(256 / PPL) rz_visibility_kernel(const PassPara
     }
 
     if (P.debug_skip == 8 || P.debug_skip == 10) return;
+    if (BLEND) {
+        if (__any(needs_order) && lane == 0) s_ordered = 1;
+        __syncthreads();
+        if (s_ordered) {
+            for (int q = 0; q < PPL; q++) if (valid[q]) P.ref[pixel[q]] = RZ_REF_NONE;     /* nothing here for the shade kernels */
+            if (threadIdx.x == 0) {
+                const uint32_t tile = blockIdx.y * (uint32_t)P.tiles_x + blockIdx.x;
+                const uint32_t part = RZ_ORDERED_LIST * RZ_QUEUE_WAYS + ((P.tile_off + tile) & (RZ_QUEUE_WAYS - 1u));
+                const uint32_t at = atomicAdd(&P.queue_counts[part * RZ_QUEUE_PAD], 1u);
+                if (at < P.queue_capacity)
+                    P.queue[(size_t)part * P.queue_capacity + at] = ((uint32_t)blockIdx.z << 20) | ((uint32_t)blockIdx.y << 9) | (uint32_t)blockIdx.x;
+                else
+                    atomicOr(&P.control[2], (uint32_t)RZ_ERR_QUEUE_OVERFLOW);
+            }
+            return;
+        }
+    }
     for (int q = 0; q < PPL; q++) {
         if (!valid[q]) continue;
         P.depth[pixel[q]] = zcur[q];

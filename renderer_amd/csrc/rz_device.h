@@ -28,6 +28,8 @@
 #define RZ_MAX_FAN 8                /* RZ_MAX_POLY - 2 */
 #define RZ_BIN 64                   /* bin edge in pixels */
 #define RZ_QUEUE_WAYS 64u           /* parts of a shade work list (one wave reads all the lengths) */
+#define RZ_ORDERED_LIST 2u          /* the third list, after the blinn and pbr families': tiles of a pass with blended draws
+                                     * where a blended fragment lies over another fragment of the pass */
 #define RZ_QUEUE_PAD 32u            /* counters sit one 128-byte line apart: atomics on one line serialise */
 #define RZ_TILE_W 32                /* raster / shade workgroup tile: 4 waves of 8x8 side by side, */
 #define RZ_TILE_H 8                 /* so a tile row is one 128-byte line of a 4-byte plane */

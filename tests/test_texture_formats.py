@@ -117,7 +117,7 @@ from renderer_amd.binding import Pipeline, GPU_LIB
 gpu = Pipeline(GPU_LIB)
 bad = 0
 for case in golden_cases():
-    if case["name"] not in ("helmet_default", "helmet_cutoff", "azura_shadow", "kgirl_blend", "drone_specgloss"):
+    if case["name"] not in ("helmet_default", "helmet_cutoff", "azura_shadow", "kgirl_blend", "drone_specgloss", "dieselpunk_shadow", "synthetic_blinn"):
         continue
     want = load_golden(case["name"]); got = render_case(gpu, case)
     bad += int((got[0] != want[0]).sum()) + int((got[1] != want[1]).sum())
@@ -129,7 +129,7 @@ sys.exit(0 if bad == 0 else 1)
 @pytest.mark.gpu
 @pytest.mark.parametrize("env", [{"MI355R_PACK": "0"}, {"MI355R_NARROW_RASTER": "1"}, {"MI355R_PPL": "4"},
                                  {"MI355R_LANES": "1", "MI355R_BATCH": "1"}, {"MI355R_MONOLITHIC": "1"},
-                                 {"MI355R_MICRO_AREA": "0"}, {"MI355R_MICRO_MIN_LIST": "0"}, {"MI355R_RECORD_COPIES": "0"}, {"MI355R_SKY_PPL": "1"}, {"MI355R_GENERIC_BLEND": "1"},
+                                 {"MI355R_MICRO_AREA": "0"}, {"MI355R_MICRO_MIN_LIST": "0"}, {"MI355R_RECORD_COPIES": "0"}, {"MI355R_SKY_PPL": "1"}, {"MI355R_GENERIC_BLEND": "1"}, {"MI355R_SPLIT_BLEND": "0"}, {"MI355R_SPLIT_BLEND": "1"},
                                  {"MI355R_MICRO_MIN_LIST": "0", "MI355R_MICRO_AREA": "128", "MI355R_PPL": "4"}],
                          ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()))
 def test_gpu_alternative_code_paths_give_the_same_frames(gpu, env):
