@@ -1235,6 +1235,7 @@ static void prepare_batch(const Batch &b, const std::vector<PassPlan> &plans, ch
         P.bin_list = L.bin_list.ptr + list_off;
         P.bin_capacity = (uint32_t)list_cap[k];
         P.ref = L.ref.ptr ? L.ref.ptr + ref_off : nullptr;
+        P.ref_scanned = (b.families & (1 << RZ_FAMILY_SKYBOX)) != 0;
         P.control = (uint32_t*)(db + controls_at + CONTROL_BYTES * i);
         P.counters = g.counting ? g.d_counters : nullptr;
         P.debug_skip = dbg ? atoi(dbg) : 0;

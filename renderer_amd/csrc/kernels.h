@@ -1087,7 +1087,9 @@ __global__ void __launch_bounds__(256 / PPL) rz_visibility_kernel(const PassPara
     const uint2 range = (bin_range_base + P.bin_off)[bin];          /* {first entry, entries} */
     const uint32_t count = range.y;
     if (count == 0 && !P.clear_color_pending && !P.clear_depth_pending) {   /* uniform over the workgroup */
-        for (int q = 0; q < PPL; q++) if (valid[q]) P.ref[pixel[q]] = RZ_REF_NONE;
+        /* nobody looks at the references of a tile that is on no work list, unless a family's kernel scans every tile */
+        if (P.ref_scanned)
+            for (int q = 0; q < PPL; q++) if (valid[q]) P.ref[pixel[q]] = RZ_REF_NONE;
         return;
     }
     float zcur[PPL];
@@ -1308,7 +1310,7 @@ __global__ void __launch_bounds__(256 / PPL) rz_visibility_kernel(const PassPara
     }
     for (int q = 0; q < PPL; q++) {
         if (!valid[q]) continue;
-        P.depth[pixel[q]] = zcur[q];
+        if (ref_of[q] != RZ_REF_NONE || P.clear_depth_pending) P.depth[pixel[q]] = zcur[q];     /* else: what was there */
         P.ref[pixel[q]] = ref_of[q];
         /* the shade kernels write the colour of every pixel that has a fragment */
         if (P.clear_color_pending && ref_of[q] == RZ_REF_NONE) P.color[pixel[q]] = P.clear_color;

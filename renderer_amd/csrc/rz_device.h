@@ -161,6 +161,7 @@ struct PassParams {
     BinEntry *bin_list;
     uint32_t bin_capacity;
     uint32_t *ref;                  /* per pixel: reference of the visible fragment (split passes) */
+    int32_t ref_scanned;            /* a shade kernel of the batch reads the references of every tile (the skybox's) */
     /* scalars written by the device: [0] fan blocks used, [1] bin entries
      * used, [2] error bits, [3] triangles queued for clipping */
     uint32_t *control;
