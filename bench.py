@@ -31,7 +31,7 @@ SCENE = "helmet"
 ORBIT = 128                 # views on the orbit circle
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E
 KERNEL_SYMBOL = {"vertex": "rz_vertex_kernel", "setup": "rz_setup_kernel", "bin": "rz_bin_fill_kernel",
-                 "raster": "rz_visibility_kernel<2>", "shade_skybox": "rz_sky_kernel<2>",
+                 "raster": "rz_visibility_kernel<2, false>", "shade_skybox": "rz_sky_kernel<2>",
                  "shade_blinn": "rz_shade_list_kernel<0, true>", "shade_pbr": "rz_shade_list_kernel<1, true>"}
 
 
