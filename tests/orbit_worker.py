@@ -16,10 +16,11 @@ from renderer_amd.binding import Pipeline                       # noqa: E402
 
 def main():
     total, width, height = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
+    name = sys.argv[4] if len(sys.argv) > 4 else "helmet"
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     dist.init_process_group("gloo", rank=rank, world_size=world)
     pipe = Pipeline(os.path.join(REPO, "oracle", "liboracle.so"))
-    scene = pipe.open_scene("helmet")
+    scene = pipe.open_scene(name)
     first, last = orbit.shard_views(total, rank, world)
     block = max(orbit.shard_views(total, r, world)[1] - orbit.shard_views(total, r, world)[0] for r in range(world))
     fbs = [pipe.framebuffer(width, height) for _ in range(block)]

@@ -23,8 +23,11 @@ def test_shards_partition_the_views():
         shard_views(8, 2, 2)
 
 
-@pytest.mark.parametrize("world,total", [(2, 5), (2, 4)])
-def test_gloo_orbit_gather(oracle, world, total):
+@pytest.mark.parametrize("world,total,scene", [(2, 5, "helmet"), (2, 4, "helmet"), (2, 6, "buster")],
+                         ids=["helmet-5", "helmet-4", "buster-animated-6"])
+def test_gloo_orbit_gather(oracle, world, total, scene):
+    """helmet: the benchmark's scene; buster: the animated scene of the batch-render configuration
+    (every view has its own frame time, so every rank evaluates its own poses)."""
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
@@ -33,7 +36,7 @@ def test_gloo_orbit_gather(oracle, world, total):
     for rank in range(world):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="1")
-        procs.append(subprocess.Popen([sys.executable, os.path.join(REPO, "tests", "orbit_worker.py"), str(total), "96", "54"],
+        procs.append(subprocess.Popen([sys.executable, os.path.join(REPO, "tests", "orbit_worker.py"), str(total), "96", "54", scene],
                                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     outs = []
     for p in procs:
