@@ -22,6 +22,7 @@
 #include <algorithm>
 #include <unordered_map>
 #include <unordered_set>
+#include <chrono>
 #include <vector>
 
 #include "../../include/mi355r.h"
@@ -77,6 +78,7 @@ struct Tex {
      * the flush (Context::flush_epoch) during whose recording a draw last referred to it */
     bool pending_write = false;
     unsigned long long used_epoch = ~0ull;
+    unsigned long long write_seq = 0;       /* order of the writes on a lane: waiting for a later one covers the earlier ones */
 };
 
 struct rz_program {
@@ -156,6 +158,7 @@ struct Context {
     struct TexWrite { Tex *tex; Fb *fb; bool depth; size_t after; };
     std::vector<TexWrite> tex_writes;
     unsigned long long flush_epoch = 0;     /* counts the flushes that had something to submit */
+    unsigned long long write_seq = 0;
     /* upload ring: pinned host memory mirrored 1:1 in device memory */
     char *ring_host = nullptr, *ring_dev = nullptr;
     size_t ring_size = 0, ring_at = 0;
@@ -625,9 +628,10 @@ static hipStream_t begin_texture_write(Tex *t, Fb *fb) {
     if (t->write_event && t->write_lane != fb->lane) HIP_OK(hipStreamWaitEvent(st, t->write_event, 0));
     return st;
 }
-static void end_texture_write(Tex *t, Fb *fb) {
+static void end_texture_write(Tex *t, Fb *fb, hipEvent_t shared = nullptr) {
     t->write_lane = fb->lane;
-    t->write_event = new_event(g.lanes[fb->lane].stream);
+    t->write_event = shared ? shared : new_event(g.lanes[fb->lane].stream);
+    t->write_seq = ++g.write_seq;
     t->device_stale = false;
     t->host_stale = true;
 }
@@ -1400,8 +1404,33 @@ static void launch_batch(const Batch &b, const std::vector<PassPlan> &plans, cha
  * A batch runs on the lane of its first framebuffer (passes into one
  * framebuffer must stay ordered), or the next lane in turn; framebuffers and
  * GPU-written textures that come from other lanes are ordered by events. */
+/* MI355R_HOST_PROFILE=1: where the host's time in graphics_flush goes, printed when the process ends */
+struct FlushProfile {
+    bool on = getenv("MI355R_HOST_PROFILE") != nullptr;
+    double seconds[8] = {0};
+    unsigned long long flushes = 0, passes = 0;
+    std::chrono::steady_clock::time_point last;
+    void start() { if (on) last = std::chrono::steady_clock::now(); }
+    void mark(int slot) {
+        if (!on) return;
+        auto now = std::chrono::steady_clock::now();
+        seconds[slot] += std::chrono::duration<double>(now - last).count();
+        last = now;
+    }
+    ~FlushProfile() {
+        if (!on || !flushes) return;
+        static const char *names[8] = {"plan", "batches", "tables", "scratch+params", "upload", "launches", "copies", "tail"};
+        fprintf(stderr, "mi355r: %llu flushes, %llu passes; host microseconds per pass:", flushes, passes);
+        for (int i = 0; i < 8; i++) fprintf(stderr, " %s %.2f", names[i], seconds[i] * 1e6 / (double)passes);
+        fprintf(stderr, "\n");
+    }
+};
+static FlushProfile g_flush_profile;
+
 extern "C" void graphics_flush(void) {
     if (!g.ready || g.pending.empty()) return;
+    FlushProfile &prof = g_flush_profile;
+    prof.start();
     std::vector<PassPlan> plans;
     size_t n = g.pending.size(), first = 0;
     while (first < n) {
@@ -1428,6 +1457,7 @@ extern "C" void graphics_flush(void) {
     const size_t params_at = total;
     total += sizeof(PassParams) * plans.size();
     for (auto &pl : plans) plan_pass(pl, total);
+    prof.mark(0);
 
     /* batches and lanes */
     const int lanes = g.timing ? 1 : g.num_lanes;      /* per-kernel timing wants kernels alone on the GPU */
@@ -1491,24 +1521,31 @@ extern "C" void graphics_flush(void) {
         }
     }
 
+    prof.mark(1);
     size_t at = ring_alloc(total);
     char *hb = g.ring_host + at, *db = g.ring_dev + at;
     for (auto &pl : plans) fill_pass(pl, hb, db);
+    prof.mark(2);
     /* scratch first, for every batch: growing a buffer moves it, and the tables written next hold its address */
     for (auto &b : batches) prepare_batch(b, plans, hb, db, controls_at, true);
     for (auto &b : batches) prepare_batch(b, plans, hb, db, controls_at, false);
+    prof.mark(3);
     HIP_OK(hipMemcpyAsync(db + params_at, hb + params_at, total - params_at, hipMemcpyHostToDevice, g.copy_stream));
     hipEvent_t uploaded = new_event(g.copy_stream);
+    prof.mark(4);
 
     bool used[MAX_LANES] = {false};
     for (auto &b : batches) {
         Lane &L = g.lanes[b.lane];
         if (!used[b.lane]) { HIP_OK(hipStreamWaitEvent(L.stream, uploaded, 0)); used[b.lane] = true; }
         std::vector<Tex*> sampled;
+        bool awaited[MAX_LANES] = {false};
         for (size_t i : b.members) {
             const PassPlan &pl = plans[i];
-            if (pl.fb->lane >= 0 && pl.fb->lane != b.lane)      /* last touched on another lane */
+            if (pl.fb->lane >= 0 && pl.fb->lane != b.lane && !awaited[pl.fb->lane]) {   /* last touched on another lane */
                 HIP_OK(hipStreamWaitEvent(L.stream, new_event(g.lanes[pl.fb->lane].stream), 0));
+                awaited[pl.fb->lane] = true;        /* everything submitted to that lane so far: once is enough */
+            }
             pl.fb->lane = b.lane;
             for (size_t d = pl.first; d < pl.last; d++) {
                 for (Tex *t : g.pending[d].gpu_textures)
@@ -1517,21 +1554,58 @@ extern "C" void graphics_flush(void) {
                     if (std::find(sampled.begin(), sampled.end(), t) == sampled.end()) sampled.push_back(t);
             }
         }
-        for (Tex *t : sampled)
-            if (t->write_event && t->write_lane != b.lane) HIP_OK(hipStreamWaitEvent(L.stream, t->write_event, 0));
+        {
+            /* per lane that wrote some of them, the latest write: a stream finishes its work in order */
+            Tex *latest[MAX_LANES] = {nullptr};
+            for (Tex *t : sampled)
+                if (t->write_event && t->write_lane != b.lane && (!latest[t->write_lane] || t->write_seq > latest[t->write_lane]->write_seq))
+                    latest[t->write_lane] = t;
+            for (int l = 0; l < MAX_LANES; l++)
+                if (latest[l]) HIP_OK(hipStreamWaitEvent(L.stream, latest[l]->write_event, 0));
+        }
         launch_batch(b, plans, db);
         if (!sampled.empty()) {
             hipEvent_t done = new_event(L.stream);
             for (Tex *t : sampled) t->read_events.push_back(done);
         }
-        for (size_t i : b.members) {
-            auto copies = copies_after.find(i);
-            if (copies == copies_after.end()) continue;
-            for (Context::TexWrite *w : copies->second) {
-                launch_texture_write(w->tex, w->fb, w->depth);      /* on the framebuffer's lane = this batch's */
-                w->tex->pending_write = false;
+        prof.mark(5);
+        {
+            /* the recorded copies this batch feeds, on its lane, RZ_COPY_GROUP per launch */
+            std::vector<Context::TexWrite*> feeds;
+            for (size_t i : b.members) {
+                auto copies = copies_after.find(i);
+                if (copies != copies_after.end()) feeds.insert(feeds.end(), copies->second.begin(), copies->second.end());
+            }
+            for (size_t at = 0; at < feeds.size(); at += RZ_COPY_GROUP) {
+                const size_t count = std::min<size_t>(RZ_COPY_GROUP, feeds.size() - at);
+                CopyJobs jobs;
+                memset(&jobs, 0, sizeof jobs);
+                std::vector<hipEvent_t> readers;
+                int max_w = 0, max_h = 0;
+                for (size_t k = 0; k < count; k++) {
+                    Context::TexWrite *w = feeds[at + k];
+                    Tex *t = w->tex;
+                    if (w->fb->lane != b.lane) fatal("a recorded copy is not on its framebuffer's lane");
+                    for (hipEvent_t e : t->read_events) if (std::find(readers.begin(), readers.end(), e) == readers.end()) readers.push_back(e);
+                    t->read_events.clear();
+                    if (t->write_event && t->write_lane != b.lane) readers.push_back(t->write_event);
+                    jobs.job[k].from = w->depth ? (const void*)w->fb->d_depth : (const void*)w->fb->d_color;
+                    jobs.job[k].to = t->d_data;
+                    jobs.job[k].w = t->pub.width; jobs.job[k].h = t->pub.height;
+                    jobs.job[k].flags = t->flags; jobs.job[k].is_depth = w->depth ? 1 : 0;
+                    max_w = std::max(max_w, t->pub.width); max_h = std::max(max_h, t->pub.height);
+                }
+                for (hipEvent_t e : readers) HIP_OK(hipStreamWaitEvent(L.stream, e, 0));   /* passes that still sample the old contents */
+                rz_buffers_to_textures_kernel<<<dim3((max_w + 15) / 16, (max_h + 15) / 16, (unsigned)count), dim3(256), 0, L.stream>>>(jobs);
+                HIP_OK(hipGetLastError());
+                hipEvent_t written = new_event(L.stream);
+                for (size_t k = 0; k < count; k++) {
+                    end_texture_write(feeds[at + k]->tex, feeds[at + k]->fb, written);
+                    feeds[at + k]->tex->pending_write = false;
+                }
             }
         }
+        prof.mark(6);
     }
     /* control blocks come back once every lane of this flush has finished */
     for (int l = 0; l < MAX_LANES; l++)
@@ -1542,6 +1616,9 @@ extern "C" void graphics_flush(void) {
     g.side.clear();
     g.tex_writes.clear();
     g.flush_epoch++;
+    prof.mark(7);
+    prof.flushes++;
+    prof.passes += plans.size();
 }
 
 /* --------------------------------------------------------------- inspection -- */

@@ -1526,6 +1526,24 @@ __global__ void rz_depth_to_texture_kernel(const float *depth, float *texels, in
     texels[texel_index(w, flags, x, y)] = depth[(size_t)y * w + x];
 }
 
+/* several of those copies in one launch (grid z = copy): the recorded copies behind one batch of passes */
+#define RZ_COPY_GROUP 32
+struct CopyJob { const void *from; void *to; int32_t w, h, flags, is_depth; };
+struct CopyJobs { CopyJob job[RZ_COPY_GROUP]; };
+__global__ void rz_buffers_to_textures_kernel(const CopyJobs jobs) {
+    const CopyJob &j = jobs.job[blockIdx.z];
+    int x = blockIdx.x * 16 + (threadIdx.x & 15), y = blockIdx.y * 16 + (threadIdx.x >> 4);
+    if (x >= j.w || y >= j.h) return;
+    if (j.is_depth) {
+        ((float*)j.to)[texel_index(j.w, j.flags, x, y)] = ((const float*)j.from)[(size_t)y * j.w + x];
+    } else {
+        uint32_t c = ((const uint32_t*)j.from)[(size_t)y * j.w + x];
+        ((float4*)j.to)[texel_index(j.w, j.flags, x, y)] =
+            make_float4((float)(c & 0xffu) / 255.0f, (float)((c >> 8) & 0xffu) / 255.0f,
+                        (float)((c >> 16) & 0xffu) / 255.0f, (float)(c >> 24) / 255.0f);
+    }
+}
+
 /* texture_from_colorbuffer (texture.c:130-145): byte / 255.0f per channel */
 __global__ void rz_color_to_texture_kernel(const uint32_t *color, float4 *texels, int w, int h, int flags, int mbits) {
     int x = blockIdx.x * 16 + (threadIdx.x & 15), y = blockIdx.y * 16 + (threadIdx.x >> 4);
