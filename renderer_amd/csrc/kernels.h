@@ -520,6 +520,7 @@ RZ_DEV int wave_max_i(int v) {
 }
 
 #define RZ_FILL_FAN_SLOTS 64
+#define RZ_FILL_FEW_BINS 16         /* a chunk whose joint bin rectangle is at most this large is filled triangle-parallel */
 
 /* One workgroup of RZ_FILL_WAVES waves per chunk.  Lanes first hold the
  * chunk's 64 triangles (box, record), then turn into BINS: the chunk's joint
@@ -577,6 +578,49 @@ __global__ void __launch_bounds__(64 * RZ_FILL_WAVES) rz_bin_fill_kernel(const P
     const uint32_t *row = P.bin_counts + (size_t)chunk * (uint32_t)bins;
     const TriRec *__restrict__ fan_tri = P.fan_tri;
     if (P.debug_skip == 6) return;
+
+    if (ubins <= RZ_FILL_FEW_BINS) {
+        /* The chunk's triangles lie in a few bins (a dense mesh: most chunks).  Lanes stay
+         * triangles and the few bins are taken one after the other: the triangles that touch the
+         * bin find their places behind the chunk's start in its list by a prefix over the lanes
+         * (ascending lane = submission order, as below) and write their entries side by side. */
+        if (wave != 0) return;
+        for (int i = 0; i < ubins; i++) {
+            const int bx = ux0 + i % uw, by = uy0 + i / uw;
+            const int b = by * P.bins_x + bx;
+            const bool touch = r.entries != 0 && bx >= r.bx0 && bx <= r.bx1 && by >= r.by0 && by <= r.by1;
+            const unsigned long long touching = __ballot(touch);
+            if (!touching || P.bin_range[b].y == 0) continue;       /* zero: the list is empty or overflowed, nothing is kept */
+            const uint32_t start = row[b];
+            uint32_t before;
+            if (__ballot(touch && r.entries != 1u) == 0) {
+                before = __builtin_amdgcn_mbcnt_hi((uint32_t)(touching >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)touching, 0u));
+            } else {
+                uint32_t total;
+                before = wave_exclusive_scan(touch ? r.entries : 0u, &total);
+            }
+            if (!touch) continue;
+            if (!(ref & RZ_REF_FAN)) {
+                float4 *dst = (float4*)&P.bin_list[start + before];
+                dst[0] = make_float4(__uint_as_float(ref), 0.0f, 0.0f, 0.0f);
+                dst[1] = r0; dst[2] = r1; dst[3] = r2; dst[4] = r3;
+            } else {
+                for (uint32_t k = 0; k < r.entries; k++) {
+                    float4 q0, q1, q2, q3;
+                    if (slot != 0xffffffffu) {
+                        q0 = s_fan[slot + k][0]; q1 = s_fan[slot + k][1]; q2 = s_fan[slot + k][2]; q3 = s_fan[slot + k][3];
+                    } else {
+                        const float4 *src = (const float4*)&fan_tri[(ref & ~RZ_REF_FAN) + k];
+                        q0 = src[0]; q1 = src[1]; q2 = src[2]; q3 = src[3];
+                    }
+                    float4 *dst = (float4*)&P.bin_list[start + before + k];
+                    dst[0] = make_float4(__uint_as_float(ref + k), 0.0f, 0.0f, 0.0f);
+                    dst[1] = q0; dst[2] = q1; dst[3] = q2; dst[4] = q3;
+                }
+            }
+        }
+        return;
+    }
 
     for (int base = wave * 64; base < ubins; base += 64 * RZ_FILL_WAVES) {
         const int i = base + lane;
