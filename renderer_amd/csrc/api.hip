@@ -149,6 +149,10 @@ struct Context {
      * the tiles that need it, 2 = the latter for large framebuffers (MI355R_SPLIT_BLEND=0 / 1; measured: 4K frames gain 8 %,
      * 1080p frames lose as much to the three extra launches) */
     int split_blend = 2;
+    /* older code paths and measurement switches, read once when the library starts (MI355R_MONOLITHIC, _GENERIC_BLEND,
+     * _VERBOSE, _DEBUG_SKIP) */
+    bool monolithic = false, generic_blend = false, verbose = false;
+    int debug_skip = 0;
     bool record_copies = true;              /* MI355R_RECORD_COPIES=0: texture_from_*buffer always flushes first */
     int micro_area = 32;                    /* MI355R_MICRO_AREA: largest box (pixels of a block) rasterised one triangle per lane; 0 = off */
     int shade_workgroups = 4096;            /* 256-thread workgroups per shade launch (compute units x 16) */
@@ -253,7 +257,12 @@ extern "C" int mi355r_init(int device) {
         if (env) g.sky_pixels_per_lane = atoi(env) == 1 ? 1 : 2;
         env = getenv("MI355R_SPLIT_BLEND");
         if (env) g.split_blend = atoi(env) != 0 ? 1 : 0;
-        if (getenv("MI355R_MONOLITHIC")) g.split_blend = 0;        /* every pass through the ordered kernel */
+        g.monolithic = getenv("MI355R_MONOLITHIC") != nullptr;
+        if (g.monolithic) g.split_blend = 0;                        /* every pass through the ordered kernel */
+        g.generic_blend = getenv("MI355R_GENERIC_BLEND") != nullptr;
+        g.verbose = getenv("MI355R_VERBOSE") != nullptr;
+        env = getenv("MI355R_DEBUG_SKIP");
+        g.debug_skip = env ? atoi(env) : 0;
         env = getenv("MI355R_RECORD_COPIES");
         if (env) g.record_copies = atoi(env) != 0;
         env = getenv("MI355R_MICRO_AREA");
@@ -555,7 +564,7 @@ static void upload_texture(Tex *t) {
     t->write_lane = -1;
     std::vector<uint32_t> packed;
     const int format = g.pack_textures ? pack_texels(t->pub.buffer, (size_t)w * h, packed) : 0;
-    if (getenv("MI355R_VERBOSE")) fprintf(stderr, "mi355r: texture %dx%d -> format %d\n", w, h, format);
+    if (g.verbose) fprintf(stderr, "mi355r: texture %dx%d -> format %d\n", w, h, format);
     if (format) {
         device_image(t, format, sizeof(uint32_t));
         uint32_t *staging;
@@ -1100,7 +1109,7 @@ static void plan_pass(PassPlan &pl, size_t &total) {
         pl.families |= 1 << pd.rec.family;
         if (pd.rec.family != RZ_FAMILY_SKYBOX && !(pd.rec.flags & RZ_DRAW_NARROW_TEXELS)) pl.narrow_texels = false;
     }
-    if (getenv("MI355R_MONOLITHIC")) pl.has_blend = true;
+    if (g.monolithic) pl.has_blend = true;
     if (D > 65535) fatal("%zu draws in one pass (limit 65535)", D);
     if (pl.T > 0x0fffffffu) fatal("%zu triangles in one pass", pl.T);
     total = (total + 255) & ~(size_t)255;
@@ -1204,7 +1213,6 @@ static void prepare_batch(const Batch &b, const std::vector<PassPlan> &plans, ch
     if (reserve_only) return;
 
     size_t tri_off = 0, fan_off = 0, list_off = 0, bin_off = 0, ref_off = 0, matrix_off = 0, tile_off = 0;
-    const char *dbg = getenv("MI355R_DEBUG_SKIP");
     for (size_t k = 0; k < b.members.size(); k++) {
         const size_t i = b.members[k];
         const PassPlan &pl = plans[i];
@@ -1242,7 +1250,7 @@ static void prepare_batch(const Batch &b, const std::vector<PassPlan> &plans, ch
         P.ref_scanned = (b.families & (1 << RZ_FAMILY_SKYBOX)) != 0;
         P.control = (uint32_t*)(db + controls_at + CONTROL_BYTES * i);
         P.counters = g.counting ? g.d_counters : nullptr;
-        P.debug_skip = dbg ? atoi(dbg) : 0;
+        P.debug_skip = g.debug_skip;
         P.micro_area = g.micro_area;
         P.micro_min_list = g.micro_min_list;
         P.tiles_x = (W + RZ_TILE_W - 1) / RZ_TILE_W;
@@ -1343,7 +1351,7 @@ static void launch_batch(const Batch &b, const std::vector<PassPlan> &plans, cha
     /* a pass with blended draws: either everything in the ordered kernel (visibility and shading
      * together, fragment stacks), or visibility first, the ordered kernel for the tiles where
      * blended fragments pile up and the shade kernels for the rest */
-    const bool one_family = !getenv("MI355R_GENERIC_BLEND");
+    const bool one_family = !g.generic_blend;
     const int only = !one_family ? -1 : b.families == (1 << RZ_FAMILY_BLINN) ? 0 : b.families == (1 << RZ_FAMILY_PBR) ? 1 : -1;
     if (b.has_blend && !splits_blend(batch_tiles, n)) {
         auto kernel = rz_raster_kernel<false>;
