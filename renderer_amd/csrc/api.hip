@@ -1406,12 +1406,12 @@ static void launch_batch(const Batch &b, const std::vector<PassPlan> &plans, cha
  * -> one host-to-device copy in front of the kernels and one small copy of the
  * control blocks back behind them, whatever the number of passes.
  *
- * Passes are grouped into batches (one launch sequence each): a pass joins the
- * running batch unless its framebuffer is already in it, it samples a texture
- * some pass wrote on the GPU (shadow maps), or it needs the other rasteriser.
- * A batch runs on the lane of its first framebuffer (passes into one
- * framebuffer must stay ordered), or the next lane in turn; framebuffers and
- * GPU-written textures that come from other lanes are ordered by events. */
+ * Passes are grouped into batches (one launch sequence each) level by level: a
+ * pass comes one level after the last pass into its framebuffer and after the
+ * pass a recorded framebuffer copy follows when it samples the copied texture;
+ * a batch holds passes of one level and one kind of rasteriser.  A batch runs
+ * on the lane of its first framebuffer, or the next lane in turn; framebuffers
+ * and GPU-written textures that come from other lanes are ordered by events. */
 /* MI355R_HOST_PROFILE=1: where the host's time in graphics_flush goes, printed when the process ends */
 struct FlushProfile {
     bool on = getenv("MI355R_HOST_PROFILE") != nullptr;

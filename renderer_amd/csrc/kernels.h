@@ -1,15 +1,17 @@
 /*
- * The gfx950 kernels of the triangle pipeline, one pass (= draws into one
- * framebuffer) per launch sequence:
+ * The gfx950 kernels of the triangle pipeline.  A launch covers a batch of
+ * passes (a pass = draws into one framebuffer; grid y or z = pass):
  *
- *   rz_vertex_kernel   vertex shaders incl. skeletal skinning, 1 thread / vertex
- *   rz_setup_kernel    cull -> viewport -> bbox for unclipped triangles, 1 thread / triangle
- *   rz_clip_kernel     homogeneous clipping -> fan for the rest, 1 wave / triangle
- *   rz_bin_kernel      ordered 64x64-pixel bin lists, 1 workgroup / bin
- *   rz_raster_kernel   coverage, early-Z, varyings, fragment shaders, blend;
- *                      1 wave / 8x8 pixels, depth + colour held in registers
- *   rz_clear_kernel, rz_depth_to_texture_kernel, rz_color_to_texture_kernel,
- *   rz_texture_tile_kernel   framebuffer/texture utilities
+ *   rz_vertex_kernel       vertex shaders incl. skeletal skinning, 1 thread / vertex
+ *   rz_setup_kernel        cull -> viewport -> bbox for unclipped triangles, 1 thread / triangle
+ *   rz_clip_kernel         homogeneous clipping -> fan for the rest, 1 wave / triangle
+ *   rz_bin_count / _scan / _fill_kernel   ordered lists per 64x64-pixel bin
+ *   rz_visibility_kernel   passes without blending: coverage + depth, leaves depth and one
+ *                          fragment reference per pixel; 1 wave / 16x8 pixels
+ *   rz_sky_kernel, rz_shade_list_kernel   per-family fragment shading of those references
+ *   rz_raster_kernel / rz_raster_list_kernel   passes with blending: coverage, depth and
+ *                          ordered in-kernel shading; 1 wave / 8x8 pixels
+ *   rz_clear_kernel, rz_*_to_texture(s)_kernel, rz_texture_*tile*_kernel   framebuffer / texture utilities
  *
  * All arithmetic that decides coverage, depth or colour follows the reference
  * expression order (renderer/core/graphics.c, cited inline).
