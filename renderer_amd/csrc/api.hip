@@ -1401,17 +1401,6 @@ static void launch_batch(const Batch &b, const std::vector<PassPlan> &plans, cha
     if (g.timing) g.timing_passes.push_back(n);
 }
 
-/* One upload region per flush:
- *   [control block per pass][PassParams per pass][pass 0 tables][pass 1 tables]...
- * -> one host-to-device copy in front of the kernels and one small copy of the
- * control blocks back behind them, whatever the number of passes.
- *
- * Passes are grouped into batches (one launch sequence each) level by level: a
- * pass comes one level after the last pass into its framebuffer and after the
- * pass a recorded framebuffer copy follows when it samples the copied texture;
- * a batch holds passes of one level and one kind of rasteriser.  A batch runs
- * on the lane of its first framebuffer, or the next lane in turn; framebuffers
- * and GPU-written textures that come from other lanes are ordered by events. */
 /* MI355R_HOST_PROFILE=1: where the host's time in graphics_flush goes, printed when the process ends */
 struct FlushProfile {
     bool on = getenv("MI355R_HOST_PROFILE") != nullptr;
@@ -1435,6 +1424,17 @@ struct FlushProfile {
 };
 static FlushProfile g_flush_profile;
 
+/* One upload region per flush:
+ *   [control block per pass][PassParams per pass][pass 0 tables][pass 1 tables]...
+ * -> one host-to-device copy in front of the kernels and one small copy of the
+ * control blocks back behind them, whatever the number of passes.
+ *
+ * Passes are grouped into batches (one launch sequence each) level by level: a
+ * pass comes one level after the last pass into its framebuffer and after the
+ * pass a recorded framebuffer copy follows when it samples the copied texture;
+ * a batch holds passes of one level and one kind of rasteriser.  A batch runs
+ * on the lane of its first framebuffer, or the next lane in turn; framebuffers
+ * and GPU-written textures that come from other lanes are ordered by events. */
 extern "C" void graphics_flush(void) {
     if (!g.ready || g.pending.empty()) return;
     FlushProfile &prof = g_flush_profile;
