@@ -126,6 +126,7 @@ struct Lane {
     DevBuf<uint2> bin_range;
     DevBuf<uint32_t> bin_counts, queue, queue_counts, tile_listed;
     DevBuf<BinEntry> bin_list;
+    DevBuf<uint2> bin_boxes;
 };
 
 static const int RZ_TEX_NARROW_FORMATS = RZ_TEX_R32F | RZ_TEX_UNORM8 | RZ_TEX_SRGB8 | RZ_TEX_RGBE8;
@@ -1209,6 +1210,7 @@ static void prepare_batch(const Batch &b, const std::vector<PassPlan> &plans, ch
     reserve(L.queue, 3 * RZ_QUEUE_WAYS * queue_capacity, st);           /* blinn, pbr, RZ_ORDERED_LIST */
     reserve(L.queue_counts, 3 * RZ_QUEUE_WAYS * RZ_QUEUE_PAD, st);
     reserve(L.bin_list, lists, st);
+    reserve(L.bin_boxes, lists, st);
     if (!b.has_blend || splits_blend(tiles, b.members.size())) reserve(L.ref, pixels, st);
     if (reserve_only) return;
 
@@ -1245,6 +1247,7 @@ static void prepare_batch(const Batch &b, const std::vector<PassPlan> &plans, ch
         P.bin_range = L.bin_range.ptr + bin_off;
         P.bin_counts = L.bin_counts.ptr + matrix_off;
         P.bin_list = L.bin_list.ptr + list_off;
+        P.bin_boxes = L.bin_boxes.ptr + list_off;
         P.bin_capacity = (uint32_t)list_cap[k];
         P.ref = L.ref.ptr ? L.ref.ptr + ref_off : nullptr;
         P.ref_scanned = (b.families & (1 << RZ_FAMILY_SKYBOX)) != 0;
@@ -1324,7 +1327,7 @@ static void launch_batch(const Batch &b, const std::vector<PassPlan> &plans, cha
         for (size_t i : b.members) { pixels += (size_t)plans[i].fb->pub.width * plans[i].fb->pub.height; tris += plans[i].T; }
         const bool uses_ref = !(b.has_blend && !splits_blend(batch_tiles, n));
         if (L.queue_counts.cap < 3 * RZ_QUEUE_WAYS * RZ_QUEUE_PAD || L.queue.cap < 3 * RZ_QUEUE_WAYS * (size_t)queue_capacity ||
-            L.tile_listed.cap < batch_tiles || (uses_ref && (!L.ref.ptr || L.ref.cap < pixels)) || L.tri.cap < tris || L.bbox.cap < tris)
+            L.tile_listed.cap < batch_tiles || L.bin_boxes.cap < L.bin_list.cap || (uses_ref && (!L.ref.ptr || L.ref.cap < pixels)) || L.tri.cap < tris || L.bbox.cap < tris)
             fatal("scratch of lane %d is smaller than the batch it is about to run", b.lane);
     }
     stamp();
@@ -1362,7 +1365,7 @@ static void launch_batch(const Batch &b, const std::vector<PassPlan> &plans, cha
         stamp(); stamp(); stamp(); stamp();
     } else {
         if (b.has_blend) {
-            rz_visibility_kernel<2, true><<<tiles, dim3(128), 0, st>>>(passes, L.bin_list.ptr, L.vary.ptr, L.fan_vary.ptr, db, L.bin_range.ptr);
+            rz_visibility_kernel<2, true><<<tiles, dim3(128), 0, st>>>(passes, L.bin_list.ptr, L.bin_boxes.ptr, L.vary.ptr, L.fan_vary.ptr, db, L.bin_range.ptr);
             auto kernel = rz_raster_list_kernel<-1, false>;
             if (only == 0) kernel = narrow ? rz_raster_list_kernel<0, true> : rz_raster_list_kernel<0, false>;
             if (only == 1) kernel = narrow ? rz_raster_list_kernel<1, true> : rz_raster_list_kernel<1, false>;
@@ -1373,9 +1376,9 @@ static void launch_batch(const Batch &b, const std::vector<PassPlan> &plans, cha
             rz_raster_kernel<true><<<tiles, dim3(256), 0, st>>>(
                 passes, L.tri.ptr, L.fan_tri.ptr, L.bin_list.ptr, L.vary.ptr, L.fan_vary.ptr, db, L.bin_range.ptr);
         else if (g.pixels_per_lane == 4)
-            rz_visibility_kernel<4><<<tiles, dim3(64), 0, st>>>(passes, L.bin_list.ptr, L.vary.ptr, L.fan_vary.ptr, db, L.bin_range.ptr);
+            rz_visibility_kernel<4><<<tiles, dim3(64), 0, st>>>(passes, L.bin_list.ptr, L.bin_boxes.ptr, L.vary.ptr, L.fan_vary.ptr, db, L.bin_range.ptr);
         else
-            rz_visibility_kernel<2><<<tiles, dim3(128), 0, st>>>(passes, L.bin_list.ptr, L.vary.ptr, L.fan_vary.ptr, db, L.bin_range.ptr);
+            rz_visibility_kernel<2><<<tiles, dim3(128), 0, st>>>(passes, L.bin_list.ptr, L.bin_boxes.ptr, L.vary.ptr, L.fan_vary.ptr, db, L.bin_range.ptr);
         stamp();
         if (b.families & (1 << RZ_FAMILY_SKYBOX)) {
             if (g.sky_pixels_per_lane == 2)     /* four per lane: 11.9 us per frame against 11.1 */

@@ -522,6 +522,11 @@ RZ_DEV int wave_max_i(int v) {
 }
 
 #define RZ_FILL_FAN_SLOTS 64
+
+/* what the list walk needs of an entry, from the last quarter of its record */
+RZ_DEV uint2 entry_box(float4 q3) {
+    return make_uint2(__float_as_uint(q3.z), __float_as_uint(q3.w) | (RZ_META_CUTOFF(__float_as_uint(q3.y)) << 31));
+}
 #define RZ_FILL_FEW_BINS 16         /* a chunk whose joint bin rectangle is at most this large is filled triangle-parallel */
 
 /* One workgroup of RZ_FILL_WAVES waves per chunk.  Lanes first hold the
@@ -606,6 +611,7 @@ __global__ void __launch_bounds__(64 * RZ_FILL_WAVES) rz_bin_fill_kernel(const P
                 float4 *dst = (float4*)&P.bin_list[start + before];
                 dst[0] = make_float4(__uint_as_float(ref), 0.0f, 0.0f, 0.0f);
                 dst[1] = r0; dst[2] = r1; dst[3] = r2; dst[4] = r3;
+                P.bin_boxes[start + before] = entry_box(r3);
             } else {
                 for (uint32_t k = 0; k < r.entries; k++) {
                     float4 q0, q1, q2, q3;
@@ -618,6 +624,7 @@ __global__ void __launch_bounds__(64 * RZ_FILL_WAVES) rz_bin_fill_kernel(const P
                     float4 *dst = (float4*)&P.bin_list[start + before + k];
                     dst[0] = make_float4(__uint_as_float(ref + k), 0.0f, 0.0f, 0.0f);
                     dst[1] = q0; dst[2] = q1; dst[3] = q2; dst[4] = q3;
+                    P.bin_boxes[start + before + k] = entry_box(q3);
                 }
             }
         }
@@ -654,6 +661,7 @@ __global__ void __launch_bounds__(64 * RZ_FILL_WAVES) rz_bin_fill_kernel(const P
                     float4 *dst = (float4*)&P.bin_list[cursor];
                     dst[0] = make_float4(__uint_as_float(refL), 0.0f, 0.0f, 0.0f);
                     dst[1] = q0; dst[2] = q1; dst[3] = q2; dst[4] = q3;
+                    P.bin_boxes[cursor] = entry_box(q3);
                     cursor += 1u;
                 }
             } else {
@@ -671,6 +679,7 @@ __global__ void __launch_bounds__(64 * RZ_FILL_WAVES) rz_bin_fill_kernel(const P
                         float4 *dst = (float4*)&P.bin_list[cursor + k];
                         dst[0] = make_float4(__uint_as_float(refL + k), 0.0f, 0.0f, 0.0f);
                         dst[1] = q0; dst[2] = q1; dst[3] = q2; dst[4] = q3;
+                        P.bin_boxes[cursor + k] = entry_box(q3);
                     }
                 }
                 if (hit) cursor += e;
@@ -723,9 +732,6 @@ RZ_DEV uint32_t pack_rgb(f4 c, uint32_t keep) {                 /* float_to_ucha
  * at exactly one place in the kernel.
  */
 
-#define RZ_META_BLEND(m) (((m) >> 22) & 1u)
-#define RZ_META_CUTOFF(m) (((m) >> 23) & 1u)
-#define RZ_META_FAMILY(m) (((m) >> 24) & 3u)
 
 /* (s0*q0 + s1*q1 + s2*q2) * norm per float (graphics.c:431-434), per lane */
 template <int NV>
@@ -1107,7 +1113,7 @@ __global__ void __launch_bounds__(256) rz_raster_list_kernel(const PassParams *_
  * one pixel per lane; only the per-pixel arithmetic is the same.  Leaves depth, the tagged reference of the visible fragment and the shade work lists. */
 template <int PPL, bool BLEND = false>
 __global__ void __launch_bounds__(256 / PPL) rz_visibility_kernel(const PassParams *__restrict__ passes,
-        const BinEntry *__restrict__ list_base,
+        const BinEntry *__restrict__ list_base, const uint2 *__restrict__ box_base,
         const float *__restrict__ vary_base, const float *__restrict__ fan_vary_base,
         const char *__restrict__ upload_base, const uint2 *__restrict__ bin_range_base) {
     const PassParams P = passes[blockIdx.z];
@@ -1148,6 +1154,7 @@ __global__ void __launch_bounds__(256 / PPL) rz_visibility_kernel(const PassPara
         if (valid[q] && !P.clear_depth_pending) zcur[q] = P.depth[pixel[q]];
     }
     const BinEntry *list = list_table + range.x;
+    const uint2 *boxes = box_base + P.list_off + range.x;
 
     /* Small triangles.  Which fragment a pixel ends up with does not depend on the order the
      * triangles are taken in: it is the one of least depth, the latest in submission order among
@@ -1214,45 +1221,60 @@ __global__ void __launch_bounds__(256 / PPL) rz_visibility_kernel(const PassPara
         }
     };
 
-    /* this lane's candidate of the NEXT group of 64 entries, loaded one group ahead */
+    /* This lane's candidate of the NEXT group of 64 entries, loaded one group ahead.  A short list
+     * is read from the entries themselves, box and edge data together (one round trip per group).
+     * A long list is walked through the 8-byte boxes -- 512 contiguous bytes per load, where the
+     * same fields out of the 80-byte entries are 64 cache lines and the loads, not the arithmetic,
+     * set the pace -- and the edge data of the few candidates whose box meets the block is fetched
+     * afterwards. */
+    const bool long_list = count >= (uint32_t)P.micro_min_list;    /* wave-uniform */
     float4 n0 = make_float4(0, 0, 0, 0), n1 = n0;
-    float2 nbox = make_float2(0, 0);
-    uint32_t nmeta = 0;
+    uint2 nbox = make_uint2(RZ_BBOX_EMPTY_X, 0u);
     if ((uint32_t)lane < count) {
-        const float4 *e = (const float4*)&list[lane];              /* reference + record, 80 bytes */
-        n0 = e[1]; n1 = e[2];
-        const float4 tail = e[4];
-        nmeta = __float_as_uint(tail.y); nbox = make_float2(tail.z, tail.w);
+        if (long_list) {
+            nbox = boxes[lane];
+        } else {
+            const float4 *e = (const float4*)&list[lane];          /* reference + record, 80 bytes */
+            n0 = e[1]; n1 = e[2];
+            nbox = entry_box(e[4]);
+        }
     }
     /* block corners at pixel centres, for the conservative triangle/block test */
     const float cx0 = (float)bx0 + 0.5f, cx1 = (float)bx1 + 0.5f, cy0 = (float)by0 + 0.5f, cy1 = (float)by0 + 7.5f;
 
     for (uint32_t base = 0; base < count && P.debug_skip != 4;) {
-        const float4 c0 = n0, c1 = n1;
-        const float2 cbox = nbox;
-        const uint32_t cmeta = nmeta;
+        const uint2 cbox = nbox;
+        float4 c0 = n0, c1 = n1;
         const bool present = base + lane < count;
         const BinEntry *group = list + base;
         const uint32_t group_at = base;
         base += 64u;
         if (base + lane < count) {
-            const float4 *e = (const float4*)&list[base + lane];
-            n0 = e[1]; n1 = e[2];
-            const float4 tail = e[4];
-            nmeta = __float_as_uint(tail.y); nbox = make_float2(tail.z, tail.w);
+            if (long_list) {
+                nbox = boxes[base + lane];
+            } else {
+                const float4 *e = (const float4*)&list[base + lane];
+                n0 = e[1]; n1 = e[2];
+                nbox = entry_box(e[4]);
+            }
         }
+        const bool cutoff = (cbox.y >> 31) != 0;
         bool hit = false;
         if (present) {
-            hit = box_overlaps(make_uint2(__float_as_uint(cbox.x), __float_as_uint(cbox.y)), bx0, by0, bx1, by1);
+            hit = box_overlaps(make_uint2(cbox.x, cbox.y & 0x7fffffffu), bx0, by0, bx1, by1);
+            if (hit && long_list) {
+                const float4 *e = (const float4*)&group[lane];
+                c0 = e[1]; c1 = e[2];
+            }
             if (hit) hit = !block_outside(c0, c1, cx0, cx1, cy0, cy1);
         }
         if (micro_area) {
             bool small = false;
             if (hit) {
-                const uint32_t bx = __float_as_uint(cbox.x), by = __float_as_uint(cbox.y);
+                const uint32_t bx = cbox.x, by = cbox.y & 0x7fffffffu;
                 const int w = min((int)(bx >> 16), sx1) - max((int)(bx & 0xffffu), bx0) + 1;
                 const int h = min((int)(by >> 16), sy1) - max((int)(by & 0xffffu), by0) + 1;
-                small = w * h <= micro_area && !RZ_META_CUTOFF(cmeta);
+                small = w * h <= micro_area && !cutoff;
             }
             const unsigned long long smalls = __ballot(small);
             if (smalls) {

@@ -132,6 +132,9 @@ struct BinEntry {
 #define RZ_META_BACKFACE(m) (((m) >> 16) & 1u)
 #define RZ_META_CLIPPED(m) (((m) >> 17) & 1u)
 #define RZ_META_FAN(m) (((m) >> 18) & 15u)
+#define RZ_META_BLEND(m) (((m) >> 22) & 1u)
+#define RZ_META_CUTOFF(m) (((m) >> 23) & 1u)
+#define RZ_META_FAMILY(m) (((m) >> 24) & 3u)
 #define RZ_BBOX_EMPTY_X 0x0000ffffu  /* min 65535 > max 0 */
 
 struct PassParams {
@@ -159,6 +162,7 @@ struct PassParams {
     uint32_t *bin_counts;           /* [chunks of 64 triangles][bins]: entries, then first entry */
     uint2 *bin_range;               /* per bin: {first entry, entries} */
     BinEntry *bin_list;
+    uint2 *bin_boxes;               /* per list entry: x0 | x1 << 16, y0 | y1 << 16 | alpha-cutoff << 31 -- all that walking a list reads */
     uint32_t bin_capacity;
     uint32_t *ref;                  /* per pixel: reference of the visible fragment (split passes) */
     int32_t ref_scanned;            /* a shade kernel of the batch reads the references of every tile (the skybox's) */
