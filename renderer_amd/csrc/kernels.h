@@ -1144,6 +1144,15 @@ __global__ void __launch_bounds__(256 / PPL) rz_visibility_kernel(const PassPara
             for (int q = 0; q < PPL; q++) if (valid[q]) P.ref[pixel[q]] = RZ_REF_NONE;
         return;
     }
+    if (count == 0) {               /* nothing but the pending clears (uniform over the workgroup) */
+        for (int q = 0; q < PPL; q++) {
+            if (!valid[q]) continue;
+            if (P.clear_depth_pending) P.depth[pixel[q]] = P.clear_depth;
+            if (P.clear_color_pending) P.color[pixel[q]] = P.clear_color;
+            if (P.ref_scanned) P.ref[pixel[q]] = RZ_REF_NONE;
+        }
+        return;
+    }
     float zcur[PPL];
     uint32_t ref_of[PPL];                                           /* tagged with the family; NONE = no fragment */
     int ord_of[PPL];                                                /* its position in the bin's list; -1 = what the buffer held */
