@@ -26,7 +26,8 @@ for f in glob.glob(os.path.join(out, "trace", "**", "*kernel_stats.csv"), recurs
 durations = defaultdict(list)
 for f in glob.glob(os.path.join(out, "trace", "**", "*kernel_trace.csv"), recursive=True):
     for row in csv.DictReader(open(f)):
-        durations[short(row["Kernel_Name"])].append((int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e3)
+        durations[short(row["Kernel_Name"])].append((int(row["Start_Timestamp"]), (int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e3))
+durations = {k: [d for _, d in sorted(v)] for k, v in durations.items()}       # in launch order
 
 
 def median(v):
@@ -39,9 +40,21 @@ for f in glob.glob(os.path.join(out, "*", "**", "*counter_collection.csv"), recu
     for row in csv.DictReader(open(f)):
         pmc[short(row["Kernel_Name"])][row["Counter_Name"]].append(float(row["Counter_Value"]))
 
-print(f"{'kernel':34s} {'calls':>6s} {'avg us':>9s} {'%':>6s} {'median us':>10s}")
+def steady(v):
+    """average over the launches of the benchmark's ordinary steps: without those that take more than twice
+    the median (the first launch of a kernel, which loads its code; the untimed step in which bench.py
+    turns the device-side fragment counters on, whose atomics make every launch 30 times longer)"""
+    m = median(v)
+    kept = [d for d in v if d <= 2 * m]
+    return sum(kept) / len(kept) if kept else float("nan")
+
+
+print("avg us = rocprofv3's own average over all launches, including bench.py's one untimed counting step (device-side")
+print("fragment counters on: every launch takes 30 times longer) and first launches; steady avg us = without the launches")
+print("longer than twice the median, i.e. the ordinary steps, which is what bench.py's HIP-event figure measures")
+print(f"{'kernel':34s} {'calls':>6s} {'avg us':>9s} {'%':>6s} {'steady avg us':>14s} {'median us':>10s}")
 for k, (calls, avg, pct) in sorted(stats.items(), key=lambda kv: -kv[1][2]):
-    print(f"{k:34s} {calls:6d} {avg:9.2f} {pct:6.2f} {median(durations.get(k, [])):10.2f}")
+    print(f"{k:34s} {calls:6d} {avg:9.2f} {pct:6.2f} {steady(durations.get(k, [])):14.2f} {median(durations.get(k, [])):10.2f}")
     for c, vals in sorted(pmc.get(k, {}).items()):
         mean = sum(vals) / len(vals)
         note = ""
