@@ -93,6 +93,45 @@ def measured_counters(symbol, frames_per_launch, key):
     return t["kernels"][symbol].get(key)
 
 
+def calibrate_split(gpu, orbit, scene, B, world, rank, device, dist, torch):
+    """Frames per peer and step for the gather-aware split, from rank 0's render rate and the rate at
+    which the peers' frames arrive when all of them send at once (both measured here, on B frames)."""
+    fbs = [gpu.framebuffer(WIDTH, HEIGHT) for _ in range(B)]
+    views = [gpu.orbit_view(i % ORBIT, ORBIT) for i in range(B)]
+    trial = orbit.FrameGather(B, HEIGHT, WIDTH, device, rank, world, depth=1)
+
+    def fence():
+        trial.drain()
+        dist.barrier()
+        torch.cuda.synchronize()
+    orbit.render_views(gpu, scene, fbs, views)
+    trial.submit(gpu, fbs, B)                   # first use of the scene, the links and the buffers
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(2):
+        orbit.render_views(gpu, scene, fbs, views)
+    torch.cuda.synchronize()
+    render_s = (time.perf_counter() - t0) / 2
+    fence()
+    t0 = time.perf_counter()
+    trial.submit(gpu, fbs, B)
+    fence()
+    gather_s = time.perf_counter() - t0
+    rates = torch.tensor([render_s, gather_s], dtype=torch.float64, device=device)
+    dist.broadcast(rates, src=0)                # rank 0's clock decides for everybody
+    render_s, gather_s = float(rates[0]), float(rates[1])
+    for fb in fbs:
+        gpu.release(fb)
+    del trial
+    # rank 0 renders R frames in R * render_s / B, a peer delivers P frames in P * gather_s / B: equal times
+    total = B * world
+    if not (render_s > 0 and gather_s > 0):
+        return B, None
+    peer = int(total / (gather_s / render_s + (world - 1)))
+    peer = max(1, min(B, peer))
+    return peer, {"render_ms_per_frame": render_s / B * 1e3, "delivery_ms_per_frame": gather_s / B * 1e3}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -101,6 +140,7 @@ def main():
     ap.add_argument("--frames", type=int, default=128, help="frames per step and rank (default: one 128-view orbit)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (gloo: CPU rehearsal of the gather)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--even", action="store_true", help="N > 1: every rank renders the same number of frames (no gather-aware split)")
     args = ap.parse_args()
 
     import torch
@@ -130,16 +170,25 @@ def main():
     info = gpu.scene_info(scene)
     faces = info["faces"] + (12 if info["skybox"] else 0)
     B = args.frames
-    fbs = [gpu.framebuffer(WIDTH, HEIGHT) for _ in range(B)]
-    # weak scaling: B frames per rank; rank r renders block r of an orbit of B * world views
-    first, last = orbit.shard_views(B * world, rank, world)
+    device = "cuda" if on_device else "cpu"
+    # weak scaling: a step is B * world frames.  N > 1: a peer's frames have to cross its xGMI link to
+    # rank 0, rank 0's own do not, and a GPU renders several times as many frames as a link carries --
+    # so the split is gather-aware: every peer renders `peer_frames` of the step's views, rank 0 the rest,
+    # sized from two measurements taken here so that rendering on rank 0 and delivery from the peers take
+    # the same time (peer_frames == B is the even split)
+    peer_frames, split = B, None
+    if world > 1 and not args.even:
+        peer_frames, split = calibrate_split(gpu, orbit, scene, B, world, rank, device, dist, torch)
+    first, last = orbit.shard_views_rooted(B * world, rank, world, peer_frames)
+    mine = last - first
+    fbs = [gpu.framebuffer(WIDTH, HEIGHT) for _ in range(mine)]
     views = [gpu.orbit_view(i % ORBIT, ORBIT) for i in range(first, last)]
-    gather = orbit.FrameGather(B, HEIGHT, WIDTH, "cuda" if on_device else "cpu", rank, world)
+    gather = orbit.FrameGather(peer_frames, HEIGHT, WIDTH, device, rank, world, root_frames=B * world - peer_frames * (world - 1))
 
     def step(with_gather=True):
         orbit.render_views(gpu, scene, fbs, views)
         if with_gather:
-            gather.submit(gpu, fbs, B)      # N > 1: this step's transfer overlaps the next step's rendering
+            gather.submit(gpu, fbs, mine)   # N > 1: this step's transfer overlaps the next step's rendering
 
     def fence():
         gather.drain()                      # every frame submitted so far has arrived on rank 0
@@ -179,7 +228,7 @@ def main():
         orbit.render_views(gpu, scene, fbs, views)
         counters = gpu.counters()
         gpu.lib.mi355r_enable_counters(0)
-        shaded_per_frame = counters[2] / B
+        shaded_per_frame = counters[2] / mine        # (rank 0's own frames: `mine` of them)
 
         # per-kernel device time: HIP events on the pipeline's own stream around every launch
         gpu.lib.mi355r_enable_timing(1)
@@ -189,13 +238,13 @@ def main():
         gpu.lib.mi355r_enable_timing(0)
         frames_per_launch = passes / sequences
         per_frame_ms = {k: v / passes for k, v in ms.items()}
-        share = kernel_frame_bytes(counters, B, faces)
+        share = kernel_frame_bytes(counters, mine, faces)
         dominant = max(per_frame_ms, key=lambda k: per_frame_ms[k])
         launch_ms = per_frame_ms[dominant] * frames_per_launch
         bytes_per_launch = share[dominant] * frames_per_launch
         achieved = bytes_per_launch / (launch_ms * 1e-3) / 1e9
         pipeline_ms = sum(per_frame_ms.values())
-        frame_bytes = reference_frame_bytes(counters, B, faces)
+        frame_bytes = reference_frame_bytes(counters, mine, faces)
         frame_achieved = frame_bytes / (pipeline_ms * 1e-3) / 1e9
 
         result = {
@@ -207,13 +256,15 @@ def main():
                                    f"(eye 1.5*(sin a, 0.3, cos a), {ORBIT}-view circle)",
                        "frames_per_step": B * world, "triangles_per_frame": faces,
                        "gather": ("%s gather of RGBA8 frames to rank 0, overlapped with the next step's rendering"
-                                  % ("rccl" if on_device else args.backend)) if world > 1 else "none"},
+                                  % ("rccl" if on_device else args.backend)) if world > 1 else "none",
+                       "split": ({"frames_on_rank_0": mine, "frames_per_peer": peer_frames, "calibration": split}
+                                 if world > 1 else None)},
             "ms_per_frame": elapsed / total_frames * 1e3,
             "render_only_fps": (total_frames / render_only) if render_only else None,
-            "gathered_gb_per_s": (total_frames * (world - 1) / world * WIDTH * HEIGHT * 4 / elapsed / 1e9) if world > 1 else None,
+            "gathered_gb_per_s": (args.steps * peer_frames * (world - 1) * WIDTH * HEIGHT * 4 / elapsed / 1e9) if world > 1 else None,
             "shaded_fragments_per_frame": shaded_per_frame,
             "shaded_mfrags_per_s": shaded_per_frame * fps / 1e6,
-            "fragments_shaded_on_device_per_frame": counters[8] / B,
+            "fragments_shaded_on_device_per_frame": counters[8] / mine,
             "kernel_ms_per_frame": per_frame_ms,
             "roofline": {"bound": "hbm", "kernel": KERNEL_SYMBOL[dominant], "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,

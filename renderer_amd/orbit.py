@@ -6,6 +6,8 @@ into its own framebuffers; nothing is exchanged while rendering.  The one
 exchange step is the gather of finished RGBA8 frames on rank 0
 (`gather_frames`), a torch.distributed collective: RCCL over xGMI for device
 tensors under the "nccl" backend, gloo for host tensors in the CPU tests.
+Blocks are either even (`shard_views`) or gather-aware (`shard_views_rooted`:
+more views on rank 0, whose frames need not cross a link).
 """
 import ctypes as C
 
@@ -19,6 +21,21 @@ def shard_views(total, rank, world):
     base, extra = divmod(total, world)
     first = rank * base + min(rank, extra)
     return first, first + base + (1 if rank < extra else 0)
+
+
+def shard_views_rooted(total, rank, world, peer_frames):
+    """Blocks for a gather-aware split: every rank but 0 renders `peer_frames` views, rank 0 the rest.
+
+    Rank 0 keeps its frames where they are, a peer's frames have to cross its xGMI link to rank 0;
+    when a GPU renders faster than a link carries frames, the job is fastest with more views on
+    rank 0 (see bench.py).  peer_frames = total // world gives the even split."""
+    if not (0 <= rank < world) or total < 0 or peer_frames < 0 or peer_frames * (world - 1) > total:
+        raise ValueError(f"bad shard request: total={total} rank={rank} world={world} peer_frames={peer_frames}")
+    root = total - peer_frames * (world - 1)
+    if rank == 0:
+        return 0, root
+    first = root + (rank - 1) * peer_frames
+    return first, first + peer_frames
 
 
 def render_views(pipe, scene, framebuffers, views):
@@ -61,16 +78,23 @@ class FrameGather:
     the transfer of one step overlaps the rendering of the next.  Rank 0 ends up with
     `received(slot)` = list over ranks of that step's frames.  world == 1: nothing is moved."""
 
-    def __init__(self, frames, height, width, device, rank, world, depth=2):
+    def __init__(self, frames, height, width, device, rank, world, depth=2, root_frames=None):
+        """frames: slot size of the collective (the largest block a rank sends).  root_frames: the
+        gather-aware split (shard_views_rooted) -- rank 0's block has that many frames and does not
+        go through the collective: rank 0 copies it into a buffer of its own per slot (`own(slot)`),
+        and takes part in the gather with an unused slot."""
         import torch
         self.rank, self.world, self.depth, self.count = rank, world, depth, 0
+        self.rooted = root_frames is not None
         self.on_device = torch.device(device).type == "cuda"
-        self.slots = self.inbox = self.work = None
+        self.slots = self.inbox = self.work = self.kept = None
         if world > 1:
             shape = (frames, height, width, 4)
             self.slots = [torch.empty(shape, dtype=torch.uint8, device=device) for _ in range(depth)]
             self.inbox = [[torch.empty(shape, dtype=torch.uint8, device=device) for _ in range(world)] if rank == 0 else None
                           for _ in range(depth)]
+            if self.rooted and rank == 0:
+                self.kept = [torch.empty((root_frames, height, width, 4), dtype=torch.uint8, device=device) for _ in range(depth)]
             self.work = [None] * depth
 
     def _finish(self, slot):
@@ -88,7 +112,8 @@ class FrameGather:
             return
         slot = self.count % self.depth
         self._finish(slot)
-        frames_to_tensor(pipe, framebuffers, count, self.slots[slot])      # returns when the copies are complete
+        # (frames_to_tensor returns when the copies are complete)
+        frames_to_tensor(pipe, framebuffers, count, self.kept[slot] if self.rooted and self.rank == 0 else self.slots[slot])
         self.work[slot] = dist.gather(self.slots[slot], self.inbox[slot], dst=0, async_op=True)
         self.count += 1
 
@@ -100,6 +125,10 @@ class FrameGather:
     def received(self, slot):
         return self.inbox[slot]
 
+    def own(self, slot):
+        """Rank 0's own frames of that step under the gather-aware split."""
+        return self.kept[slot]
+
 
 def assemble(gathered, total, world):
     """Rank-major gathered blocks (each padded to the largest block) -> frames in view order."""
@@ -107,4 +136,12 @@ def assemble(gathered, total, world):
     for r, block in enumerate(gathered):
         first, last = shard_views(total, r, world)
         frames.extend(block[i] for i in range(last - first))
+    return frames
+
+
+def assemble_rooted(root_frames, gathered, total, world, peer_frames):
+    """Frames in view order for shard_views_rooted: rank 0's own frames, then the peers' gathered blocks."""
+    frames = list(root_frames[:total - peer_frames * (world - 1)])
+    for r in range(1, world):
+        frames.extend(gathered[r][i] for i in range(peer_frames))
     return frames

@@ -17,16 +17,22 @@ from renderer_amd.binding import Pipeline                       # noqa: E402
 def main():
     total, width, height = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
     name = sys.argv[4] if len(sys.argv) > 4 else "helmet"
+    peer_frames = int(sys.argv[5]) if len(sys.argv) > 5 else None    # given: the gather-aware split
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     dist.init_process_group("gloo", rank=rank, world_size=world)
     pipe = Pipeline(os.path.join(REPO, "oracle", "liboracle.so"))
     scene = pipe.open_scene(name)
-    first, last = orbit.shard_views(total, rank, world)
-    block = max(orbit.shard_views(total, r, world)[1] - orbit.shard_views(total, r, world)[0] for r in range(world))
+    if peer_frames is None:
+        first, last = orbit.shard_views(total, rank, world)
+        block = max(orbit.shard_views(total, r, world)[1] - orbit.shard_views(total, r, world)[0] for r in range(world))
+        pipeline = orbit.FrameGather(block, height, width, "cpu", rank, world)
+    else:
+        first, last = orbit.shard_views_rooted(total, rank, world, peer_frames)
+        block = last - first
+        pipeline = orbit.FrameGather(peer_frames, height, width, "cpu", rank, world, root_frames=total - peer_frames * (world - 1))
     fbs = [pipe.framebuffer(width, height) for _ in range(block)]
     views = [pipe.orbit_view(i, total) for i in range(first, last)]
     # the pipelined gather bench.py uses, three steps through two slots: the last step is the one checked
-    pipeline = orbit.FrameGather(block, height, width, "cpu", rank, world)
     for step in range(3):
         orbit.render_views(pipe, scene, fbs, views)
         pipeline.submit(pipe, fbs, last - first)
@@ -37,7 +43,10 @@ def main():
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     ok = True
     if rank == 0:
-        frames = orbit.assemble(gathered, total, world)
+        if peer_frames is None:
+            frames = orbit.assemble(gathered, total, world)
+        else:
+            frames = orbit.assemble_rooted(pipeline.own(2 % 2), gathered, total, world, peer_frames)
         ok = len(frames) == total and float(t.item()) == float(world)
         for i, frame in enumerate(frames):
             want, _ = pipe.render(scene, width, height, pipe.orbit_view(i, total))

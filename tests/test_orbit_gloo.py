@@ -23,11 +23,28 @@ def test_shards_partition_the_views():
         shard_views(8, 2, 2)
 
 
-@pytest.mark.parametrize("world,total,scene", [(2, 5, "helmet"), (2, 4, "helmet"), (2, 6, "buster")],
-                         ids=["helmet-5", "helmet-4", "buster-animated-6"])
-def test_gloo_orbit_gather(oracle, world, total, scene):
+def test_rooted_shards_partition_the_views():
+    from renderer_amd.orbit import shard_views_rooted
+    for world in [1, 2, 4, 8]:
+        for total, peer in [(8 * world, 8), (8 * world, 3), (8 * world, 0), (1024, 37)]:
+            if peer * (world - 1) > total:
+                continue
+            blocks = [shard_views_rooted(total, r, world, peer) for r in range(world)]
+            assert blocks[0][0] == 0 and blocks[-1][1] == total
+            assert all(blocks[r][1] == blocks[r + 1][0] for r in range(world - 1))
+            assert all(b - a == peer for a, b in blocks[1:])
+    with pytest.raises(ValueError):
+        shard_views_rooted(8, 0, 4, 3)
+
+
+@pytest.mark.parametrize("world,total,scene,peer", [(2, 5, "helmet", None), (2, 4, "helmet", None), (2, 6, "buster", None),
+                                                    (2, 6, "helmet", 2), (3, 7, "helmet", 1)],
+                         ids=["helmet-5", "helmet-4", "buster-animated-6", "helmet-6-rooted-2", "helmet-7-of-3-rooted-1"])
+def test_gloo_orbit_gather(oracle, world, total, scene, peer):
     """helmet: the benchmark's scene; buster: the animated scene of the batch-render configuration
-    (every view has its own frame time, so every rank evaluates its own poses)."""
+    (every view has its own frame time, so every rank evaluates its own poses).  rooted: the
+    gather-aware split bench.py uses for N > 1 (peers render `peer` views each, rank 0 the rest and
+    keeps its own outside the collective)."""
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
@@ -36,7 +53,7 @@ def test_gloo_orbit_gather(oracle, world, total, scene):
     for rank in range(world):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="1")
-        procs.append(subprocess.Popen([sys.executable, os.path.join(REPO, "tests", "orbit_worker.py"), str(total), "96", "54", scene],
+        procs.append(subprocess.Popen([sys.executable, os.path.join(REPO, "tests", "orbit_worker.py"), str(total), "96", "54", scene] + ([str(peer)] if peer is not None else []),
                                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     outs = []
     for p in procs:
