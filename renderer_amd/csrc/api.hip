@@ -392,6 +392,10 @@ extern "C" void framebuffer_read(rz_framebuffer *p, void *color, void *depth) {
     if (color) HIP_OK(hipMemcpyAsync(color, fb->d_color, n * 4, hipMemcpyDeviceToHost, st));
     if (depth) HIP_OK(hipMemcpyAsync(depth, fb->d_depth, n * sizeof(float), hipMemcpyDeviceToHost, st));
     HIP_OK(hipStreamSynchronize(st));       /* only this framebuffer's lane has to drain: other frames keep rendering */
+    /* the passes' error words come back on the copy stream, behind every lane of their flush: looked at
+     * here when they have all arrived, otherwise at the next full synchronisation */
+    if (hipStreamQuery(g.copy_stream) == hipSuccess) check_passes_in_flight();
+    else (void)hipGetLastError();           /* "not ready" is an answer, not an error to be found by a later check */
 }
 
 extern "C" void framebuffer_read_device(rz_framebuffer *p, void *color, void *depth) {
