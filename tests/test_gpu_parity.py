@@ -215,3 +215,52 @@ def test_gpu_passes_into_one_framebuffer_stay_ordered(gpu, oracle):
         results.append([cleared, piled] + sides)
     for got, want in zip(*results):
         assert_same(got, want, w * h)
+
+
+class _Texture(C.Structure):
+    _fields_ = [("width", C.c_int), ("height", C.c_int), ("buffer", C.POINTER(C.c_float))]
+
+
+def _texture_api(lib):
+    lib.texture_create.restype = C.POINTER(_Texture)
+    lib.texture_create.argtypes = [C.c_int, C.c_int]
+    lib.texture_release.argtypes = [C.POINTER(_Texture)]
+    lib.texture_sync.argtypes = [C.POINTER(_Texture)]
+    lib.texture_from_colorbuffer.argtypes = [C.POINTER(_Texture), C.c_void_p]
+    lib.texture_from_depthbuffer.argtypes = [C.POINTER(_Texture), C.c_void_p]
+
+
+@pytest.mark.parametrize("recorded", [True, False], ids=["recorded-behind-the-draws", "after-a-read"])
+def test_gpu_framebuffer_copies_into_textures(gpu, oracle, recorded):
+    """texture_from_colorbuffer / texture_from_depthbuffer (texture.c:130-158): texels = byte / 255.0f
+    per channel, and (d, d, d, 1).  Called right after the draws (the copy is then recorded behind them
+    and runs at the next flush) and after the frame has been read back (nothing pending: it runs at
+    once); either way the texture's host image, made valid by texture_sync, equals the oracle's."""
+    w, h = 160, 90
+    images = []
+    for pipe in (gpu, oracle):
+        _texture_api(pipe.lib)
+        scene = pipe.open_scene("helmet")
+        fb = pipe.framebuffer(w, h)
+        colour, depth = pipe.lib.texture_create(w, h), pipe.lib.texture_create(w, h)
+        pipe.draw(scene, fb, pipe.orbit_view(2, 16))
+        if not recorded:
+            pipe.read(fb)
+        pipe.lib.texture_from_colorbuffer(colour, fb)
+        pipe.lib.texture_from_depthbuffer(depth, fb)
+        frame = pipe.read(fb)
+        out = []
+        for t in (colour, depth):
+            pipe.lib.texture_sync(t)
+            out.append(np.ctypeslib.as_array(t.contents.buffer, (h, w, 4)).copy())
+            pipe.lib.texture_release(t)
+        images.append((frame, out))
+        pipe.release(fb)
+        pipe.close_scene(scene)
+    (gf, (gc, gd)), (of, (oc, od)) = images
+    assert_same(gf, of, w * h)
+    # the copies against the frame they were taken from, exactly
+    assert np.array_equal(gc, gf[0].astype(np.float32) / np.float32(255.0))
+    assert np.array_equal(gd[..., 0], gf[1]) and np.array_equal(gd[..., 1], gf[1]) and np.array_equal(gd[..., 2], gf[1])
+    assert np.all(gd[..., 3] == 1)
+    assert np.array_equal(od[..., 0], of[1]) and np.array_equal(oc, of[0].astype(np.float32) / np.float32(255.0))
