@@ -176,3 +176,99 @@ def test_empty_pass_and_clear_only(gpu, oracle):
     assert np.all(a[0] == [25, 51, 76, 255]) and np.all(a[1] == 1.0)      # float_to_uchar truncates (maths.c:33)
     outside = random_triangles(1, 10, 0.3) + np.float32(5.0)             # all off screen
     assert same(skybox_frame(gpu, (70, 40), outside), b)
+
+
+class Vertex(C.Structure):
+    _fields_ = [("position", C.c_float * 3), ("texcoord", C.c_float * 2), ("normal", C.c_float * 3),
+                ("tangent", C.c_float * 4), ("joint", C.c_float * 4), ("weight", C.c_float * 4)]
+
+
+class HostTexture(C.Structure):
+    _fields_ = [("width", C.c_int), ("height", C.c_int), ("buffer", C.POINTER(C.c_float))]
+
+
+assert C.sizeof(Vertex) == 80
+
+SHADER = C.CFUNCTYPE(None)
+
+
+def test_gpu_invalidation_and_registered_shader_pairs(gpu, oracle):
+    """The three calls a host needs when it goes around the recorded state: texture_invalidate after
+    writing texture->buffer by hand, mesh_invalidate after changing a vertex array that was drawn
+    with graphics_draw_mesh, and program_register_family for shader functions of its own (the
+    library tells families by function pointer; the functions themselves are never called)."""
+    w, h = 96, 64
+    frames = []
+    keep = []
+    for pipe in (gpu, oracle):
+        lib = pipe.lib
+        declare(lib)
+        P = C.c_void_p
+        lib.texture_create.restype = C.POINTER(HostTexture)
+        lib.texture_create.argtypes = [C.c_int, C.c_int]
+        lib.texture_release.argtypes = [C.POINTER(HostTexture)]
+        lib.texture_invalidate.argtypes = [C.POINTER(HostTexture)]
+        lib.graphics_draw_mesh.argtypes = [P, P, P, C.c_int]
+        lib.mesh_invalidate.argtypes = [P]
+        lib.program_register_family.argtypes = [P, P, C.c_int]
+        if pipe is gpu:
+            # a shader pair of the host's own, registered as blinn (the GPU library never calls it)
+            vs, fs = SHADER(lambda: None), SHADER(lambda: None)
+            keep += [vs, fs]
+            lib.program_register_family(C.cast(vs, P), C.cast(fs, P), 0)
+            prog = lib.program_create(C.cast(vs, P), C.cast(fs, P), 64, 44, 344, 1, 0)
+        else:
+            # the oracle runs the shader functions it is given, like the reference: its own blinn pair
+            prog = lib.program_create(fn(lib, "blinn_vertex_shader"), fn(lib, "blinn_fragment_shader"), 64, 44, 344, 1, 0)
+        u = BlinnUniforms.from_address(lib.program_get_uniforms(prog))
+        u.light_dir[:] = [0.0, 0.0, -1.0]
+        u.camera_pos[:] = [0.0, 0.0, 2.0]
+        u.model_matrix[:] = IDENTITY4[:]
+        u.normal_matrix[:] = IDENTITY3[:]
+        u.light_vp_matrix[:] = IDENTITY4[:]
+        u.camera_vp_matrix[:] = IDENTITY4[:]
+        u.ambient_intensity = 1.0
+        u.punctual_intensity = 0.0
+        u.shininess = 4.0
+        u.basecolor[:] = [1.0, 1.0, 1.0, 1.0]
+        tex = lib.texture_create(8, 8)
+        texels = np.ctypeslib.as_array(tex.contents.buffer, (8, 8, 4))
+        texels[...] = [0.25, 0.5, 0.75, 1.0]
+        lib.texture_invalidate(tex)                 # texture_create's image was uploaded as zeros at most; this one counts
+        u.diffuse_map = C.cast(tex, P)
+        verts = (Vertex * 3)()
+        for j, (x, y) in enumerate([(-0.8, -0.8), (0.8, -0.8), (0.0, 0.8)]):
+            verts[j].position[:] = [x, y, 0.0]
+            verts[j].texcoord[:] = [0.5, 0.5]
+            verts[j].normal[:] = [0.0, 0.0, 1.0]
+        fb = pipe.framebuffer(w, h)
+        out = []
+        lib.graphics_draw_mesh(C.cast(fb, P), prog, C.cast(verts, P), 1)
+        out.append(pipe.read(fb))
+        # new texels, same texture object
+        texels[...] = [1.0, 0.125, 0.0, 1.0]
+        lib.texture_invalidate(tex)
+        lib.framebuffer_clear_color(fb, Vec4(0.0, 0.0, 0.0, 1.0))
+        lib.framebuffer_clear_depth(fb, 1.0)
+        lib.graphics_draw_mesh(C.cast(fb, P), prog, C.cast(verts, P), 1)
+        out.append(pipe.read(fb))
+        # new positions, same vertex array
+        for j in range(3):
+            verts[j].position[0] *= 0.5
+            verts[j].position[1] *= -0.5
+        lib.mesh_invalidate(C.cast(verts, P))
+        lib.framebuffer_clear_color(fb, Vec4(0.0, 0.0, 0.0, 1.0))
+        lib.framebuffer_clear_depth(fb, 1.0)
+        lib.graphics_draw_mesh(C.cast(fb, P), prog, C.cast(verts, P), 1)
+        out.append(pipe.read(fb))
+        frames.append(out)
+        pipe.release(fb)
+        lib.program_release(prog)
+        lib.texture_release(tex)
+    got, want = frames
+    for a, b in zip(got, want):
+        assert same(a, b)
+    covered = [int((f[1] < 1).sum()) for f in got]
+    assert covered[0] == covered[1] > 500 and 0 < covered[2] < covered[0] // 2      # the mesh did shrink
+    inside = got[0][1] < 1
+    assert np.all(got[0][0][inside][:, :3] == [63, 127, 191]) and np.all(got[1][0][inside][:, :3] == [255, 31, 0])
