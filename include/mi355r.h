@@ -229,6 +229,9 @@ void graphics_flush(void);
  * valid on the host.  Any code that reads or writes those arrays directly
  * (blit, 2D overlay, dumps) calls this first. */
 void framebuffer_sync(rz_framebuffer *framebuffer);
+/* The same for color_buffer alone: what a blit needs (renderer/core/private.c:8-28 reads nothing
+ * else), half the bytes over the bus. */
+void framebuffer_sync_color(rz_framebuffer *framebuffer);
 /* Same for a texture written by texture_from_{color,depth}buffer. */
 void texture_sync(rz_texture *texture);
 /* Tells the library that texture->buffer was modified by the host. */

@@ -100,6 +100,7 @@ void framebuffer_clear_depth(rz_framebuffer *fb, float depth) {
 }
 
 void framebuffer_sync(rz_framebuffer *fb) { trace_close(fb); }
+void framebuffer_sync_color(rz_framebuffer *fb) { trace_close(fb); }
 void graphics_flush(void) {}
 
 void framebuffer_read(rz_framebuffer *fb, void *color, void *depth) {

@@ -383,6 +383,11 @@ extern "C" void framebuffer_sync(rz_framebuffer *p) {
     framebuffer_read(p, fb->pub.color_buffer, fb->pub.depth_buffer);
 }
 
+extern "C" void framebuffer_sync_color(rz_framebuffer *p) {
+    Fb *fb = as_fb(p);
+    framebuffer_read(p, fb->pub.color_buffer, nullptr);
+}
+
 extern "C" void framebuffer_read(rz_framebuffer *p, void *color, void *depth) {
     Fb *fb = as_fb(p);
     graphics_flush();

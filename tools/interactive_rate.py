@@ -14,7 +14,9 @@ fb = gpu.framebuffer(W, H)
 views = [gpu.orbit_view(i, 240) for i in range(240)]
 for v in views[:20]:
     gpu.draw(scene, fb, v); gpu.lib.framebuffer_sync(fb)
-for what, sync in (("frame on the host (framebuffer_sync)", lambda: gpu.lib.framebuffer_sync(fb)),
+gpu.lib.framebuffer_sync_color.argtypes = gpu.lib.framebuffer_sync.argtypes
+for what, sync in (("colour and depth on the host (framebuffer_sync)", lambda: gpu.lib.framebuffer_sync(fb)),
+                   ("colour on the host (framebuffer_sync_color)", lambda: gpu.lib.framebuffer_sync_color(fb)),
                    ("frame finished on the device (framebuffer_read_device of nothing)", lambda: gpu.lib.framebuffer_read_device(fb, None, None))):
     t0 = time.perf_counter()
     for v in views:
