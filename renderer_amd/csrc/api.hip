@@ -1346,15 +1346,6 @@ static void launch_batch(const Batch &b, const std::vector<PassPlan> &plans, cha
     rz_setup_kernel<<<tgrid, dim3(256), 0, st>>>(passes);
     rz_clip_kernel<<<dim3(256, n), dim3(64), 0, st>>>(passes);
     stamp();
-    {
-        size_t matrix = 0;
-        for (size_t i : b.members) {
-            const PassPlan &pl = plans[i];
-            const int W = pl.fb->pub.width, H = pl.fb->pub.height;
-            matrix += ((pl.T + 63) / 64) * (size_t)((W + RZ_BIN - 1) / RZ_BIN) * ((H + RZ_BIN - 1) / RZ_BIN);
-        }
-        HIP_OK(hipMemsetAsync(L.bin_counts.ptr, 0, matrix * sizeof(uint32_t), st));
-    }
     rz_bin_count_kernel<<<tgrid, dim3(256), 0, st>>>(passes);
     rz_bin_scan_kernel<<<dim3((unsigned)((max_bins + 63) / 64), n), dim3(64 * RZ_SCAN_SEGMENTS), 0, st>>>(passes);
     rz_bin_fill_kernel<<<dim3((unsigned)((max_T + 63) / 64), n), dim3(64 * RZ_FILL_WAVES), 0, st>>>(passes);

@@ -67,6 +67,10 @@ __global__ void __launch_bounds__(256) rz_vertex_kernel(const PassParams *__rest
     if (blockIdx.y == 0 && gv < 3u * RZ_QUEUE_WAYS) P.queue_counts[gv * RZ_QUEUE_PAD] = 0;    /* ... and the batch's work-list lengths */
     /* the grid is sized for the largest pass of the batch: all of its threads share the clearing */
     for (uint32_t t = gv; t < (uint32_t)(P.tiles_x * P.tiles_y); t += gridDim.x * 256u) P.tile_listed[t] = 0;
+    {   /* ... and the pass's (chunk, bin) matrix, which rz_bin_count_kernel adds into */
+        const uint32_t cells = (((uint32_t)P.num_tris + 63u) / 64u) * (uint32_t)(P.bins_x * P.bins_y);
+        for (uint32_t t = gv; t < cells; t += gridDim.x * 256u) P.bin_counts[t] = 0;
+    }
     if (gv >= 3u * (uint32_t)P.num_tris) return;
     int d = find_draw(P.first_tri, P.num_draws, gv / 3u);
     const DrawRec &D = P.draws[d];
