@@ -554,7 +554,6 @@ __global__ void __launch_bounds__(64 * RZ_FILL_WAVES) rz_bin_fill_kernel(const P
     if (t < (uint32_t)P.num_tris) r = bin_rect_of(P.bbox[t]);
     const unsigned long long active = __ballot(r.entries != 0);
     if (!active) return;                                        /* same for every wave of the workgroup */
-    if (P.debug_skip == 5) return;
     const int ux0 = wave_min_i(r.entries ? r.bx0 : 0x7fffffff), ux1 = wave_max_i(r.entries ? r.bx1 : -1);
     const int uy0 = wave_min_i(r.entries ? r.by0 : 0x7fffffff), uy1 = wave_max_i(r.entries ? r.by1 : -1);
     const int uw = ux1 - ux0 + 1, ubins = uw * (uy1 - uy0 + 1);
@@ -588,7 +587,6 @@ __global__ void __launch_bounds__(64 * RZ_FILL_WAVES) rz_bin_fill_kernel(const P
     }
     const uint32_t *row = P.bin_counts + (size_t)chunk * (uint32_t)bins;
     const TriRec *__restrict__ fan_tri = P.fan_tri;
-    if (P.debug_skip == 6) return;
 
     if (ubins <= RZ_FILL_FEW_BINS) {
         /* The chunk's triangles lie in a few bins (a dense mesh: most chunks).  Lanes stay
@@ -652,7 +650,7 @@ __global__ void __launch_bounds__(64 * RZ_FILL_WAVES) rz_bin_fill_kernel(const P
             todo &= todo - 1;
             const int x0 = RZ_BCAST_I(r.bx0, L), x1 = RZ_BCAST_I(r.bx1, L);
             const int y0 = RZ_BCAST_I(r.by0, L), y1 = RZ_BCAST_I(r.by1, L);
-            const bool hit = keep && bx >= x0 && bx <= x1 && by >= y0 && by <= y1 && P.debug_skip != 7;
+            const bool hit = keep && bx >= x0 && bx <= x1 && by >= y0 && by <= y1;
             if (!__any(hit)) continue;
             const uint32_t e = (uint32_t)RZ_BCAST_I(r.entries, L);
             const uint32_t refL = (uint32_t)RZ_BCAST_I(ref, L);
@@ -1217,7 +1215,6 @@ __global__ void __launch_bounds__(256 / PPL) rz_visibility_kernel(const PassPara
         }
         int x = x0, y = y0;
         const uint32_t low = ~ord;
-        if (P.debug_skip == 11) return;
         while (__any(y <= y1)) {
             if (y <= y1) {
                 float w0, w1, w2;
@@ -1227,7 +1224,7 @@ __global__ void __launch_bounds__(256 / PPL) rz_visibility_kernel(const PassPara
                     const uint32_t bits = __float_as_uint(depth + 0.0f);
                     const uint32_t up = bits ^ ((uint32_t)((int32_t)bits >> 31) | 0x80000000u);
                     const int lx = x - bx0, ly = y - by0;
-                    if (P.debug_skip != 12) atomicMin(&keys[(lx >> 3) * 64 + (ly << 3) + (lx & 7)], ((unsigned long long)up << 32) | low);
+                    atomicMin(&keys[(lx >> 3) * 64 + (ly << 3) + (lx & 7)], ((unsigned long long)up << 32) | low);
                 }
                 if (++x > x1) { x = x0; y++; }
             }
@@ -1371,7 +1368,6 @@ __global__ void __launch_bounds__(256 / PPL) rz_visibility_kernel(const PassPara
         }
     }
 
-    if (P.debug_skip == 8 || P.debug_skip == 10) return;
     if (BLEND) {
         if (__any(needs_order) && lane == 0) s_ordered = 1;
         __syncthreads();
