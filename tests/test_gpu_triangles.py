@@ -135,6 +135,18 @@ def test_equal_depth_overlap_last_writer_wins(gpu, oracle, size, n, spread):
     assert same(skybox_frame(gpu, size, tris), skybox_frame(oracle, size, tris))
 
 
+@pytest.mark.parametrize("size,n,extent", [((128, 96), 4000, 0.05), ((64, 64), 6000, 0.12), ((200, 40), 3000, 0.02)])
+def test_many_small_triangles_at_equal_depth(gpu, oracle, size, n, extent):
+    """Thousands of triangles of a few pixels each in a handful of bins, all at the same depth: the
+    rasteriser takes them many at a time, one per lane, and settles every pixel by an atomic
+    minimum over (depth, submission order) -- the last one submitted has to win exactly as in the
+    reference's sequential loop, and triangles of one pixel or none must not disturb that."""
+    rng = np.random.default_rng(100 + n)
+    centre = rng.uniform(-0.9, 0.9, (n, 1, 3))
+    tris = (centre + rng.uniform(-extent, extent, (n, 3, 3))).astype(np.float32)
+    assert same(skybox_frame(gpu, size, tris), skybox_frame(oracle, size, tris))
+
+
 def test_triangles_through_the_clipper(gpu, oracle):
     """Corners far outside the view volume in x, y and z, and behind w = 0 is impossible here
     (w = 1), so the +-x, +-y, +-z planes do the work (graphics.c:279-313)."""
