@@ -42,16 +42,18 @@ for f in glob.glob(os.path.join(out, "*", "**", "*counter_collection.csv"), recu
 
 def steady(v):
     """average over the launches of the benchmark's ordinary steps: without those that take more than twice
-    the median (the first launch of a kernel, which loads its code; the untimed step in which bench.py
-    turns the device-side fragment counters on, whose atomics make every launch 30 times longer)"""
+    the median (the untimed step in which bench.py turns the device-side fragment counters on, whose atomics
+    make every launch 30 times longer) or less than half of it (the small frame bench.py draws first to
+    load the code and the scene)"""
     m = median(v)
-    kept = [d for d in v if d <= 2 * m]
+    kept = [d for d in v if 0.5 * m <= d <= 2 * m]
     return sum(kept) / len(kept) if kept else float("nan")
 
 
 print("avg us = rocprofv3's own average over all launches, including bench.py's one untimed counting step (device-side")
-print("fragment counters on: every launch takes 30 times longer) and first launches; steady avg us = without the launches")
-print("longer than twice the median, i.e. the ordinary steps, which is what bench.py's HIP-event figure measures")
+print("fragment counters on: every launch takes 30 times longer) and the small first frame; steady avg us = without the")
+print("launches longer than twice or shorter than half the median, i.e. the ordinary steps, which is what bench.py's")
+print("HIP-event figure measures")
 print(f"{'kernel':34s} {'calls':>6s} {'avg us':>9s} {'%':>6s} {'steady avg us':>14s} {'median us':>10s}")
 for k, (calls, avg, pct) in sorted(stats.items(), key=lambda kv: -kv[1][2]):
     print(f"{k:34s} {calls:6d} {avg:9.2f} {pct:6.2f} {steady(durations.get(k, [])):14.2f} {median(durations.get(k, [])):10.2f}")
