@@ -300,6 +300,16 @@ int mi355r_inspect_pass(rz_pass_info *info);
 void mi355r_inspect_boxes(unsigned int *boxes, unsigned int *fans);
 void mi355r_inspect_bins(unsigned int *counts, unsigned int *entries);
 
+/* Scratch estimates (tests).  The clipper's block table and the bin lists of a pass are sized by an
+ * estimate before the pass runs; a pass that needs more does not touch its framebuffer, reports what
+ * it needs, and is run again -- together with the passes of its flush that may depend on it -- before
+ * the next flush starts or its framebuffer is read, so no input makes the library give up
+ * (graphics.c:537-608 renders any input).  mi355r_set_scratch_estimate forces the first-time sizes
+ * (clipper blocks and list entries per pass; 0, 0 = the library's own estimate), which lets a test
+ * send ordinary scenes down that road; mi355r_passes_run_again counts the passes that took it. */
+void mi355r_set_scratch_estimate(unsigned long long fan_blocks, unsigned long long list_entries);
+unsigned long long mi355r_passes_run_again(void);
+
 /* Device image formats.  texture->buffer is float RGBA as in the reference
  * (texture.h:14-17); on the device an image is kept in 4 bytes per texel when
  * that loses nothing, which is decided by looking at every texel.  This entry

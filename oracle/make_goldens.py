@@ -21,11 +21,12 @@ GOLDEN = os.path.join(REPO, "tests", "golden")
 REFDUMP = os.path.join(HERE, "_ref", "refdump")
 
 
-def run_case(case, assets):
+def run_case(case, assets, binary=None, env=None):
+    """Renders one case with a build of ref_driver.c (default: the unmodified reference, strict build)."""
     w, h = case["size"]
     with tempfile.NamedTemporaryFile(suffix=".bin", delete=False) as tmp:
         out = tmp.name
-    cmd = [REFDUMP, "--scene", case["ref"], "--assets", assets, "--size", str(w), str(h), "--out", out]
+    cmd = [binary or REFDUMP, "--scene", case["ref"], "--assets", assets, "--size", str(w), str(h), "--out", out]
     if case["scene"].endswith(".scn"):
         cmd += ["--scn", os.path.join(REPO, "scenes", case["scene"])]
     if "eye" in case:
@@ -36,7 +37,7 @@ def run_case(case, assets):
         cmd += ["--time", repr(float(case["time"]))]
     if "layer" in case:
         cmd += ["--layer", str(case["layer"])]
-    subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL)
+    subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, env=env, timeout=300)
     raw = open(out, "rb").read()
     os.unlink(out)
     magic, rw, rh, _ = struct.unpack("4i", raw[:16])

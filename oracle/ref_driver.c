@@ -24,6 +24,13 @@
 #include "scenes/scene_helper.h"
 #include "tests/test_helper.h"
 
+#ifdef RZ_DROP_IN
+/* Built on top of the C ABI instead of the reference's core/graphics.c and
+ * core/texture.c (oracle/Makefile, target refhost): draws are recorded, so a
+ * host that reads color_buffer / depth_buffer itself synchronises first. */
+void framebuffer_sync(framebuffer_t *framebuffer);
+#endif
+
 typedef scene_t *factory_t(void);
 typedef struct {const char *name; factory_t *make;} entry_t;
 
@@ -157,6 +164,9 @@ int main(int argc, char **argv) {
         free(samples);
     }
 
+#ifdef RZ_DROP_IN
+    framebuffer_sync(fb);
+#endif
     if (out) {
         FILE *f = fopen(out, "wb");
         int hdr[4];

@@ -37,13 +37,22 @@ static_assert(sizeof(TriRec) == 64, "TriRec is four float4");
 static_assert(sizeof(BinEntry) == 80, "BinEntry is five float4");
 static_assert(sizeof(DevTex) == 24, "DevTex");
 
+/* The message goes to stderr and, when MI355R_FATAL_LOG names a file, to that file as well: a test
+ * runner that captures stderr loses what it captured when the process aborts. */
 [[noreturn]] static void fatal(const char *fmt, ...) {
+    char text[1024];
     va_list ap;
     va_start(ap, fmt);
-    fprintf(stderr, "mi355r: fatal: ");
-    vfprintf(stderr, fmt, ap);
-    fprintf(stderr, "\n");
+    vsnprintf(text, sizeof text, fmt, ap);
     va_end(ap);
+    fprintf(stderr, "mi355r: fatal: %s\n", text);
+    fflush(stderr);
+    if (const char *path = getenv("MI355R_FATAL_LOG")) {
+        if (FILE *f = fopen(path, "a")) {
+            fprintf(f, "mi355r: fatal: %s\n", text);
+            fclose(f);
+        }
+    }
     abort();
 }
 
@@ -167,7 +176,10 @@ struct Context {
     /* upload ring: pinned host memory mirrored 1:1 in device memory */
     char *ring_host = nullptr, *ring_dev = nullptr;
     size_t ring_size = 0, ring_at = 0;
-    std::vector<size_t> control_slots;      /* ring offsets of passes in flight */
+    /* scratch estimates (scratch_entries): what passes that ran out turned out to need, and values forced for tests */
+    size_t fan_highwater = 0, list_highwater = 0;
+    size_t forced_fan_estimate = 0, forced_list_estimate = 0;
+    unsigned long long passes_run_again = 0;
     /* recording */
     std::vector<Pending> pending;
     std::vector<char> side;                 /* joint matrices snapshotted at record time */
@@ -216,8 +228,8 @@ static void init_packed_formats();
 
 static void sync_stream();
 
+/* events live until the next full synchronisation; graphics_flush bounds their number before it creates its first */
 static hipEvent_t new_event(hipStream_t on) {
-    if (g.events.size() > 8192) sync_stream();      /* bound the number of live events */
     hipEvent_t e;
     HIP_OK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     HIP_OK(hipEventRecord(e, on));
@@ -367,8 +379,11 @@ extern "C" void framebuffer_clear_depth(rz_framebuffer *p, float depth) {
 }
 
 /* a clear that no pass consumed has to be executed on its own */
+static void settle_before_touching(Fb *fb);
+
 static void apply_pending_clear(Fb *fb) {
     if (!fb->clear_color_pending && !fb->clear_depth_pending) return;
+    settle_before_touching(fb);     /* a pass of the flush in flight that has to run again must not come after this clear */
     size_t n = (size_t)fb->pub.width * fb->pub.height;
     if (fb->lane < 0) fb->lane = 0;
     rz_clear_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, g.lanes[fb->lane].stream>>>(
@@ -388,31 +403,30 @@ extern "C" void framebuffer_sync_color(rz_framebuffer *p) {
     framebuffer_read(p, fb->pub.color_buffer, nullptr);
 }
 
-extern "C" void framebuffer_read(rz_framebuffer *p, void *color, void *depth) {
-    Fb *fb = as_fb(p);
+static void settle_framebuffer(Fb *fb);
+
+/* Only this framebuffer's lane has to drain: other frames keep rendering.  The control blocks of its
+ * passes come back on that lane behind them; should one of them say that the pass did not run (out of
+ * scratch), the flush is settled -- that pass and what depends on it run again -- before the pixels
+ * are handed out. */
+static void read_framebuffer(Fb *fb, void *color, void *depth, hipMemcpyKind kind) {
     graphics_flush();
+    HIP_OK(hipStreamSynchronize(g.lanes[fb->lane < 0 ? 0 : fb->lane].stream));
+    settle_framebuffer(fb);
     apply_pending_clear(fb);
     size_t n = (size_t)fb->pub.width * fb->pub.height;
     hipStream_t st = g.lanes[fb->lane < 0 ? 0 : fb->lane].stream;
-    if (color) HIP_OK(hipMemcpyAsync(color, fb->d_color, n * 4, hipMemcpyDeviceToHost, st));
-    if (depth) HIP_OK(hipMemcpyAsync(depth, fb->d_depth, n * sizeof(float), hipMemcpyDeviceToHost, st));
-    HIP_OK(hipStreamSynchronize(st));       /* only this framebuffer's lane has to drain: other frames keep rendering */
-    /* the passes' error words come back on the copy stream, behind every lane of their flush: looked at
-     * here when they have all arrived, otherwise at the next full synchronisation */
-    if (hipStreamQuery(g.copy_stream) == hipSuccess) check_passes_in_flight();
-    else (void)hipGetLastError();           /* "not ready" is an answer, not an error to be found by a later check */
+    if (color) HIP_OK(hipMemcpyAsync(color, fb->d_color, n * 4, kind, st));
+    if (depth) HIP_OK(hipMemcpyAsync(depth, fb->d_depth, n * sizeof(float), kind, st));
+    HIP_OK(hipStreamSynchronize(st));
+}
+
+extern "C" void framebuffer_read(rz_framebuffer *p, void *color, void *depth) {
+    read_framebuffer(as_fb(p), color, depth, hipMemcpyDeviceToHost);
 }
 
 extern "C" void framebuffer_read_device(rz_framebuffer *p, void *color, void *depth) {
-    Fb *fb = as_fb(p);
-    graphics_flush();
-    apply_pending_clear(fb);
-    size_t n = (size_t)fb->pub.width * fb->pub.height;
-    /* only this framebuffer's lane has to drain: other frames keep rendering */
-    hipStream_t st = g.lanes[fb->lane < 0 ? 0 : fb->lane].stream;
-    if (color) HIP_OK(hipMemcpyAsync(color, fb->d_color, n * 4, hipMemcpyDeviceToDevice, st));
-    if (depth) HIP_OK(hipMemcpyAsync(depth, fb->d_depth, n * sizeof(float), hipMemcpyDeviceToDevice, st));
-    HIP_OK(hipStreamSynchronize(st));
+    read_framebuffer(as_fb(p), color, depth, hipMemcpyDeviceToDevice);
 }
 
 /* ---------------------------------------------------------------- textures -- */
@@ -571,7 +585,10 @@ static void upload_texture(Tex *t) {
     int w = t->pub.width, h = t->pub.height;
     size_t bytes = (size_t)w * h * sizeof(float4);
     graphics_flush();               /* recorded draws may still sample the old image */
-    if (t->write_lane >= 0 || !t->read_events.empty()) sync_stream();
+    /* ... and so may passes that are still running, on any lane: an image that is replaced (after
+     * texture_invalidate, or one the GPU wrote) waits for all of them.  Only the first upload of an
+     * image has no reader yet. */
+    if (t->d_data || t->write_lane >= 0 || !t->read_events.empty()) sync_stream();
     t->write_lane = -1;
     std::vector<uint32_t> packed;
     const int format = g.pack_textures ? pack_texels(t->pub.buffer, (size_t)w * h, packed) : 0;
@@ -656,18 +673,7 @@ static void end_texture_write(Tex *t, Fb *fb, hipEvent_t shared = nullptr) {
     t->host_stale = true;
 }
 
-static void launch_texture_write(Tex *t, Fb *fb, bool depth) {
-    const int w = t->pub.width, h = t->pub.height;
-    hipStream_t st = begin_texture_write(t, fb);
-    if (depth)
-        rz_depth_to_texture_kernel<<<dim3((w + 15) / 16, (h + 15) / 16), dim3(256), 0, st>>>(
-            fb->d_depth, (float*)t->d_data, w, h, t->flags, t->mbits);
-    else
-        rz_color_to_texture_kernel<<<dim3((w + 15) / 16, (h + 15) / 16), dim3(256), 0, st>>>(
-            fb->d_color, (float4*)t->d_data, w, h, t->flags, t->mbits);
-    HIP_OK(hipGetLastError());
-    end_texture_write(t, fb);
-}
+static void launch_texture_write(Tex *t, Fb *fb, bool depth);
 
 /* texture.c:130-158.  When the framebuffer still has recorded draws the copy is recorded too, behind
  * them, and runs at the next flush between the passes on either side of it: a frame made of a
@@ -1005,6 +1011,8 @@ static void snapshot_uniforms_once(rz_program *p, Pending &pd, int num_joints) {
         pd.joint_normals_at = g.side.size();
         if (joint_normals)
             g.side.insert(g.side.end(), (const char*)joint_normals, (const char*)joint_normals + sizeof(rz_mat3) * num_joints);
+        else
+            g.side.insert(g.side.end(), sizeof(rz_mat3) * num_joints, 0);    /* a shadow pass reads none; the layout stays the same */
         while (g.side.size() % 16) g.side.push_back(0);
     }
 }
@@ -1023,8 +1031,51 @@ extern "C" void graphics_draw_mesh(rz_framebuffer *fp, rz_program *program, cons
     g.pending.push_back(std::move(pd));
 }
 
+/* the joint matrices a program's uniform block points at right now (nullptr: not skinned) */
+static void pose_of(const rz_program *p, const rz_mat4 **joints, const rz_mat3 **joint_normals) {
+    *joints = nullptr;
+    *joint_normals = nullptr;
+    if (p->family == RZ_FAMILY_BLINN) {
+        *joints = ((const rz_blinn_uniforms*)p->uniforms)->joint_matrices;
+        *joint_normals = ((const rz_blinn_uniforms*)p->uniforms)->joint_n_matrices;
+    } else if (p->family == RZ_FAMILY_PBR) {
+        *joints = ((const rz_pbr_uniforms*)p->uniforms)->joint_matrices;
+        *joint_normals = ((const rz_pbr_uniforms*)p->uniforms)->joint_n_matrices;
+    }
+}
+
+/* Whether one more triangle that refers to joints [0, need) can join the draw `last` (the most
+ * recent record; its uniform block already compared equal, so the matrices sit at the same
+ * addresses): the matrices that draw snapshotted must still be what the host holds -- the skeleton
+ * rewrites them in place (skeleton.c:336-337) without telling anybody.  A triangle that refers to
+ * more joints than the draw has seen so far extends the snapshot, which is the last thing in the
+ * side buffer. */
+static bool same_pose(const rz_program *p, Pending &last, int need) {
+    if (last.num_joints == 0) return true;          /* the draw is not skinned: its uniform block says all */
+    const rz_mat4 *joints;
+    const rz_mat3 *joint_normals;
+    pose_of(p, &joints, &joint_normals);
+    if (!joints) return false;
+    const size_t n = (size_t)last.num_joints;
+    if (memcmp(g.side.data() + last.joints_at, joints, sizeof(rz_mat4) * n) != 0) return false;
+    if (joint_normals && memcmp(g.side.data() + last.joint_normals_at, joint_normals, sizeof(rz_mat3) * n) != 0) return false;
+    if ((size_t)need > n) {
+        g.side.resize(last.joints_at);
+        g.side.insert(g.side.end(), (const char*)joints, (const char*)joints + sizeof(rz_mat4) * need);
+        last.joint_normals_at = g.side.size();
+        if (joint_normals)
+            g.side.insert(g.side.end(), (const char*)joint_normals, (const char*)joint_normals + sizeof(rz_mat3) * need);
+        else
+            g.side.insert(g.side.end(), sizeof(rz_mat3) * need, 0);
+        while (g.side.size() % 16) g.side.push_back(0);
+        last.num_joints = need;
+    }
+    return true;
+}
+
 /* graphics.c:537: one triangle from the program's three attribute blocks.
- * Consecutive calls with an unchanged uniform block extend one draw. */
+ * Consecutive calls with an unchanged uniform block -- and, for a skinned
+ * program, unchanged joint matrices -- extend one draw. */
 extern "C" void graphics_draw_triangle(rz_framebuffer *fp, rz_program *program) {
     Fb *fb = as_fb(fp);
     rz_vertex tri[3];
@@ -1047,9 +1098,10 @@ extern "C" void graphics_draw_triangle(rz_framebuffer *fp, rz_program *program) 
     if (!g.pending.empty()) {
         Pending &last = g.pending.back();
         const bool copy_between = !g.tex_writes.empty() && g.tex_writes.back().after == g.pending.size();
-        if (!copy_between && last.transient && last.fb == fb && last.program == program && last.num_joints == 0 &&
+        if (!copy_between && last.transient && last.fb == fb && last.program == program &&
             last.uniform_bytes.size() == (size_t)program->uniform_bytes &&
-            memcmp(last.uniform_bytes.data(), ub, program->uniform_bytes) == 0) {
+            memcmp(last.uniform_bytes.data(), ub, program->uniform_bytes) == 0 &&
+            same_pose(program, last, top + 1)) {
             last.verts.insert(last.verts.end(), tri, tri + 3);
             last.rec.num_faces++;
             return;
@@ -1068,9 +1120,22 @@ extern "C" void graphics_draw_triangle(rz_framebuffer *fp, rz_program *program) 
 
 /* ------------------------------------------------------------------- flush -- */
 
+static const size_t CONTROL_BYTES = 64;
+
 static size_t ring_alloc(size_t bytes) {
     bytes = (bytes + 255) & ~(size_t)255;
-    if (bytes > g.ring_size) fatal("one flush needs %zu bytes of upload space (ring is %zu)", bytes, g.ring_size);
+    if (bytes > g.ring_size) {
+        /* a flush larger than the ring (hundreds of thousands of triangles recorded one by one): a larger ring */
+        sync_stream();
+        size_t size = g.ring_size;
+        while (size < bytes) size *= 2;
+        HIP_OK(hipHostFree(g.ring_host));
+        HIP_OK(hipFree(g.ring_dev));
+        HIP_OK(hipHostMalloc((void**)&g.ring_host, size, hipHostMallocDefault));
+        HIP_OK(hipMalloc((void**)&g.ring_dev, size));
+        g.ring_size = size;
+        g.ring_at = 0;
+    }
     if (g.ring_at + bytes > g.ring_size) {
         sync_stream();              /* everything that used the ring has finished */
         g.ring_at = 0;
@@ -1080,20 +1145,9 @@ static size_t ring_alloc(size_t bytes) {
     return at;
 }
 
-static void check_passes_in_flight() {
-    for (size_t at : g.control_slots) {
-        const uint32_t *c = (const uint32_t*)(g.ring_host + at);
-        if (c[2] & RZ_ERR_FAN_OVERFLOW) fatal("clipped-triangle buffer overflow (%u blocks needed)", c[0]);
-        if (c[2] & RZ_ERR_BIN_OVERFLOW) fatal("bin list overflow (%u entries needed)", c[1]);
-        if (c[2] & RZ_ERR_QUEUE_OVERFLOW) fatal("shade work list overflow");
-        g.host_counters[3] += c[1];
-    }
-    g.control_slots.clear();
-}
-
 /* layout of one pass inside the flush's upload region */
 struct PassPlan {
-    size_t first, last;             /* range in g.pending */
+    size_t first, last;             /* range in g.pending (while the flush is being put together) */
     size_t T;                       /* triangles */
     size_t off_draws, off_first;    /* offsets from the region start */
     std::vector<size_t> side_at, verts_at;
@@ -1101,9 +1155,9 @@ struct PassPlan {
     bool narrow_texels;             /* every blinn / pbr draw samples 4-byte images only */
     int families;
     Fb *fb;
+    int level;                      /* 0: depends on no other pass of the flush */
+    size_t slot;                    /* its place in batch order: control block and PassParams of the pass */
 };
-
-static const size_t CONTROL_BYTES = 64;
 
 static void plan_pass(PassPlan &pl, size_t &total) {
     const size_t D = pl.last - pl.first;
@@ -1121,8 +1175,6 @@ static void plan_pass(PassPlan &pl, size_t &total) {
         if (pd.rec.family != RZ_FAMILY_SKYBOX && !(pd.rec.flags & RZ_DRAW_NARROW_TEXELS)) pl.narrow_texels = false;
     }
     if (g.monolithic) pl.has_blend = true;
-    if (D > 65535) fatal("%zu draws in one pass (limit 65535)", D);
-    if (pl.T > 0x0fffffffu) fatal("%zu triangles in one pass", pl.T);
     total = (total + 255) & ~(size_t)255;
     pl.off_draws = total;
     total += sizeof(DrawRec) * D;
@@ -1177,10 +1229,27 @@ static void fill_pass(const PassPlan &pl, char *hb, char *db) {
 struct Batch {
     std::vector<size_t> members;    /* indices into the flush's plan list, in submission order */
     int lane;
-    size_t off_params;              /* PassParams[] in the upload region */
+    size_t off_params;              /* PassParams[] of the members in the upload region */
     bool has_blend;
     int families;
 };
+
+/* What is kept of a flush until its control blocks have been looked at: enough to run any of its
+ * passes again.  Its region of the upload ring:
+ *   [control block per pass][flush word][PassParams per pass][PassParams for passes run again][pass tables]
+ * Control blocks and PassParams are in batch order (PassPlan::slot). */
+struct FlushRecord {
+    size_t at = 0;                                          /* the region */
+    size_t flag_at = 0, params_at = 0, again_at = 0;        /* offsets in it */
+    std::vector<PassPlan> plans;
+    std::vector<Batch> batches;
+    struct Copy { Tex *tex; Fb *fb; bool depth; size_t producer; };     /* producer: the plan whose pass rendered the source */
+    std::vector<Copy> copies;
+    bool used[MAX_LANES] = {false};
+    const uint32_t *control(size_t plan) const { return (const uint32_t*)(g.ring_host + at + CONTROL_BYTES * plans[plan].slot); }
+    uint32_t *control_dev(size_t plan) const { return (uint32_t*)(g.ring_dev + at + CONTROL_BYTES * plans[plan].slot); }
+};
+static std::vector<FlushRecord> g_in_flight;
 
 /* whether a batch of passes with blended draws takes the visibility-first route */
 static bool splits_blend(size_t batch_tiles, size_t passes) {
@@ -1188,9 +1257,34 @@ static bool splits_blend(size_t batch_tiles, size_t passes) {
     return g.split_blend == 1 || batch_tiles >= 16384 * passes;
 }
 
-/* sizes the lane's scratch for the batch and (second call) writes the PassParams array */
-static void prepare_batch(const Batch &b, const std::vector<PassPlan> &plans, char *hb, char *db, size_t controls_at,
-                          bool reserve_only) {
+/* Entries of the clipper's block table and of the bin lists a pass gets.  First time round an
+ * estimate: a block per triangle up to 2^18, 16 list entries per triangle but at least 2^18 --
+ * never more than a triangle in every bin with a full fan -- raised to what earlier passes turned out
+ * to need (or set by mi355r_set_scratch_estimate).  A pass that is run again gets exactly what it
+ * reported (control[0], control[1]). */
+static void scratch_entries(const FlushRecord &fr, size_t plan, bool again, size_t *fan_cap, size_t *list_cap) {
+    const PassPlan &pl = fr.plans[plan];
+    if (again) {
+        const uint32_t *c = fr.control(plan);
+        *fan_cap = std::max<size_t>(c[0], 1);
+        *list_cap = std::max<size_t>(c[1], 1);
+        return;
+    }
+    const size_t nb = (size_t)((pl.fb->pub.width + RZ_BIN - 1) / RZ_BIN) * ((pl.fb->pub.height + RZ_BIN - 1) / RZ_BIN);
+    if (g.forced_fan_estimate || g.forced_list_estimate) {
+        *fan_cap = std::max<size_t>(std::min(pl.T, g.forced_fan_estimate ? g.forced_fan_estimate : (size_t)1 << 18), 1);
+        *list_cap = std::max<size_t>(g.forced_list_estimate ? g.forced_list_estimate : std::max<size_t>(pl.T * 16, 1u << 18), 1);
+        return;
+    }
+    *fan_cap = std::min(pl.T, std::max<size_t>(1u << 18, g.fan_highwater));
+    *list_cap = std::min(pl.T * RZ_MAX_FAN * nb, std::max(std::max<size_t>(pl.T * 16, 1u << 18), g.list_highwater));
+}
+
+/* sizes the lane's scratch for the batch and (second call) writes the PassParams array; `again`: the
+ * batch holds passes of a finished flush that are run a second time */
+static void prepare_batch(const Batch &b, const FlushRecord &fr, bool reserve_only, bool again) {
+    const std::vector<PassPlan> &plans = fr.plans;
+    char *hb = g.ring_host + fr.at, *db = g.ring_dev + fr.at;
     Lane &L = g.lanes[b.lane];
     hipStream_t st = L.stream;
     size_t tris = 0, fans = 0, lists = 0, bins = 0, pixels = 0, matrix = 0, tiles = 0;
@@ -1198,13 +1292,18 @@ static void prepare_batch(const Batch &b, const std::vector<PassPlan> &plans, ch
     for (size_t i : b.members) {
         const PassPlan &pl = plans[i];
         const size_t nb = (size_t)((pl.fb->pub.width + RZ_BIN - 1) / RZ_BIN) * ((pl.fb->pub.height + RZ_BIN - 1) / RZ_BIN);
-        fan_cap.push_back(std::min<size_t>(pl.T, 1u << 18));
-        list_cap.push_back(std::min<size_t>(pl.T * 8 * nb, std::max<size_t>(pl.T * 16, 1u << 18)));
-        tris += pl.T; fans += fan_cap.back(); lists += list_cap.back(); bins += nb;
+        size_t fan, list;
+        scratch_entries(fr, i, again, &fan, &list);
+        fan_cap.push_back(fan);
+        list_cap.push_back(list);
+        tris += pl.T; fans += fan; lists += list; bins += nb;
         matrix += ((pl.T + 63) / 64) * nb;
         tiles += (size_t)((pl.fb->pub.width + RZ_TILE_W - 1) / RZ_TILE_W) * ((pl.fb->pub.height + RZ_TILE_H - 1) / RZ_TILE_H);
         pixels += (size_t)pl.fb->pub.width * pl.fb->pub.height;
     }
+    if (lists > 0xffffffffull || fans * RZ_MAX_FAN > 0x7fffffffull)
+        fatal("a batch of %zu passes needs %zu bin-list entries and %zu clipper blocks: beyond the 32-bit offsets of its tables "
+              "(fewer passes per batch: MI355R_BATCH)", b.members.size(), lists, fans);
     reserve(L.clip, tris * 3 * 4, st);
     reserve(L.vary, tris * 3 * RZ_VARY_STRIDE, st);
     reserve(L.tri, tris, st);
@@ -1231,19 +1330,34 @@ static void prepare_batch(const Batch &b, const std::vector<PassPlan> &plans, ch
         Fb *fb = pl.fb;
         const int W = fb->pub.width, H = fb->pub.height;
         PassParams P;
-        memset(&P, 0, sizeof P);
-        P.color = fb->d_color;
-        P.depth = fb->d_depth;
-        P.width = W;
-        P.height = H;
-        P.clear_color_pending = fb->clear_color_pending;
-        P.clear_depth_pending = fb->clear_depth_pending;
-        P.clear_color = fb->clear_color;
-        P.clear_depth = fb->clear_depth;
-        P.draws = (const DrawRec*)(db + pl.off_draws);
-        P.first_tri = (const uint32_t*)(db + pl.off_first);
-        P.num_draws = (int)(pl.last - pl.first);
-        P.num_tris = (int)pl.T;
+        if (again) {
+            /* as it was submitted: target, pending clears, tables -- only the scratch below changes;
+             * a pass run again waits for nothing of its flush */
+            memcpy(&P, hb + fr.params_at + sizeof(PassParams) * pl.slot, sizeof P);
+            P.level = 0;
+        } else {
+            memset(&P, 0, sizeof P);
+            P.color = fb->d_color;
+            P.depth = fb->d_depth;
+            P.width = W;
+            P.height = H;
+            P.clear_color_pending = fb->clear_color_pending;
+            P.clear_depth_pending = fb->clear_depth_pending;
+            P.clear_color = fb->clear_color;
+            P.clear_depth = fb->clear_depth;
+            P.draws = (const DrawRec*)(db + pl.off_draws);
+            P.first_tri = (const uint32_t*)(db + pl.off_first);
+            P.num_draws = (int)(pl.last - pl.first);
+            P.num_tris = (int)pl.T;
+            P.control = (uint32_t*)(db + CONTROL_BYTES * pl.slot);
+            P.flush_flag = (uint32_t*)(db + fr.flag_at);
+            P.level = pl.level;
+            P.draws_off = pl.off_draws;
+            fb->clear_color_pending = fb->clear_depth_pending = false;
+            g.host_counters[0] += pl.T;
+            g.host_counters[4] += 1;
+            g.host_counters[5] += (unsigned long long)(pl.last - pl.first);
+        }
         P.clip = L.clip.ptr + tri_off * 3 * 4;
         P.vary = L.vary.ptr + tri_off * 3 * RZ_VARY_STRIDE;
         P.tri = L.tri.ptr + tri_off;
@@ -1251,7 +1365,7 @@ static void prepare_batch(const Batch &b, const std::vector<PassPlan> &plans, ch
         P.clip_list = L.clip_list.ptr + tri_off;
         P.fan_tri = L.fan_tri.ptr + fan_off * RZ_MAX_FAN;
         P.fan_vary = L.fan_vary.ptr + fan_off * RZ_MAX_POLY * RZ_VARY_STRIDE;
-        P.fan_capacity = (int)fan_cap[k];
+        P.fan_capacity = (int)std::min<size_t>(fan_cap[k], 0x7fffffff);
         P.bins_x = (W + RZ_BIN - 1) / RZ_BIN;
         P.bins_y = (H + RZ_BIN - 1) / RZ_BIN;
         P.bin_range = L.bin_range.ptr + bin_off;
@@ -1261,7 +1375,6 @@ static void prepare_batch(const Batch &b, const std::vector<PassPlan> &plans, ch
         P.bin_capacity = (uint32_t)list_cap[k];
         P.ref = L.ref.ptr ? L.ref.ptr + ref_off : nullptr;
         P.ref_scanned = (b.families & (1 << RZ_FAMILY_SKYBOX)) != 0;
-        P.control = (uint32_t*)(db + controls_at + CONTROL_BYTES * i);
         P.counters = g.counting ? g.d_counters : nullptr;
         P.debug_skip = g.debug_skip;
         P.micro_area = g.micro_area;
@@ -1279,7 +1392,6 @@ static void prepare_batch(const Batch &b, const std::vector<PassPlan> &plans, ch
         P.list_off = (uint32_t)list_off;
         P.bin_off = (uint32_t)bin_off;
         P.ref_off = ref_off;
-        P.draws_off = pl.off_draws;
         memcpy(hb + b.off_params + sizeof(PassParams) * k, &P, sizeof P);
         g.last_pass = P;
         g.have_last_pass = true;
@@ -1287,10 +1399,6 @@ static void prepare_batch(const Batch &b, const std::vector<PassPlan> &plans, ch
         bin_off += (size_t)P.bins_x * P.bins_y;
         matrix_off += ((pl.T + 63) / 64) * (size_t)P.bins_x * P.bins_y;
         ref_off += (size_t)W * H;
-        fb->clear_color_pending = fb->clear_depth_pending = false;
-        g.host_counters[0] += pl.T;
-        g.host_counters[4] += 1;
-        g.host_counters[5] += (unsigned long long)(pl.last - pl.first);
     }
 }
 
@@ -1405,6 +1513,157 @@ static void launch_batch(const Batch &b, const std::vector<PassPlan> &plans, cha
     if (g.timing) g.timing_passes.push_back(n);
 }
 
+/* one framebuffer -> texture copy job (texture.c:130-158); `producer`: the control block of the pass
+ * that rendered the source, on the device, or nullptr */
+static CopyJob copy_job(Tex *t, Fb *fb, bool depth, const uint32_t *producer) {
+    CopyJob j;
+    memset(&j, 0, sizeof j);
+    j.from = depth ? (const void*)fb->d_depth : (const void*)fb->d_color;
+    j.to = t->d_data;
+    j.w = t->pub.width; j.h = t->pub.height;
+    j.flags = t->flags; j.is_depth = depth ? 1 : 0;
+    j.producer = producer;
+    return j;
+}
+
+/* Runs again, in submission order and one batch at a time, the passes of a finished flush that did
+ * not run: those whose scratch was too small -- their control blocks hold what they need -- and
+ * those that were left out because they might have depended on one of them; then the recorded
+ * copies out of their framebuffers.  Every stream is idle when this is called and again when it
+ * returns. */
+static void run_again(FlushRecord &fr) {
+    char *hb = g.ring_host + fr.at, *db = g.ring_dev + fr.at;
+    size_t again_used = 0, passes_again = 0;
+    for (const Batch &b : fr.batches) {
+        Batch r;
+        r.lane = b.lane;
+        r.has_blend = b.has_blend;
+        r.families = 0;
+        for (size_t i : b.members) {
+            const uint32_t *c = fr.control(i);
+            if (c[2] & RZ_ERR_QUEUE_OVERFLOW) fatal("shade work list overflow (internal error)");
+            if (c[2] == 0) continue;
+            r.members.push_back(i);
+            r.families |= fr.plans[i].families;
+            if (c[2] & RZ_ERR_FAN_OVERFLOW) g.fan_highwater = std::max<size_t>(g.fan_highwater, c[0]);
+            if (c[2] & RZ_ERR_BIN_OVERFLOW) g.list_highwater = std::max<size_t>(g.list_highwater, c[1]);
+        }
+        if (r.members.empty()) continue;
+        r.off_params = fr.again_at + sizeof(PassParams) * again_used;
+        again_used += r.members.size();
+        passes_again += r.members.size();
+        Lane &L = g.lanes[r.lane];
+        /* A pass that ran out of clipper blocks did not bin the triangles it had no block for, so the
+         * list entries it reported are too few: its second run has enough blocks, reports the true
+         * number of entries and may need a third. */
+        for (int attempt = 0;; attempt++) {
+            prepare_batch(r, fr, true, true);
+            prepare_batch(r, fr, false, true);
+            HIP_OK(hipMemcpyAsync(db + r.off_params, hb + r.off_params, sizeof(PassParams) * r.members.size(), hipMemcpyHostToDevice, L.stream));
+            launch_batch(r, fr.plans, db);
+            for (size_t i : r.members)
+                HIP_OK(hipMemcpyAsync(hb + CONTROL_BYTES * fr.plans[i].slot, db + CONTROL_BYTES * fr.plans[i].slot, CONTROL_BYTES,
+                                      hipMemcpyDeviceToHost, L.stream));
+            HIP_OK(hipStreamSynchronize(L.stream));
+            bool failed = false;
+            for (size_t i : r.members) {
+                const uint32_t *c = fr.control(i);
+                failed = failed || c[2] != 0;
+                if (c[2] & RZ_ERR_BIN_OVERFLOW) g.list_highwater = std::max<size_t>(g.list_highwater, c[1]);
+            }
+            if (!failed) break;
+            if (attempt == 2)
+                for (size_t i : r.members)
+                    if (fr.control(i)[2] != 0)
+                        fatal("a pass run again with the scratch it asked for (%u clipper blocks, %u list entries) failed again: error bits %u",
+                              fr.control(i)[0], fr.control(i)[1], fr.control(i)[2]);
+        }
+        for (const FlushRecord::Copy &c : fr.copies) {
+            if (std::find(r.members.begin(), r.members.end(), c.producer) == r.members.end()) continue;
+            CopyJobs jobs;
+            memset(&jobs, 0, sizeof jobs);
+            jobs.job[0] = copy_job(c.tex, c.fb, c.depth, nullptr);
+            rz_buffers_to_textures_kernel<<<dim3((c.tex->pub.width + 15) / 16, (c.tex->pub.height + 15) / 16, 1), dim3(256), 0, L.stream>>>(jobs);
+            HIP_OK(hipGetLastError());
+        }
+        HIP_OK(hipStreamSynchronize(L.stream));
+    }
+    g.passes_run_again += passes_again;
+    if (g.verbose) fprintf(stderr, "mi355r: %zu passes of a flush ran again with larger scratch\n", passes_again);
+}
+
+/* Looks at the control blocks of the flushes in flight -- waiting for their lanes unless the caller
+ * knows them idle -- and runs again what did not run. */
+static void settle_in_flight(bool lanes_idle) {
+    while (!g_in_flight.empty()) {
+        FlushRecord fr = std::move(g_in_flight.back());
+        g_in_flight.pop_back();
+        if (!lanes_idle)
+            for (int l = 0; l < MAX_LANES; l++) if (fr.used[l]) HIP_OK(hipStreamSynchronize(g.lanes[l].stream));
+        bool failed = false;
+        for (size_t i = 0; i < fr.plans.size(); i++) {
+            const uint32_t *c = fr.control(i);
+            failed = failed || c[2] != 0;
+            g.host_counters[3] += c[1];
+        }
+        if (failed) {
+            if (!lanes_idle) {      /* other lanes may be busy with later work on the same framebuffers and textures */
+                for (int i = 0; i < g.num_lanes; i++) HIP_OK(hipStreamSynchronize(g.lanes[i].stream));
+                HIP_OK(hipStreamSynchronize(g.copy_stream));
+            }
+            run_again(fr);
+        }
+    }
+}
+
+static void check_passes_in_flight() { settle_in_flight(true); }
+
+/* A framebuffer is about to be handed out and its lane has drained: its own passes of the flush in
+ * flight either all ran (their control blocks came back on that lane) or the flush is settled now. */
+static void settle_framebuffer(Fb *fb) {
+    for (const FlushRecord &fr : g_in_flight)
+        for (size_t i = 0; i < fr.plans.size(); i++)
+            if (fr.plans[i].fb == fb && fr.control(i)[2] != 0) { settle_in_flight(false); return; }
+}
+
+/* the last pass into `fb` of the flush in flight, if any */
+static bool last_pass_in_flight(Fb *fb, FlushRecord **record, size_t *plan) {
+    for (size_t r = g_in_flight.size(); r-- > 0;)
+        for (size_t i = g_in_flight[r].plans.size(); i-- > 0;)
+            if (g_in_flight[r].plans[i].fb == fb) { *record = &g_in_flight[r]; *plan = i; return true; }
+    return false;
+}
+
+/* the framebuffer is about to be written outside a pass (a clear on its own): a pass of the flush in
+ * flight that has to run again must do so first */
+static void settle_before_touching(Fb *fb) {
+    FlushRecord *fr;
+    size_t plan;
+    if (last_pass_in_flight(fb, &fr, &plan)) settle_in_flight(false);
+}
+
+/* texture_from_{color,depth}buffer at once (nothing recorded for the framebuffer): on its lane, behind
+ * the passes already submitted.  When the last of those belongs to the flush in flight the copy joins
+ * that flush's record: it does nothing if the pass did not run, and is repeated after the pass has
+ * run again. */
+static void launch_texture_write(Tex *t, Fb *fb, bool depth) {
+    const int w = t->pub.width, h = t->pub.height;
+    hipStream_t st = begin_texture_write(t, fb);
+    FlushRecord *fr;
+    size_t plan;
+    const uint32_t *producer = nullptr;
+    if (last_pass_in_flight(fb, &fr, &plan)) {
+        producer = fr->control_dev(plan);
+        fr->copies.push_back({t, fb, depth, plan});
+    }
+    CopyJobs jobs;
+    memset(&jobs, 0, sizeof jobs);
+    jobs.job[0] = copy_job(t, fb, depth, producer);
+    rz_buffers_to_textures_kernel<<<dim3((w + 15) / 16, (h + 15) / 16, 1), dim3(256), 0, st>>>(jobs);
+    HIP_OK(hipGetLastError());
+    end_texture_write(t, fb);
+}
+
 /* MI355R_HOST_PROFILE=1: where the host's time in graphics_flush goes, printed when the process ends */
 struct FlushProfile {
     bool on = getenv("MI355R_HOST_PROFILE") != nullptr;
@@ -1428,45 +1687,59 @@ struct FlushProfile {
 };
 static FlushProfile g_flush_profile;
 
-/* One upload region per flush:
- *   [control block per pass][PassParams per pass][pass 0 tables][pass 1 tables]...
- * -> one host-to-device copy in front of the kernels and one small copy of the
- * control blocks back behind them, whatever the number of passes.
+/* One upload region per flush (FlushRecord) -> one host-to-device copy in front of the kernels and
+ * one small copy of its control blocks back behind every batch, whatever the number of passes.
  *
  * Passes are grouped into batches (one launch sequence each) level by level: a
  * pass comes one level after the last pass into its framebuffer and after the
  * pass a recorded framebuffer copy follows when it samples the copied texture;
  * a batch holds passes of one level and one kind of rasteriser.  A batch runs
  * on the lane of its first framebuffer, or the next lane in turn; framebuffers
- * and GPU-written textures that come from other lanes are ordered by events. */
+ * and GPU-written textures that come from other lanes are ordered by events.
+ *
+ * The flush before this one is settled first (its control blocks looked at, passes that ran out of
+ * scratch run again): what this flush renders on top of is then what it should be.  The host has
+ * recorded this flush while the GPU ran that one, so the wait is short. */
 extern "C" void graphics_flush(void) {
     if (!g.ready || g.pending.empty()) return;
     FlushProfile &prof = g_flush_profile;
     prof.start();
-    std::vector<PassPlan> plans;
+    if (g.events.size() > 4096) sync_stream();          /* bound the number of live events; no event of this flush exists yet */
+    FlushRecord fr;
+    std::vector<PassPlan> &plans = fr.plans;
     size_t n = g.pending.size(), first = 0;
     while (first < n) {
         size_t last = first + 1;
         /* A pass ends where the framebuffer changes -- and in front of its first blended draw:
          * the draws before it need no colour below them and go through the split rasteriser and
-         * the per-family shade kernels, only the rest needs ordered in-kernel shading. */
+         * the per-family shade kernels, only the rest needs ordered in-kernel shading.  It also ends
+         * at the limits of what a triangle's record can say about it (16 bits of draw index). */
         const bool starts_blended = (g.pending[first].rec.flags & RZ_DRAW_BLEND) != 0;
         auto copy_point = [&](size_t at) {      /* a recorded copy of this framebuffer sits in front of draw `at` */
             for (auto &w : g.tex_writes) if (w.after == at && w.fb == g.pending[first].fb) return true;
             return false;
         };
+        size_t tris = (size_t)g.pending[first].rec.num_faces;
         while (last < n && g.pending[last].fb == g.pending[first].fb && !copy_point(last) &&
-               (starts_blended || !(g.pending[last].rec.flags & RZ_DRAW_BLEND))) last++;
+               (starts_blended || !(g.pending[last].rec.flags & RZ_DRAW_BLEND)) &&
+               last - first < 65535 && tris + (size_t)g.pending[last].rec.num_faces <= 0x0fffffffu) {
+            tris += (size_t)g.pending[last].rec.num_faces;
+            last++;
+        }
+        if (tris > 0x0fffffffu) fatal("%zu triangles in one draw (limit 268435455)", tris);
         PassPlan pl;
         pl.first = first;
         pl.last = last;
         plans.push_back(std::move(pl));
         first = last;
     }
-    const size_t controls_at = 0;
     size_t total = CONTROL_BYTES * plans.size();
     total = (total + 255) & ~(size_t)255;
-    const size_t params_at = total;
+    fr.flag_at = total;
+    total += 256;
+    fr.params_at = total;
+    total += sizeof(PassParams) * plans.size();
+    fr.again_at = total;
     total += sizeof(PassParams) * plans.size();
     for (auto &pl : plans) plan_pass(pl, total);
     prof.mark(0);
@@ -1477,8 +1750,8 @@ extern "C" void graphics_flush(void) {
      * framebuffer (textures written on the GPU were written before this flush started), so passes
      * are taken level by level: level = number of earlier passes into the same framebuffer.  A
      * batch holds passes of one level and one kind of rasteriser, in submission order. */
-    std::vector<Batch> batches;
-    std::unordered_map<size_t, std::vector<Context::TexWrite*>> copies_after;   /* pass -> the recorded copies it feeds */
+    std::vector<Batch> &batches = fr.batches;
+    std::unordered_map<size_t, std::vector<size_t>> copies_after;   /* pass -> the recorded copies (fr.copies) it feeds */
     {
         /* a recorded copy runs behind the last pass into its framebuffer that ends at or before it;
          * a pass that samples the copied texture comes one level after that pass */
@@ -1489,10 +1762,10 @@ extern "C" void graphics_flush(void) {
                 if (plans[i].fb == w.fb && plans[i].last <= w.after) found = i;
             if (found == plans.size()) fatal("a recorded framebuffer copy has no pass to follow");
             producer[w.tex] = found;
-            copies_after[found].push_back(&w);
+            copies_after[found].push_back(fr.copies.size());
+            fr.copies.push_back({w.tex, w.fb, w.depth, found});
         }
         std::unordered_map<Fb*, int> last_level;
-        std::vector<int> level(plans.size());
         int levels = 0;
         for (size_t i = 0; i < plans.size(); i++) {
             auto seen = last_level.find(plans[i].fb);
@@ -1501,9 +1774,9 @@ extern "C" void graphics_flush(void) {
                 for (Tex *t : g.pending[d].pending_textures) {
                     auto from = producer.find(t);
                     if (from == producer.end() || from->second >= i) fatal("a draw samples a texture whose copy is not recorded before it");
-                    l = std::max(l, level[from->second] + 1);
+                    l = std::max(l, plans[from->second].level + 1);
                 }
-            level[i] = l;
+            plans[i].level = l;
             last_level[plans[i].fb] = l;
             levels = std::max(levels, l + 1);
         }
@@ -1513,8 +1786,8 @@ extern "C" void graphics_flush(void) {
                 Batch b;
                 auto close = [&]() {
                     if (b.members.empty()) return;
-                    b.off_params = params_at + sizeof(PassParams) * params_used;
-                    params_used += b.members.size();
+                    b.off_params = fr.params_at + sizeof(PassParams) * params_used;
+                    for (size_t i : b.members) plans[i].slot = params_used++;
                     int lane = plans[b.members[0]].fb->lane;
                     if (lane < 0 || lane >= lanes) { lane = g.next_lane % lanes; g.next_lane = (g.next_lane + 1) % lanes; }
                     b.lane = lane;
@@ -1522,7 +1795,7 @@ extern "C" void graphics_flush(void) {
                     b = Batch();
                 };
                 for (size_t i = 0; i < plans.size(); i++) {
-                    if (level[i] != l || (int)plans[i].has_blend != blend) continue;
+                    if (plans[i].level != l || (int)plans[i].has_blend != blend) continue;
                     if (b.members.empty()) { b.has_blend = blend != 0; b.families = 0; }
                     b.members.push_back(i);
                     b.families |= plans[i].families;
@@ -1532,21 +1805,23 @@ extern "C" void graphics_flush(void) {
             }
         }
     }
-
     prof.mark(1);
-    size_t at = ring_alloc(total);
-    char *hb = g.ring_host + at, *db = g.ring_dev + at;
+
+    settle_in_flight(false);        /* the flush before this one */
+    fr.at = ring_alloc(total);
+    char *hb = g.ring_host + fr.at, *db = g.ring_dev + fr.at;
+    memset(hb + fr.flag_at, 0, 256);
     for (auto &pl : plans) fill_pass(pl, hb, db);
     prof.mark(2);
     /* scratch first, for every batch: growing a buffer moves it, and the tables written next hold its address */
-    for (auto &b : batches) prepare_batch(b, plans, hb, db, controls_at, true);
-    for (auto &b : batches) prepare_batch(b, plans, hb, db, controls_at, false);
+    for (auto &b : batches) prepare_batch(b, fr, true, false);
+    for (auto &b : batches) prepare_batch(b, fr, false, false);
     prof.mark(3);
-    HIP_OK(hipMemcpyAsync(db + params_at, hb + params_at, total - params_at, hipMemcpyHostToDevice, g.copy_stream));
+    HIP_OK(hipMemcpyAsync(db + fr.flag_at, hb + fr.flag_at, total - fr.flag_at, hipMemcpyHostToDevice, g.copy_stream));
     hipEvent_t uploaded = new_event(g.copy_stream);
     prof.mark(4);
 
-    bool used[MAX_LANES] = {false};
+    bool *used = fr.used;
     for (auto &b : batches) {
         Lane &L = g.lanes[b.lane];
         if (!used[b.lane]) { HIP_OK(hipStreamWaitEvent(L.stream, uploaded, 0)); used[b.lane] = true; }
@@ -1583,7 +1858,7 @@ extern "C" void graphics_flush(void) {
         prof.mark(5);
         {
             /* the recorded copies this batch feeds, on its lane, RZ_COPY_GROUP per launch */
-            std::vector<Context::TexWrite*> feeds;
+            std::vector<size_t> feeds;
             for (size_t i : b.members) {
                 auto copies = copies_after.find(i);
                 if (copies != copies_after.end()) feeds.insert(feeds.end(), copies->second.begin(), copies->second.end());
@@ -1595,16 +1870,13 @@ extern "C" void graphics_flush(void) {
                 std::vector<hipEvent_t> readers;
                 int max_w = 0, max_h = 0;
                 for (size_t k = 0; k < count; k++) {
-                    Context::TexWrite *w = feeds[at + k];
-                    Tex *t = w->tex;
-                    if (w->fb->lane != b.lane) fatal("a recorded copy is not on its framebuffer's lane");
+                    const FlushRecord::Copy &w = fr.copies[feeds[at + k]];
+                    Tex *t = w.tex;
+                    if (w.fb->lane != b.lane) fatal("a recorded copy is not on its framebuffer's lane");
                     for (hipEvent_t e : t->read_events) if (std::find(readers.begin(), readers.end(), e) == readers.end()) readers.push_back(e);
                     t->read_events.clear();
                     if (t->write_event && t->write_lane != b.lane) readers.push_back(t->write_event);
-                    jobs.job[k].from = w->depth ? (const void*)w->fb->d_depth : (const void*)w->fb->d_color;
-                    jobs.job[k].to = t->d_data;
-                    jobs.job[k].w = t->pub.width; jobs.job[k].h = t->pub.height;
-                    jobs.job[k].flags = t->flags; jobs.job[k].is_depth = w->depth ? 1 : 0;
+                    jobs.job[k] = copy_job(t, w.fb, w.depth, fr.control_dev(w.producer));
                     max_w = std::max(max_w, t->pub.width); max_h = std::max(max_h, t->pub.height);
                 }
                 for (hipEvent_t e : readers) HIP_OK(hipStreamWaitEvent(L.stream, e, 0));   /* passes that still sample the old contents */
@@ -1612,25 +1884,25 @@ extern "C" void graphics_flush(void) {
                 HIP_OK(hipGetLastError());
                 hipEvent_t written = new_event(L.stream);
                 for (size_t k = 0; k < count; k++) {
-                    end_texture_write(feeds[at + k]->tex, feeds[at + k]->fb, written);
-                    feeds[at + k]->tex->pending_write = false;
+                    const FlushRecord::Copy &w = fr.copies[feeds[at + k]];
+                    end_texture_write(w.tex, w.fb, written);
+                    w.tex->pending_write = false;
                 }
             }
         }
+        /* the batch's control blocks come back behind it, on its lane */
+        HIP_OK(hipMemcpyAsync(hb + CONTROL_BYTES * plans[b.members[0]].slot, db + CONTROL_BYTES * plans[b.members[0]].slot,
+                              CONTROL_BYTES * b.members.size(), hipMemcpyDeviceToHost, L.stream));
         prof.mark(6);
     }
-    /* control blocks come back once every lane of this flush has finished */
-    for (int l = 0; l < MAX_LANES; l++)
-        if (used[l]) HIP_OK(hipStreamWaitEvent(g.copy_stream, new_event(g.lanes[l].stream), 0));
-    HIP_OK(hipMemcpyAsync(hb, db, CONTROL_BYTES * plans.size(), hipMemcpyDeviceToHost, g.copy_stream));
-    for (size_t i = 0; i < plans.size(); i++) g.control_slots.push_back(at + CONTROL_BYTES * i);
+    prof.flushes++;
+    prof.passes += plans.size();
     g.pending.clear();
     g.side.clear();
     g.tex_writes.clear();
     g.flush_epoch++;
+    g_in_flight.push_back(std::move(fr));
     prof.mark(7);
-    prof.flushes++;
-    prof.passes += plans.size();
 }
 
 /* --------------------------------------------------------------- inspection -- */
@@ -1778,6 +2050,23 @@ extern "C" unsigned long long mi355r_get_timing(double out[8], int reset) {
     unsigned long long n = g.kernel_launches;
     if (reset) { for (int k = 0; k < 7; k++) g.kernel_ms[k] = 0; g.kernel_launches = 0; g.timed_sequences = 0; }
     return n;
+}
+
+/* tests: force the first-time sizes of the clipper's block table and the bin lists (0 = the
+ * library's own estimate), and count the passes that had to run again */
+extern "C" void mi355r_set_scratch_estimate(unsigned long long fan_blocks, unsigned long long list_entries) {
+    ensure_ready();
+    graphics_flush();
+    g.forced_fan_estimate = (size_t)fan_blocks;
+    g.forced_list_estimate = (size_t)list_entries;
+    if (!fan_blocks && !list_entries) g.fan_highwater = g.list_highwater = 0;
+}
+
+extern "C" unsigned long long mi355r_passes_run_again(void) {
+    ensure_ready();
+    graphics_flush();
+    sync_stream();
+    return g.passes_run_again;
 }
 
 extern "C" void mi355r_shutdown(void) {

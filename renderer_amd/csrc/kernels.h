@@ -63,7 +63,9 @@ RZ_DEV void mat_mul(const float *a, const float *b, float *c) {
 __global__ void __launch_bounds__(256) rz_vertex_kernel(const PassParams *__restrict__ passes) {
     const PassParams &P = passes[blockIdx.y];
     uint32_t gv = blockIdx.x * 256u + threadIdx.x;
-    if (gv < 8u) P.control[gv] = 0;             /* the pass's device-written scalars start at zero */
+    /* the pass's device-written scalars start at zero -- unless another pass of the flush ran out of
+     * scratch and this one may depend on it: then it is marked to be left out and run again later */
+    if (gv < 8u) P.control[gv] = (gv == 2u && P.level > 0 && *P.flush_flag != 0u) ? (uint32_t)RZ_ERR_SKIPPED : 0u;
     if (blockIdx.y == 0 && gv < 3u * RZ_QUEUE_WAYS) P.queue_counts[gv * RZ_QUEUE_PAD] = 0;    /* ... and the batch's work-list lengths */
     /* the grid is sized for the largest pass of the batch: all of its threads share the clearing */
     for (uint32_t t = gv; t < (uint32_t)(P.tiles_x * P.tiles_y); t += gridDim.x * 256u) P.tile_listed[t] = 0;
@@ -330,8 +332,8 @@ __global__ void __launch_bounds__(64) rz_clip_kernel(const PassParams *__restric
         if (lane == 0) block = atomicAdd(&P.control[0], 1u);
         block = (uint32_t)__builtin_amdgcn_readfirstlane((int)block);
         if (block >= (uint32_t)P.fan_capacity) {
-            if (lane == 0) atomicOr(&P.control[2], (uint32_t)RZ_ERR_FAN_OVERFLOW);
-            continue;
+            if (lane == 0) { atomicOr(&P.control[2], (uint32_t)RZ_ERR_FAN_OVERFLOW); atomicOr(P.flush_flag, 1u); }
+            continue;                           /* control[0] goes on counting the blocks the pass needs */
         }
         if (lane >= 4 && lane < 4 + nv) {
             for (int i = 0; i < n; i++)
@@ -481,8 +483,9 @@ __global__ void __launch_bounds__(64 * RZ_SCAN_SEGMENTS) rz_bin_scan_kernel(cons
     __syncthreads();
     if (segment == 0 && bin < bins) {
         uint32_t start = total ? atomicAdd(&P.control[1], total) : 0u;
-        if (start + total > P.bin_capacity) {
+        if (start + total > P.bin_capacity) {      /* control[1] still ends up as the entries the pass needs */
             atomicOr(&P.control[2], (uint32_t)RZ_ERR_BIN_OVERFLOW);
+            atomicOr(P.flush_flag, 1u);
             total = 0;
         }
         P.bin_range[bin] = make_uint2(start, total);
@@ -546,6 +549,7 @@ __global__ void __launch_bounds__(64 * RZ_FILL_WAVES) rz_bin_fill_kernel(const P
     const PassParams &P = passes[blockIdx.y];
     const uint32_t chunk = blockIdx.x;
     if (chunk * 64u >= (uint32_t)P.num_tris) return;            /* uniform over the workgroup */
+    if (P.control[2] != 0u) return;                             /* out of scratch, or left out: the pass is run again later */
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t t = chunk * 64u + lane;
     const int bins = P.bins_x * P.bins_y;
@@ -887,6 +891,7 @@ RZ_DEV void raster_tile(const PassParams &P, const uint32_t pass_index, const ui
         const float *__restrict__ vary_base, const float *__restrict__ fan_vary_base,
         const char *__restrict__ upload_base, const uint2 *__restrict__ bin_range_base) {
     if ((int)tile_x >= P.tiles_x || (int)tile_y >= P.tiles_y) return;
+    if (P.control[2] != 0u) return;                             /* out of scratch, or left out: the pass is run again later */
     /* this pass's slices of the batch-wide tables */
     const TriRec *tri_table = tri_base + P.tri_off;
     const TriRec *fan_table = fan_base + (size_t)P.fan_off * RZ_MAX_FAN;
@@ -1121,6 +1126,7 @@ __global__ void __launch_bounds__(256 / PPL) rz_visibility_kernel(const PassPara
     const PassParams P = passes[blockIdx.z];
     if ((int)blockIdx.x >= P.tiles_x || (int)blockIdx.y >= P.tiles_y) return;
     if (P.debug_skip == 3) return;
+    if (P.control[2] != 0u) return;                             /* out of scratch, or left out: the pass is run again later */
     const BinEntry *list_table = list_base + P.list_off;
     const float *vary_table = vary_base + (size_t)P.tri_off * 3 * RZ_VARY_STRIDE;
     const float *fan_vary_table = fan_vary_base + (size_t)P.fan_off * RZ_MAX_POLY * RZ_VARY_STRIDE;
@@ -1471,6 +1477,7 @@ __global__ void __launch_bounds__(256) rz_shade_kernel(const PassParams *__restr
         const char *__restrict__ upload_base, const uint32_t *__restrict__ ref_base) {
     const PassParams P = passes[blockIdx.z];          /* by value: one burst of scalar loads up front, not one wait per field */
     if ((int)blockIdx.x >= P.tiles_x || (int)blockIdx.y >= P.tiles_y) return;
+    if (P.control[2] != 0u) return;                   /* the pass did not run: its reference plane holds nothing */
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     shade_pixel<FAMILY>(P, tri_base, fan_base, vary_base, fan_vary_base, upload_base, ref_base,
                         (int)blockIdx.x * RZ_TILE_W + (lane & 31), (int)blockIdx.y * RZ_TILE_H + wave * 2 + (lane >> 5));
@@ -1488,6 +1495,7 @@ __global__ void __launch_bounds__(256 / PPL) rz_sky_kernel(const PassParams *__r
         const char *__restrict__ upload_base, const uint32_t *__restrict__ ref_base) {
     const PassParams P = passes[blockIdx.z];
     if ((int)blockIdx.x >= P.tiles_x || (int)blockIdx.y >= P.tiles_y) return;
+    if (P.control[2] != 0u) return;                   /* the pass did not run: its reference plane holds nothing */
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const TriRec *tri_table = tri_base + P.tri_off;
     const TriRec *fan_table = fan_base + (size_t)P.fan_off * RZ_MAX_FAN;
@@ -1595,22 +1603,20 @@ __global__ void rz_clear_kernel(uint32_t *color, float *depth, size_t n, int do_
     if (do_depth) depth[i] = d;
 }
 
-/* texture_from_depthbuffer (texture.c:147-158): the texel is (d, d, d, 1);
- * stored as one float, expanded on fetch */
-__global__ void rz_depth_to_texture_kernel(const float *depth, float *texels, int w, int h, int flags, int mbits) {
-    int x = blockIdx.x * 16 + (threadIdx.x & 15), y = blockIdx.y * 16 + (threadIdx.x >> 4);
-    if (x >= w || y >= h) return;
-    texels[texel_index(w, flags, x, y)] = depth[(size_t)y * w + x];
-}
+/* texture_from_depthbuffer (texture.c:147-158): the texel is (d, d, d, 1), stored as one float and
+ * expanded on fetch; texture_from_colorbuffer (texture.c:130-145): byte / 255.0f per channel. */
 
-/* several of those copies in one launch (grid z = copy): the recorded copies behind one batch of passes */
+/* one launch for several such copies (grid z = copy): e.g. the recorded copies behind one batch of passes */
 #define RZ_COPY_GROUP 32
-struct CopyJob { const void *from; void *to; int32_t w, h, flags, is_depth; };
+struct CopyJob { const void *from; void *to; int32_t w, h, flags, is_depth; const uint32_t *producer; };
 struct CopyJobs { CopyJob job[RZ_COPY_GROUP]; };
 __global__ void rz_buffers_to_textures_kernel(const CopyJobs jobs) {
     const CopyJob &j = jobs.job[blockIdx.z];
     int x = blockIdx.x * 16 + (threadIdx.x & 15), y = blockIdx.y * 16 + (threadIdx.x >> 4);
     if (x >= j.w || y >= j.h) return;
+    /* the control block of the pass that rendered the source: when that pass did not run (it is run
+     * again later, and this copy after it) the texture keeps what it holds */
+    if (j.producer && j.producer[2] != 0u) return;
     if (j.is_depth) {
         ((float*)j.to)[texel_index(j.w, j.flags, x, y)] = ((const float*)j.from)[(size_t)y * j.w + x];
     } else {
@@ -1619,16 +1625,6 @@ __global__ void rz_buffers_to_textures_kernel(const CopyJobs jobs) {
             make_float4((float)(c & 0xffu) / 255.0f, (float)((c >> 8) & 0xffu) / 255.0f,
                         (float)((c >> 16) & 0xffu) / 255.0f, (float)(c >> 24) / 255.0f);
     }
-}
-
-/* texture_from_colorbuffer (texture.c:130-145): byte / 255.0f per channel */
-__global__ void rz_color_to_texture_kernel(const uint32_t *color, float4 *texels, int w, int h, int flags, int mbits) {
-    int x = blockIdx.x * 16 + (threadIdx.x & 15), y = blockIdx.y * 16 + (threadIdx.x >> 4);
-    if (x >= w || y >= h) return;
-    uint32_t c = color[(size_t)y * w + x];
-    texels[texel_index(w, flags, x, y)] =
-        make_float4((float)(c & 0xffu) / 255.0f, (float)((c >> 8) & 0xffu) / 255.0f,
-                    (float)((c >> 16) & 0xffu) / 255.0f, (float)(c >> 24) / 255.0f);
 }
 
 /* row-major float4 image -> device layout (8x8 tiles where the size allows) */

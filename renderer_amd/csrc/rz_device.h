@@ -194,8 +194,17 @@ struct PassParams {
     uint32_t bin_off;               /* bins before this pass */
     uint64_t ref_off;               /* pixels before this pass in the reference plane */
     uint64_t draws_off;             /* byte offset of draws[] in the flush's upload region */
+    /* Scratch that turns out too small.  The clipper's blocks and the bin lists are sized by an
+     * estimate; a pass that needs more sets its error bits and one word shared by the whole flush,
+     * touches nothing of its framebuffer (every kernel behind the binning looks at control[2]
+     * first), and goes on counting what it needs.  A pass that may depend on another pass of the
+     * flush (level > 0) and finds the flush's word set does not run either (RZ_ERR_SKIPPED).  The
+     * host runs those passes again, in order, with scratch of the sizes they reported. */
+    uint32_t *flush_flag;
+    int32_t level;                  /* 0: depends on no other pass of its flush */
+    int32_t pad_;
 };
 
-enum { RZ_ERR_FAN_OVERFLOW = 1, RZ_ERR_BIN_OVERFLOW = 2, RZ_ERR_QUEUE_OVERFLOW = 4 };
+enum { RZ_ERR_FAN_OVERFLOW = 1, RZ_ERR_BIN_OVERFLOW = 2, RZ_ERR_QUEUE_OVERFLOW = 4, RZ_ERR_SKIPPED = 8 };
 
 #endif

@@ -14,6 +14,10 @@ ORACLE_LIB = os.path.join(REPO, "oracle", "liboracle.so")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the library's last words before an abort: pytest's capture of stderr dies with the process
+    out = os.path.join(REPO, "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    os.environ.setdefault("MI355R_FATAL_LOG", os.path.join(out, "mi355r_fatal.log"))
 
 
 def golden_cases():

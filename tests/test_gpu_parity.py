@@ -79,6 +79,32 @@ def test_gpu_per_triangle_submission_matches_reference_golden(gpu, case):
     assert_same(got, load_golden(case["name"]), got[1].size)
 
 
+@pytest.mark.parametrize("name,like", [("kgirl_blend.scn", "kgirl"), ("helmet", None)])
+def test_gpu_per_triangle_submission_records_one_draw_per_model(gpu, name, like):
+    """graphics_draw_triangle merges consecutive triangles of one model into one draw: the uniform
+    block is compared per call and, for a skinned program, the joint matrices it points at -- so the
+    reference's per-face loop over a skinned mesh (blinn_shader.c:323-341) costs as many draws, and as
+    many copies of the pose, as graphics_draw_mesh."""
+    import os
+    from renderer_amd.binding import SCENES
+    scene = gpu.open_scene(os.path.join(SCENES, name) if name.endswith(".scn") else name, like)
+    view = gpu.make_view((0.5, 0.2, -1.3), None, 1.9)
+    draws = []
+    for per_triangle in (0, 1):
+        gpu.lib.rzs_set_per_triangle(per_triangle)
+        try:
+            gpu.render(scene, 256, 144, view)           # uploads
+            gpu.lib.mi355r_reset_counters()
+            gpu.render(scene, 256, 144, view)
+            c = gpu.counters()
+        finally:
+            gpu.lib.rzs_set_per_triangle(0)
+        draws.append((c[5], c[0]))
+    gpu.close_scene(scene)
+    assert draws[0] == draws[1], draws                  # (draws, triangles) of the frame
+    assert draws[0][0] < 64 and draws[0][1] > 3000
+
+
 @pytest.mark.parametrize("size", [(1, 1), (31, 9), (65, 64), (333, 77), (64, 1)])
 def test_gpu_ragged_framebuffer_sizes(gpu, oracle, size):
     """Sizes that are not multiples of the 32x8 tile or the 64x64 bin."""

@@ -1,0 +1,61 @@
+"""The reference's OWN host code on top of the C ABI (CPU container only: needs /root/reference).
+
+oracle/Makefile (target refhost) compiles every source file of the reference except the two the
+library replaces (core/graphics.c, core/texture.c) -- scenes/*.c with the .scn parser, the shaders'
+update_model / draw_model loops (per-face program_get_attribs + graphics_draw_triangle), the caches,
+loaders and tests/test_helper.c's frame driver, unchanged, where they lie -- and links them
+  (1) against renderer_amd/libmi355r.so with --no-undefined: every symbol the reference's host
+      needs from graphics.c / texture.c is exported by the library (it cannot run here: no GPU;
+      tests/test_00_reference_host_gpu.py runs it on the GPU box);
+  (2) against oracle/liboracle.so, and runs that through ref_driver.c: the frames must equal the
+      goldens (rendered by the unmodified reference) bit for bit, which pins the C ABI's semantics
+      -- recorded draws, texture_from_file / cubemap_from_files, the samplers the reference's CPU
+      shaders call back into, texture_from_depthbuffer -- under the reference's own callers."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import REPO, golden_cases, load_golden
+
+REFERENCE = "/root/reference/renderer"
+REF_OUT = os.path.join(REPO, "oracle", "_ref")
+
+pytestmark = pytest.mark.skipif(not os.path.isdir(REFERENCE), reason="the reference sources are not present")
+
+
+@pytest.fixture(scope="module")
+def refhost():
+    subprocess.run(["make", "-C", os.path.join(REPO, "renderer_amd")], check=True, capture_output=True)
+    subprocess.run(["make", "-C", os.path.join(REPO, "oracle"), "oracle", "refhost"], check=True, capture_output=True)
+    return {k: os.path.join(REF_OUT, "refhost_" + k) for k in ("oracle", "mi355r")}
+
+
+def test_reference_host_links_against_the_gpu_library(refhost):
+    """Link line of INTEGRATION.md with -Wl,--no-undefined: nothing the reference's host calls is missing."""
+    exe = refhost["mi355r"]
+    assert os.path.exists(exe)
+    dynamic = subprocess.run(["readelf", "-d", exe], check=True, capture_output=True, text=True).stdout
+    assert "libmi355r.so" in dynamic
+    # the entry points it binds are the reference's own names
+    undefined = subprocess.run(["nm", "-D", "--undefined-only", exe], check=True, capture_output=True, text=True).stdout
+    for name in ("graphics_draw_triangle", "program_create", "program_get_attribs", "program_get_uniforms",
+                 "framebuffer_create", "framebuffer_clear_color", "framebuffer_clear_depth", "texture_from_file",
+                 "cubemap_from_files", "texture_from_depthbuffer", "texture_create", "framebuffer_sync"):
+        assert f" U {name}" in undefined, name
+    # and none of them is the batched addition: the reference's loops are per triangle
+    assert "graphics_draw_mesh" not in undefined
+
+
+@pytest.mark.parametrize("name", ["helmet_default", "kgirl_anim", "azura_shadow", "helmet_inside", "kgirl_blend",
+                                  "craftsman_default", "buster_anim"])
+def test_reference_host_on_the_c_abi_reproduces_goldens(refhost, name):
+    sys.path.insert(0, os.path.join(REPO, "oracle"))
+    from make_goldens import run_case
+    case = next(c for c in golden_cases() if c["name"] == name)
+    color, depth = run_case(case, os.path.join(REPO, "assets"), binary=refhost["oracle"])
+    want_color, want_depth = load_golden(name)
+    assert np.array_equal(depth, want_depth)
+    assert np.array_equal(color, want_color)

@@ -1,8 +1,9 @@
 # parity tests, then the default bench; stops at the first failure
 set -e
 mkdir -p gpurun_out
-timeout -k 10 600 python -u -m pytest tests -m gpu -x -q --timeout 180 --timeout-method thread > gpurun_out/pytest_gpu.log 2>&1 || { tail -30 gpurun_out/pytest_gpu.log; exit 1; }
-tail -2 gpurun_out/pytest_gpu.log
+rm -f gpurun_out/mi355r_fatal.log
+timeout -k 10 900 python -u -m pytest tests -m gpu -x -q --timeout 300 --timeout-method thread --durations=8 > gpurun_out/pytest_gpu.log 2>&1 || { tail -40 gpurun_out/pytest_gpu.log; cat gpurun_out/mi355r_fatal.log 2>/dev/null; exit 1; }
+tail -14 gpurun_out/pytest_gpu.log
 timeout -k 10 300 python bench.py --no-cpu > gpurun_out/bench_check.json
 python - <<'PY'
 import json
