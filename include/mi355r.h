@@ -234,6 +234,18 @@ void framebuffer_sync(rz_framebuffer *framebuffer);
 void framebuffer_sync_color(rz_framebuffer *framebuffer);
 /* Same for a texture written by texture_from_{color,depth}buffer. */
 void texture_sync(rz_texture *texture);
+/* texture_sync for callers that cannot allocate device memory.  No counterpart in the reference (whose
+ * textures live in host memory only); it is for callers that must not call hipMalloc: code under HIP
+ * graph capture, tight per-frame loops (a viewer that shows the shadow map every frame), harnesses that
+ * forbid allocation.  Same result as texture_sync -- texture->buffer valid on the host -- but the
+ * row-major staging image lives in a fixed 16 MiB array inside the library's device image instead of
+ * a buffer allocated and freed per call; the call allocates and frees nothing and creates no event.
+ * Limits: at most 1024 x 1024 = 1 048 576 texels; the copy into the texture must have been submitted
+ * (graphics_flush) -- a recorded copy is not submitted here, because submitting sizes scratch.  One
+ * staging array per GPU, shared by all calls on it: calls that overlap on one GPU race.
+ * Returns RZ_NOALLOC_OK, or a negative code after a message on stderr (nothing is written then). */
+enum { RZ_NOALLOC_OK = 0, RZ_NOALLOC_TOO_LARGE = -1, RZ_NOALLOC_NOT_SUBMITTED = -2 };
+int texture_sync_noalloc(rz_texture *texture);
 /* Tells the library that texture->buffer was modified by the host. */
 void texture_invalidate(rz_texture *texture);
 /* Copies the finished device images into caller memory (host pointers) or

@@ -78,6 +78,7 @@ struct Tex {
     int flags, mbits;               /* RZ_TEX_* of the device image */
     bool device_stale;              /* host buffer is newer */
     bool host_stale;                /* device image is newer */
+    bool host_pinned = false;       /* pub.buffer is page-locked (textures the GPU writes: their read-back is a plain DMA) */
     /* a texture written on the GPU (texture_from_*buffer) orders the passes
      * around it: readers wait for the write, the next write for the readers */
     int write_lane;
@@ -225,6 +226,7 @@ template <typename T> static void reserve(DevBuf<T> &b, size_t n, hipStream_t us
 
 static void check_passes_in_flight();
 static void init_packed_formats();
+static float4 *scratch_on_device(int device);
 
 static void sync_stream();
 
@@ -304,6 +306,7 @@ extern "C" int mi355r_init(int device) {
         HIP_OK(hipMemcpyToSymbol(HIP_SYMBOL(rz_srgb_tables), &tables, sizeof tables));
     }
     init_packed_formats();
+    (void)scratch_on_device(g.device);      /* texture_sync_noalloc's staging array: its address on this device, while it is current */
     HIP_OK(hipMalloc((void**)&g.d_counters, 12 * sizeof(unsigned long long)));
     HIP_OK(hipMemset(g.d_counters, 0, 12 * sizeof(unsigned long long)));
     HIP_OK(hipDeviceSynchronize());
@@ -477,6 +480,7 @@ extern "C" void texture_release(rz_texture *p) {                    /* texture.c
     sync_stream();
     drop_derived_handles();
     if (t->d_data) HIP_OK(hipFree(t->d_data));
+    if (t->host_pinned) (void)hipHostUnregister(t->pub.buffer);
     free(t->pub.buffer);
     g.texs.erase(t);
     delete t;
@@ -683,6 +687,13 @@ static void launch_texture_write(Tex *t, Fb *fb, bool depth);
  * that case flushes first. */
 static void texture_from_buffer(Tex *t, Fb *fb, bool depth, const char *who) {
     if (t->pub.width != fb->pub.width || t->pub.height != fb->pub.height) fatal("%s: size mismatch", who);
+    if (!t->host_pinned) {
+        /* its host image will be filled from the device (texture_sync): page-locked, that copy needs no staging */
+        if (hipHostRegister(t->pub.buffer, (size_t)t->pub.width * t->pub.height * sizeof(rz_vec4), hipHostRegisterDefault) == hipSuccess)
+            t->host_pinned = true;
+        else
+            (void)hipGetLastError();
+    }
     const bool in_use = t->pending_write || (!g.pending.empty() && t->used_epoch == g.flush_epoch);
     if (!has_pending_for(fb) || in_use || !g.record_copies) {
         graphics_flush();
@@ -1624,6 +1635,73 @@ static void settle_framebuffer(Fb *fb) {
     for (const FlushRecord &fr : g_in_flight)
         for (size_t i = 0; i < fr.plans.size(); i++)
             if (fr.plans[i].fb == fb && fr.control(i)[2] != 0) { settle_in_flight(false); return; }
+}
+
+/* ---- texture_sync without allocations ---------------------------------------
+ * texture_sync above stages the row-major float4 image in a buffer it allocates and frees per call.
+ * Callers that cannot allocate device memory (code under HIP graph capture, a viewer's loop that shows
+ * the shadow map every frame, harnesses that forbid hipMalloc) get the same result through a staging
+ * area that is part of the library's image on the device: a file-scope __device__ array of
+ * RZ_SYNC_SCRATCH_TEXELS float4 texels.  Every GPU the library runs on holds its own copy of that
+ * array, at its own address, until the process ends; the address is looked up once per device
+ * (scratch_on_device) and only that pointer is ever handed to kernels and copies.  Every call on a
+ * GPU uses the same array: calls that overlap on one GPU would race (the library is single-threaded,
+ * like the reference).  Nothing in it has to start at zero: the kernel writes every texel the copy
+ * then reads. */
+#define RZ_SYNC_SCRATCH_TEXELS (1024u * 1024u)      /* 16 MiB: a 1024x1024 image, twice the default shadow map's side */
+static __device__ __align__(256) float4 rz_sync_scratch[RZ_SYNC_SCRATCH_TEXELS];
+
+static const int RZ_MAX_DEVICES = 64;
+static float4 *g_sync_scratch_ptr[RZ_MAX_DEVICES] = {nullptr};
+
+/* the array's address on `device`, which must be the current device; looked up on first use (mi355r_init) */
+static float4 *scratch_on_device(int device) {
+    if (device < 0 || device >= RZ_MAX_DEVICES) fatal("device %d: the library keeps per-device state for devices 0..%d", device, RZ_MAX_DEVICES - 1);
+    if (!g_sync_scratch_ptr[device]) {
+        int current = -1;
+        HIP_OK(hipGetDevice(&current));
+        if (current != device) fatal("the staging array of device %d is looked up while device %d is current", device, current);
+        void *ptr = nullptr;
+        HIP_OK(hipGetSymbolAddress(&ptr, HIP_SYMBOL(rz_sync_scratch)));
+        if (!ptr) fatal("hipGetSymbolAddress gave no address for the staging array on device %d", device);
+        g_sync_scratch_ptr[device] = (float4*)ptr;
+    }
+    return g_sync_scratch_ptr[device];
+}
+
+extern "C" int texture_sync_noalloc(rz_texture *p) {
+    Tex *t = as_tex(p);
+    if (!t->host_stale) return RZ_NOALLOC_OK;       /* the host image is current */
+    const size_t texels = (size_t)t->pub.width * t->pub.height;
+    if (texels > RZ_SYNC_SCRATCH_TEXELS) {
+        fprintf(stderr, "mi355r: texture_sync_noalloc: %dx%d = %zu texels, the staging area holds %u (use texture_sync)\n",
+                t->pub.width, t->pub.height, texels, RZ_SYNC_SCRATCH_TEXELS);
+        return RZ_NOALLOC_TOO_LARGE;
+    }
+    if (t->pending_write) {
+        /* the copy that fills it is recorded but not submitted: submitting sizes scratch, which allocates */
+        fprintf(stderr, "mi355r: texture_sync_noalloc: the copy into this texture is still recorded; call graphics_flush first\n");
+        return RZ_NOALLOC_NOT_SUBMITTED;
+    }
+    if (!t->d_data || t->write_lane < 0) fatal("texture_sync_noalloc: the texture has no device image written by the GPU");
+    float4 *staging = scratch_on_device(g.device);
+    hipStream_t st = g.lanes[t->write_lane].stream;             /* behind the copy that wrote the image */
+    /* the passes of the flush in flight that fed the copy: if one of them ran out of scratch, the
+     * image is not there yet and settling the flush may allocate */
+    HIP_OK(hipStreamSynchronize(st));
+    for (const FlushRecord &fr : g_in_flight)
+        for (const FlushRecord::Copy &c : fr.copies)
+            if (c.tex == t && fr.control(c.producer)[2] != 0) {
+                fprintf(stderr, "mi355r: texture_sync_noalloc: the pass that renders this texture's source has to run again; call texture_sync\n");
+                return RZ_NOALLOC_NOT_SUBMITTED;
+            }
+    const int w = t->pub.width, h = t->pub.height;
+    rz_texture_untile_kernel<<<dim3((w + 15) / 16, (h + 15) / 16), dim3(256), 0, st>>>(t->d_data, staging, w, h, t->flags, t->mbits);
+    HIP_OK(hipGetLastError());
+    HIP_OK(hipMemcpyAsync(t->pub.buffer, staging, texels * sizeof(float4), hipMemcpyDeviceToHost, st));
+    HIP_OK(hipStreamSynchronize(st));
+    t->host_stale = false;
+    return RZ_NOALLOC_OK;
 }
 
 /* the last pass into `fb` of the flush in flight, if any */
