@@ -140,6 +140,7 @@ def main():
     ap.add_argument("--frames", type=int, default=128, help="frames per step and rank (default: one 128-view orbit)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (gloo: CPU rehearsal of the gather)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-other", action="store_true", help="skip the other BASELINE configurations (other_configs)")
     ap.add_argument("--even", action="store_true", help="N > 1: every rank renders the same number of frames (no gather-aware split)")
     args = ap.parse_args()
 
@@ -277,6 +278,27 @@ def main():
                                "algorithmic_bytes_per_frame": frame_bytes,
                                "kernel_ms_per_frame_total": pipeline_ms},
         }
+        if world > 1:
+            result["config"]["ranks_seen"] = dist.get_world_size()
+            result["config"]["backend"] = dist.get_backend()
+        if world == 1 and not args.no_other:
+            # the other BASELINE configurations, a few steps each, outside the timed region of `value`
+            from renderer_amd.configs import CONFIGS, time_config
+            for fb in fbs:
+                gpu.release(fb)
+            fbs = []
+            others = {}
+            for config in CONFIGS:
+                if config[0].startswith("C2"):
+                    continue
+                r = time_config(gpu, config, steps=3, warmup=1)
+                others[config[0].split()[0]] = r
+            # the compatible slow path: the reference's own per-face loops (one graphics_draw_triangle per face)
+            for config in CONFIGS:
+                if config[0].startswith(("C2", "C3")):
+                    r = time_config(gpu, config, steps=2, warmup=1, frames=32, per_triangle=True)
+                    others[config[0].split()[0] + "_per_triangle"] = r
+            result["other_configs"] = others
         if world == 1 and not args.no_cpu:
             result["cpu_baseline"] = cpu_baseline(48)
 

@@ -11,15 +11,7 @@ sys.path.insert(0, REPO)
 from renderer_amd import orbit                                     # noqa: E402
 from renderer_amd.binding import Pipeline, GPU_LIB, SCENES          # noqa: E402
 
-CONFIGS = [
-    ("C1 azura + shadow 800x600", os.path.join(SCENES, "azura_shadow.scn"), "azura", (800, 600)),
-    ("C2 helmet 1080p", "helmet", None, (1920, 1080)),
-    ("C3 kgirl skinned + blend 1080p", os.path.join(SCENES, "kgirl_blend.scn"), "kgirl", (1920, 1080)),
-    ("C4 dieselpunk + 2048^2 shadow 4K", os.path.join(SCENES, "dieselpunk_shadow.scn"), "dieselpunk", (3840, 2160)),
-    ("C5 buster animated 1080p", "buster", None, (1920, 1080)),
-    # procedural meshes and seeded textures only (tools/make_synthetic.py): no third-party asset involved
-    ("S1 synthetic blinn + shadow + cutoff + blend 1080p", os.path.join(SCENES, "synthetic_blinn.scn"), None, (1920, 1080)),
-]
+from renderer_amd.configs import CONFIGS                           # noqa: E402
 
 
 def main():
@@ -27,7 +19,7 @@ def main():
     frames = int(sys.argv[1]) if len(sys.argv) > 1 else 16
     only = sys.argv[2] if len(sys.argv) > 2 else None
     gpu = Pipeline(GPU_LIB)
-    for label, name, like, (w, h) in CONFIGS:
+    for label, name, like, (w, h), _ in CONFIGS:
         if only and not label.startswith(only):
             continue
         scene = gpu.open_scene(name, like)

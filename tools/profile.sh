@@ -7,7 +7,7 @@ TAG=${1:-run}
 OUT=gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-BENCH="python3 bench.py --steps 3 --warmup 1 --frames 32 --no-cpu"
+BENCH="python3 bench.py --steps 3 --warmup 1 --frames 32 --no-cpu --no-other"
 timeout -s KILL 240 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- $BENCH > "$OUT/trace.log" 2>&1 || { echo "trace pass failed"; tail -5 "$OUT/trace.log"; exit 1; }
 pass() {
     name=$1; shift
