@@ -31,8 +31,8 @@ SCENE = "helmet"
 ORBIT = 128                 # views on the orbit circle
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E
 KERNEL_SYMBOL = {"vertex": "rz_vertex_kernel", "setup": "rz_setup_kernel", "bin": "rz_bin_fill_kernel",
-                 "raster": "rz_visibility_kernel<2, false>", "shade_skybox": "rz_sky_kernel<2>",
-                 "shade_blinn": "rz_shade_list_kernel<0, true>", "shade_pbr": "rz_shade_list_kernel<1, true>"}
+                 "raster": "rz_strip_kernel<2, false>", "shade_skybox": "rz_sky_kernel<2>",
+                 "shade_blinn": "rz_shade_list_kernel<0, true, true>", "shade_pbr": "rz_shade_list_kernel<1, true, true>"}
 
 
 def reference_frame_bytes(counters, frames, faces):
@@ -48,9 +48,10 @@ def reference_frame_bytes(counters, frames, faces):
 def kernel_frame_bytes(counters, frames, faces):
     """The same figures attributed to the kernel that moves them, per frame, with the fragments
     each shade kernel really shades (only fragments that stay visible): vertex stream -> vertex
-    kernel; depth plane -> raster; texels + the colour bytes of its pixels -> shade kernels."""
+    kernel; depth plane + the plane of fragment references it hands to the shade kernels (4 B per
+    pixel each) -> raster; texels + the colour bytes of its pixels -> shade kernels."""
     shaded, skybox = counters[8] / frames, counters[9] / frames
-    return {"vertex": 240.0 * faces, "setup": 0.0, "bin": 0.0, "raster": 4.0 * WIDTH * HEIGHT,
+    return {"vertex": 240.0 * faces, "setup": 0.0, "bin": 0.0, "raster": 8.0 * WIDTH * HEIGHT,
             "shade_skybox": (16 + 4) * skybox, "shade_blinn": 0.0, "shade_pbr": (144 + 4) * (shaded - skybox)}
 
 
@@ -270,7 +271,11 @@ def main():
             "roofline": {"bound": "hbm", "kernel": KERNEL_SYMBOL[dominant], "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": measured_counters(KERNEL_SYMBOL[dominant], frames_per_launch, "hbm_bytes_per_launch"),
+                         # what limits it: the kernel is far from the HBM roof; its waves spend their time issuing
+                         # instructions (vector and scalar in about equal numbers) and waiting for dependent loads
+                         "limiter": "instruction issue + load latency, not HBM",
                          "valu_issue_frac": measured_counters(KERNEL_SYMBOL[dominant], frames_per_launch, "valu_issue_frac"),
+                         "salu_issue_frac": measured_counters(KERNEL_SYMBOL[dominant], frames_per_launch, "salu_issue_frac"),
                          "algorithmic_bytes_per_launch": bytes_per_launch, "launch_ms": launch_ms,
                          "frames_per_launch": frames_per_launch},
             "frame_roofline": {"bound": "hbm", "achieved": frame_achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -156,6 +156,8 @@ struct Context {
     int pixels_per_lane = 2;                /* MI355R_PPL=4: a wave takes the whole 32x8 tile */
     int micro_min_list = 256;               /* MI355R_MICRO_MIN_LIST: ... only in bins with at least this many list entries */
     int sky_pixels_per_lane = 2;            /* MI355R_SKY_PPL=1: the one-pixel-per-lane skybox kernel */
+    bool strip_sky = false;                 /* MI355R_STRIP_SKY=1: rz_strip_kernel shades skybox fragments in place (measured: slower) */
+    int strip = 2;                          /* MI355R_STRIP: 16x8 blocks a wave of rz_strip_kernel takes (8, 4, 2, 1); 0 = rz_visibility_kernel + rz_sky_kernel */
     /* passes with blended draws: 0 = whole through the ordered kernel, 1 = visibility first and the ordered kernel only for
      * the tiles that need it, 2 = the latter for large framebuffers (MI355R_SPLIT_BLEND=0 / 1; measured: 4K frames gain 8 %,
      * 1080p frames lose as much to the three extra launches) */
@@ -270,6 +272,10 @@ extern "C" int mi355r_init(int device) {
         if (env) g.pixels_per_lane = atoi(env);
         env = getenv("MI355R_SKY_PPL");
         if (env) g.sky_pixels_per_lane = atoi(env) == 1 ? 1 : 2;
+        env = getenv("MI355R_STRIP");
+        if (env) { const int v = atoi(env); g.strip = (v == 8 || v == 4 || v == 2 || v == 1) ? v : 0; }
+        env = getenv("MI355R_STRIP_SKY");
+        if (env) g.strip_sky = atoi(env) != 0;
         env = getenv("MI355R_SPLIT_BLEND");
         if (env) g.split_blend = atoi(env) != 0 ? 1 : 0;
         g.monolithic = getenv("MI355R_MONOLITHIC") != nullptr;
@@ -1325,7 +1331,8 @@ static void prepare_batch(const Batch &b, const FlushRecord &fr, bool reserve_on
     reserve(L.bin_range, bins, st);
     reserve(L.bin_counts, matrix, st);
     /* tiles are dealt to the parts of a list by their index: a part holds at most its even share */
-    const size_t queue_capacity = (tiles + RZ_QUEUE_WAYS - 1) / RZ_QUEUE_WAYS;
+    /* (32x8 tiles, or the two 16x8 blocks of each that rz_strip_kernel lists) */
+    const size_t queue_capacity = (2 * tiles + RZ_QUEUE_WAYS - 1) / RZ_QUEUE_WAYS;
     reserve(L.tile_listed, tiles, st);
     reserve(L.queue, 3 * RZ_QUEUE_WAYS * queue_capacity, st);           /* blinn, pbr, RZ_ORDERED_LIST */
     reserve(L.queue_counts, 3 * RZ_QUEUE_WAYS * RZ_QUEUE_PAD, st);
@@ -1448,7 +1455,7 @@ static void launch_batch(const Batch &b, const std::vector<PassPlan> &plans, cha
     size_t batch_tiles = 0;
     for (size_t i : b.members)
         batch_tiles += (size_t)((plans[i].fb->pub.width + RZ_TILE_W - 1) / RZ_TILE_W) * ((plans[i].fb->pub.height + RZ_TILE_H - 1) / RZ_TILE_H);
-    const uint32_t queue_capacity = (uint32_t)((batch_tiles + RZ_QUEUE_WAYS - 1) / RZ_QUEUE_WAYS);
+    const uint32_t queue_capacity = (uint32_t)((2 * batch_tiles + RZ_QUEUE_WAYS - 1) / RZ_QUEUE_WAYS);
     const dim3 shade_grid((unsigned)std::min<size_t>(max_tiles_x * max_tiles_y * n, (size_t)g.shade_workgroups));
     {
         /* what the kernels below index without a check of their own: wrong sizes here must stop the host, not fault the GPU */
@@ -1476,6 +1483,7 @@ static void launch_batch(const Batch &b, const std::vector<PassPlan> &plans, cha
      * blended fragments pile up and the shade kernels for the rest */
     const bool one_family = !g.generic_blend;
     const int only = !one_family ? -1 : b.families == (1 << RZ_FAMILY_BLINN) ? 0 : b.families == (1 << RZ_FAMILY_PBR) ? 1 : -1;
+    bool in_strips = false, sky_done = false;       /* the shade lists hold 16x8 blocks; skybox fragments are shaded already */
     if (b.has_blend && !splits_blend(batch_tiles, n)) {
         auto kernel = rz_raster_kernel<false>;
         if (only == 0) kernel = narrow ? rz_raster_kernel<false, 0, true> : rz_raster_kernel<false, 0, false>;
@@ -1497,10 +1505,20 @@ static void launch_batch(const Batch &b, const std::vector<PassPlan> &plans, cha
                 passes, L.tri.ptr, L.fan_tri.ptr, L.bin_list.ptr, L.vary.ptr, L.fan_vary.ptr, db, L.bin_range.ptr);
         else if (g.pixels_per_lane == 4)
             rz_visibility_kernel<4><<<tiles, dim3(64), 0, st>>>(passes, L.bin_list.ptr, L.bin_boxes.ptr, L.vary.ptr, L.fan_vary.ptr, db, L.bin_range.ptr);
-        else
+        else if (g.strip == 0)
             rz_visibility_kernel<2><<<tiles, dim3(128), 0, st>>>(passes, L.bin_list.ptr, L.bin_boxes.ptr, L.vary.ptr, L.fan_vary.ptr, db, L.bin_range.ptr);
+        else {
+            /* visibility and skybox shading together, a strip of 16x8 blocks per wave: the default */
+            in_strips = true;
+            const unsigned rows = (unsigned)max_tiles_y * RZ_TILE_H;
+            sky_done = g.strip_sky;
+            auto kernel = g.strip_sky ? (g.strip == 8 ? rz_strip_kernel<8, true> : g.strip == 4 ? rz_strip_kernel<4, true> : g.strip == 2 ? rz_strip_kernel<2, true> : rz_strip_kernel<1, true>)
+                                      : (g.strip == 8 ? rz_strip_kernel<8, false> : g.strip == 4 ? rz_strip_kernel<4, false> : g.strip == 2 ? rz_strip_kernel<2, false> : rz_strip_kernel<1, false>);
+            kernel<<<dim3((unsigned)max_tiles_x, (rows + 8u * g.strip - 1u) / (8u * g.strip), n), dim3(128), 0, st>>>(
+                passes, L.bin_list.ptr, L.bin_boxes.ptr, L.vary.ptr, L.fan_vary.ptr, db, L.bin_range.ptr);
+        }
         stamp();
-        if (b.families & (1 << RZ_FAMILY_SKYBOX)) {
+        if ((b.families & (1 << RZ_FAMILY_SKYBOX)) && !sky_done) {
             if (g.sky_pixels_per_lane == 2)     /* four per lane: 11.9 us per frame against 11.1 */
                 rz_sky_kernel<2><<<tiles, dim3(128), 0, st>>>(passes, L.tri.ptr, L.fan_tri.ptr, L.vary.ptr, L.fan_vary.ptr, db, L.ref.ptr);
             else
@@ -1508,13 +1526,15 @@ static void launch_batch(const Batch &b, const std::vector<PassPlan> &plans, cha
         }
         stamp();
         if (b.families & (1 << RZ_FAMILY_BLINN)) {
-            auto kernel = narrow ? rz_shade_list_kernel<0, true> : rz_shade_list_kernel<0, false>;
+            auto kernel = in_strips ? (narrow ? rz_shade_list_kernel<0, true, true> : rz_shade_list_kernel<0, false, true>)
+                                    : (narrow ? rz_shade_list_kernel<0, true, false> : rz_shade_list_kernel<0, false, false>);
             kernel<<<shade_grid, dim3(256), 0, st>>>(passes, L.tri.ptr, L.fan_tri.ptr, L.vary.ptr, L.fan_vary.ptr, db, L.ref.ptr,
                                                      L.queue.ptr, L.queue_counts.ptr, queue_capacity);
         }
         stamp();
         if (b.families & (1 << RZ_FAMILY_PBR)) {
-            auto kernel = narrow ? rz_shade_list_kernel<1, true> : rz_shade_list_kernel<1, false>;
+            auto kernel = in_strips ? (narrow ? rz_shade_list_kernel<1, true, true> : rz_shade_list_kernel<1, false, true>)
+                                    : (narrow ? rz_shade_list_kernel<1, true, false> : rz_shade_list_kernel<1, false, false>);
             kernel<<<shade_grid, dim3(256), 0, st>>>(passes, L.tri.ptr, L.fan_tri.ptr, L.vary.ptr, L.fan_vary.ptr, db, L.ref.ptr,
                                                      L.queue.ptr, L.queue_counts.ptr, queue_capacity);
         }

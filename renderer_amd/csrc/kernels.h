@@ -1425,6 +1425,354 @@ __global__ void __launch_bounds__(256 / PPL) rz_visibility_kernel(const PassPara
     }
 }
 
+/* K4c  visibility AND skybox shading for passes without blending, a STRIP of blocks per wave.
+ *
+ * rz_visibility_kernel spends its time waiting: a wave lives for some 14 000 cycles and issues 700
+ * instructions, the rest is a chain of dependent memory round trips (the pass's parameters, the bin's
+ * range, the list's first entries, the surviving entries, the stores), paid by every wave for 128
+ * pixels.  Here a wave keeps its 16-pixel column and takes STRIP blocks of 16x8 pixels one above the
+ * other inside one bin -- same list, same parameters -- so the chain is paid once per 128 * STRIP
+ * pixels; a list of up to 64 entries (any bin that holds only sky) stays in the lanes' registers for
+ * the whole strip.  The first group of the next block's candidates is requested before the current
+ * block's epilogue, which hides its latency behind the epilogue's arithmetic.
+ *
+ * The epilogue shades skybox fragments in place (skybox_shader.c:21-29; what rz_sky_kernel does
+ * from the reference plane): the sky fills most of a frame, and writing a reference per sky pixel only
+ * to read it back in the next kernel was most of this stage's memory traffic.  References are written
+ * only for blocks that hold blinn or pbr fragments; such a block is appended to its family's work list
+ * (16x8 blocks, not 32x8 tiles: the wave that owns the block is the only one to list it). */
+#define RZ_BLOCK_ITEM(pass, by, bx) (((uint32_t)(pass) << 21) | ((uint32_t)(by) << 10) | (uint32_t)(bx))
+template <int STRIP, bool SKY>
+__global__ void __launch_bounds__(128) rz_strip_kernel(const PassParams *__restrict__ passes,
+        const BinEntry *__restrict__ list_base, const uint2 *__restrict__ box_base,
+        const float *__restrict__ vary_base, const float *__restrict__ fan_vary_base,
+        const char *__restrict__ upload_base, const uint2 *__restrict__ bin_range_base) {
+    constexpr int PPL = 2;
+    static_assert(RZ_BIN % (8 * STRIP) == 0, "a strip lies inside one bin");
+    const PassParams P = passes[blockIdx.z];
+    const int sy0 = (int)blockIdx.y * 8 * STRIP;
+    if ((int)blockIdx.x >= P.tiles_x || sy0 >= P.height) return;
+    if (P.control[2] != 0u) return;                             /* out of scratch, or left out: the pass is run again later */
+    const BinEntry *list_table = list_base + P.list_off;
+    const float *vary_table = vary_base + (size_t)P.tri_off * 3 * RZ_VARY_STRIDE;
+    const float *fan_vary_table = fan_vary_base + (size_t)P.fan_off * RZ_MAX_POLY * RZ_VARY_STRIDE;
+    const DrawRec *draw_table = (const DrawRec*)(upload_base + P.draws_off);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int tx0 = (int)blockIdx.x * RZ_TILE_W;
+    const int bx0 = tx0 + wave * 8 * PPL, bx1 = bx0 + 8 * PPL - 1;
+    int px[PPL];
+    for (int q = 0; q < PPL; q++) px[q] = bx0 + 8 * q + (lane & 7);
+    const int bin = (sy0 / RZ_BIN) * P.bins_x + tx0 / RZ_BIN;
+    const uint2 range = (bin_range_base + P.bin_off)[bin];          /* {first entry, entries} */
+    const uint32_t count = range.y;
+    if (count == 0) {               /* nothing but the pending clears (uniform over the workgroup) */
+        const bool blank_refs = !SKY && P.ref_scanned;              /* a kernel that scans every pixel's reference follows */
+        if (!P.clear_color_pending && !P.clear_depth_pending && !blank_refs) return;
+        for (int k = 0; k < STRIP; k++) {
+            const int py = sy0 + 8 * k + (lane >> 3);
+            for (int q = 0; q < PPL; q++) {
+                if (px[q] >= P.width || py >= P.height) continue;
+                const uint32_t pixel = (uint32_t)py * (uint32_t)P.width + (uint32_t)px[q];
+                if (P.clear_depth_pending) P.depth[pixel] = P.clear_depth;
+                if (P.clear_color_pending) P.color[pixel] = P.clear_color;
+                if (blank_refs) P.ref[pixel] = RZ_REF_NONE;
+            }
+        }
+        return;
+    }
+    const BinEntry *list = list_table + range.x;
+    const uint2 *boxes = box_base + P.list_off + range.x;
+
+    /* small triangles, one per lane, into per-pixel keys in LDS: see rz_visibility_kernel */
+    __shared__ unsigned long long micro_keys[256];
+    __shared__ uint32_t micro_ring[2][128];
+    unsigned long long *keys = micro_keys + wave * 64 * PPL;
+    uint32_t *ring = micro_ring[wave];
+    const int micro_area = (P.counters || count < (uint32_t)P.micro_min_list) ? 0 : P.micro_area;
+    const int sx1 = min(bx1, P.width - 1);
+
+    /* this lane's candidate of the next group of 64 entries (see rz_visibility_kernel); a list of at
+     * most 64 entries is loaded once and serves every block of the strip */
+    const bool long_list = count >= (uint32_t)P.micro_min_list;    /* wave-uniform */
+    float4 n0 = make_float4(0, 0, 0, 0), n1 = n0;
+    uint2 nbox = make_uint2(RZ_BBOX_EMPTY_X, 0u);
+    auto request_first_group = [&]() {
+        if ((uint32_t)lane < count) {
+            if (long_list) {
+                nbox = boxes[lane];
+            } else {
+                const float4 *e = (const float4*)&list[lane];          /* reference + record, 80 bytes */
+                n0 = e[1]; n1 = e[2];
+                nbox = entry_box(e[4]);
+            }
+        }
+    };
+    request_first_group();
+
+    for (int k = 0; k < STRIP; k++) {
+        const int by0 = sy0 + 8 * k, by1 = by0 + 7;
+        if (by0 >= P.height) break;                                 /* uniform */
+        const int py = by0 + (lane >> 3);
+        const int sy1 = min(by1, P.height - 1);
+        bool valid[PPL];
+        uint32_t pixel[PPL];
+        float zcur[PPL];
+        uint32_t ref_of[PPL];                                       /* tagged with the family; NONE = no fragment */
+        int ord_of[PPL];                                            /* its position in the bin's list; -1 = what the buffer held */
+        for (int q = 0; q < PPL; q++) {
+            valid[q] = px[q] < P.width && py < P.height;
+            pixel[q] = (uint32_t)py * (uint32_t)P.width + (uint32_t)px[q];
+            ref_of[q] = RZ_REF_NONE;
+            ord_of[q] = -1;
+            zcur[q] = P.clear_depth;
+            if (valid[q] && !P.clear_depth_pending) zcur[q] = P.depth[pixel[q]];
+        }
+        uint32_t ring_head = 0, ring_tail = 0;                      /* wave-uniform */
+        if (micro_area)
+            for (int q = 0; q < PPL; q++) keys[q * 64 + lane] = ~0ull;
+        auto rasterise_ring = [&](uint32_t n) {                     /* one triangle per lane, the ring's oldest n <= 64 */
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            const bool on = (uint32_t)lane < n;
+            const uint32_t ord = on ? ring[(ring_head + (uint32_t)lane) & 127u] : 0u;
+            ring_head += n;
+            TriRec r;
+            int x0 = 0, x1 = -1, y0 = 0, y1 = -1;
+            if (on) {
+                const float4 *e = (const float4*)&list[ord];
+                const float4 a = e[1], b = e[2], c = e[3], d = e[4];
+                r.ax = a.x; r.ay = a.y; r.abx = a.z; r.aby = a.w;
+                r.acx = b.x; r.acy = b.y; r.factor = b.z; r.z[0] = b.w;
+                r.z[1] = c.x; r.z[2] = c.y;
+                const uint32_t bx = __float_as_uint(d.z), by = __float_as_uint(d.w);
+                x0 = max((int)(bx & 0xffffu), bx0); x1 = min((int)(bx >> 16), sx1);
+                y0 = max((int)(by & 0xffffu), by0); y1 = min((int)(by >> 16), sy1);
+            }
+            int x = x0, y = y0;
+            const uint32_t low = ~ord;
+            while (__any(y <= y1)) {
+                if (y <= y1) {
+                    float w0, w1, w2;
+                    pixel_weights(r, x, y, w0, w1, w2);
+                    const float depth = r.z[0] * w0 + r.z[1] * w1 + r.z[2] * w2;                       /* :403-408 */
+                    if (w0 > -RZ_EPS && w1 > -RZ_EPS && w2 > -RZ_EPS && depth == depth) {             /* :516-519 */
+                        const uint32_t bits = __float_as_uint(depth + 0.0f);
+                        const uint32_t up = bits ^ ((uint32_t)((int32_t)bits >> 31) | 0x80000000u);
+                        const int lx = x - bx0, ly = y - by0;
+                        atomicMin(&keys[(lx >> 3) * 64 + (ly << 3) + (lx & 7)], ((unsigned long long)up << 32) | low);
+                    }
+                    if (++x > x1) { x = x0; y++; }
+                }
+            }
+        };
+        /* block corners at pixel centres, for the conservative triangle/block test */
+        const float cx0 = (float)bx0 + 0.5f, cx1 = (float)bx1 + 0.5f, cy0 = (float)by0 + 0.5f, cy1 = (float)by0 + 7.5f;
+
+        for (uint32_t base = 0; base < count;) {
+            const uint2 cbox = nbox;
+            float4 c0 = n0, c1 = n1;
+            const bool present = base + lane < count;
+            const BinEntry *group = list + base;
+            const uint32_t group_at = base;
+            base += 64u;
+            if (base + lane < count) {
+                if (long_list) {
+                    nbox = boxes[base + lane];
+                } else {
+                    const float4 *e = (const float4*)&list[base + lane];
+                    n0 = e[1]; n1 = e[2];
+                    nbox = entry_box(e[4]);
+                }
+            }
+            const bool cutoff = (cbox.y >> 31) != 0;
+            bool hit = false;
+            if (present) {
+                hit = box_overlaps(make_uint2(cbox.x, cbox.y & 0x7fffffffu), bx0, by0, bx1, by1);
+                if (hit && long_list) {
+                    const float4 *e = (const float4*)&group[lane];
+                    c0 = e[1]; c1 = e[2];
+                }
+                if (hit) hit = !block_outside(c0, c1, cx0, cx1, cy0, cy1);
+            }
+            if (micro_area) {
+                bool small = false;
+                if (hit) {
+                    const uint32_t bx = cbox.x, by = cbox.y & 0x7fffffffu;
+                    const int w = min((int)(bx >> 16), sx1) - max((int)(bx & 0xffffu), bx0) + 1;
+                    const int h = min((int)(by >> 16), sy1) - max((int)(by & 0xffffu), by0) + 1;
+                    small = w * h <= micro_area && !cutoff;
+                }
+                const unsigned long long smalls = __ballot(small);
+                if (smalls) {
+                    if (small) ring[(ring_tail + __builtin_amdgcn_mbcnt_hi((uint32_t)(smalls >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)smalls, 0u))) & 127u] = group_at + (uint32_t)lane;
+                    ring_tail += (uint32_t)__popcll(smalls);
+                    hit = hit && !small;
+                    if (ring_tail - ring_head >= 64u) rasterise_ring(64u);
+                }
+            }
+            unsigned long long todo = __ballot(hit);
+            while (todo) {
+                /* the wave-uniform entry index makes these scalar loads */
+                const uint32_t at = (uint32_t)__ffsll((long long)todo) - 1u;
+                const BinEntry *e = &group[at];
+                todo &= todo - 1;
+                const uint32_t ref = e->tri;
+                const TriRec r = e->rec;
+                const int x0 = (int)(r.bx & 0xffffu), x1 = (int)(r.bx >> 16);
+                const int y0 = (int)(r.by & 0xffffu), y1 = (int)(r.by >> 16);
+                const bool row_in = py >= y0 && py <= y1;
+                float w[PPL][3], depth[PPL];
+                bool pass[PPL];
+                for (int q = 0; q < PPL; q++) {
+                    pixel_weights(r, px[q], py, w[q][0], w[q][1], w[q][2]);
+                    const bool inside = valid[q] && row_in && px[q] >= x0 && px[q] <= x1 &&
+                                        w[q][0] > -RZ_EPS && w[q][1] > -RZ_EPS && w[q][2] > -RZ_EPS;     /* :516-519 */
+                    depth[q] = r.z[0] * w[q][0] + r.z[1] * w[q][1] + r.z[2] * w[q][2];              /* :403-408 */
+                    pass[q] = inside && depth[q] <= zcur[q];                                          /* :523 */
+                }
+                bool any_pass = false;
+                for (int q = 0; q < PPL; q++) any_pass |= pass[q];
+                if (!__any(any_pass)) continue;
+                if (P.counters) {       /* fragments the reference would shade: [2] all, [6] skybox */
+                    unsigned long long n = 0;
+                    for (int q = 0; q < PPL; q++) n += (unsigned long long)__popcll(__ballot(pass[q]));
+                    if (lane == 0) {
+                        atomicAdd(P.counters + 2, n);
+                        if (RZ_META_FAMILY(r.meta) == 2) atomicAdd(P.counters + 6, n);
+                    }
+                }
+                if (RZ_META_CUTOFF(r.meta)) {
+                    /* the shaders' discard test (blinn_shader.c:104-113, 220; pbr_shader.c:116-134, 452):
+                     * alpha = base alpha * first map's alpha, from the interpolated texcoord */
+                    const DrawRec &D = draw_table[RZ_META_DRAW(r.meta)];
+                    const int tc = D.family == 0 ? 6 : 19;
+                    const float *v0, *v1, *v2;
+                    ref_varyings(ref, vary_table, fan_vary_table, v0, v1, v2);
+                    for (int q = 0; q < PPL; q++) {
+                        float q0 = r.rw[0] * w[q][0], q1 = r.rw[1] * w[q][1], q2 = r.rw[2] * w[q][2];
+                        float norm = 1 / (q0 + q1 + q2);
+                        float tu = (v0[tc] * q0 + v1[tc] * q1 + v2[tc] * q2) * norm;
+                        float tv = (v0[tc + 1] * q0 + v1[tc + 1] * q1 + v2[tc + 1] * q2) * norm;
+                        if (pass[q]) {
+                            float a = D.base[3];
+                            if (D.maps[0].data) a *= sample_repeat(D.maps[0], tu, tv).w;
+                            if (a < D.alpha_cutoff) pass[q] = false;
+                        }
+                    }
+                }
+                const uint32_t tagged = ref | (RZ_META_FAMILY(r.meta) << 28);
+                for (int q = 0; q < PPL; q++) if (pass[q]) { zcur[q] = depth[q]; ref_of[q] = tagged; ord_of[q] = (int)(group_at + at); }
+            }
+        }
+        if (micro_area) {
+            if (ring_tail != ring_head) rasterise_ring(ring_tail - ring_head);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            for (int q = 0; q < PPL; q++) {
+                const unsigned long long key = keys[q * 64 + lane];
+                if (key == ~0ull) continue;
+                const uint32_t up = (uint32_t)(key >> 32);
+                const float depth = __uint_as_float(up ^ ((up >> 31) ? 0x80000000u : 0xffffffffu));
+                const int ord = (int)~(uint32_t)key;
+                if (depth < zcur[q] || (depth == zcur[q] && ord > ord_of[q])) {
+                    const BinEntry *e = &list[ord];
+                    zcur[q] = depth;
+                    ref_of[q] = e->tri | (RZ_META_FAMILY(e->rec.meta) << 28);
+                    ord_of[q] = ord;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");      /* the keys are set up again for the next block */
+        }
+        /* the next block's first candidates: on their way while this block's epilogue runs */
+        if (count > 64u && k + 1 < STRIP) request_first_group();
+
+        /* ---- epilogue: depth, skybox colour, references of blocks with blinn / pbr fragments ---- */
+        bool sky[PPL], any_sky = false, listed = false;
+        for (int q = 0; q < PPL; q++) {
+            if (valid[q] && (ref_of[q] != RZ_REF_NONE || P.clear_depth_pending)) P.depth[pixel[q]] = zcur[q];  /* else: what was there */
+            const uint32_t family = (ref_of[q] >> 28) & 3u;         /* RZ_REF_NONE reads as family 3 */
+            sky[q] = family == 2u;
+            any_sky |= sky[q];
+            listed |= family < 2u;
+            /* a pixel without a fragment shows the clear colour */
+            if (valid[q] && P.clear_color_pending && ref_of[q] == RZ_REF_NONE) P.color[pixel[q]] = P.clear_color;
+        }
+        if (SKY && __any(any_sky)) {
+            /* the colour below only lends its alpha byte; under a pending clear it is the clear colour */
+            uint32_t ccur[PPL];
+            for (int q = 0; q < PPL; q++) {
+                ccur[q] = P.clear_color;
+                if (sky[q] && !P.clear_color_pending) ccur[q] = P.color[pixel[q]];
+            }
+            int mine = -1;                                          /* a list position this lane's sky fragments come from */
+            for (int q = PPL - 1; q >= 0; q--) if (sky[q]) mine = ord_of[q];
+            const int first = __builtin_amdgcn_readlane(mine, __ffsll((long long)__ballot(any_sky)) - 1);
+            bool uniform = true;
+            for (int q = 0; q < PPL; q++) uniform = uniform && (!sky[q] || ord_of[q] == first);
+            if (__all(uniform)) {
+                /* one sky triangle under all of them: its record and varyings come through scalar loads */
+                const BinEntry *e = &list[first];
+                const uint32_t ref = e->tri;
+                const TriRec m = e->rec;
+                const float *m0, *m1, *m2;
+                ref_varyings(ref, vary_table, fan_vary_table, m0, m1, m2);
+                const DrawRec &D = draw_table[RZ_META_DRAW(m.meta)];
+                for (int q = 0; q < PPL; q++) {
+                    if (!sky[q]) continue;
+                    float w0, w1, w2, v[4];
+                    pixel_weights(m, px[q], py, w0, w1, w2);
+                    const float q0 = m.rw[0] * w0, q1 = m.rw[1] * w1, q2 = m.rw[2] * w2;    /* graphics.c:426-429 */
+                    const float norm = 1 / (q0 + q1 + q2);
+                    interpolate_lane<3>(m0, m1, m2, q0, q1, q2, norm, v);
+                    f4 color = fs_skybox(D, v);
+                    color = mk4(d_sat(color.x), d_sat(color.y), d_sat(color.z), d_sat(color.w));     /* graphics.c:452-468; no blending in these passes */
+                    P.color[pixel[q]] = pack_rgb(color, ccur[q]);
+                }
+                if (P.counters) {       /* [8] fragments shaded on the device, [9] of those, skybox */
+                    unsigned long long n = 0;
+                    for (int q = 0; q < PPL; q++) n += (unsigned long long)__popcll(__ballot(sky[q]));
+                    if (lane == 0) { atomicAdd(P.counters + 8, n); atomicAdd(P.counters + 9, n); }
+                }
+            } else {
+                for (int q = 0; q < PPL; q++) {                     /* an edge of the sky box crosses the block */
+                    if (!__any(sky[q])) continue;
+                    TriRec m;
+                    const float *m0 = vary_table, *m1 = vary_table, *m2 = vary_table;
+                    if (sky[q]) {
+                        m = load_tri(&list[ord_of[q]].rec);
+                        ref_varyings(ref_of[q] & ~RZ_REF_FAMILY_BITS, vary_table, fan_vary_table, m0, m1, m2);
+                    }
+                    shade_lanes<2>(P, draw_table, sky[q], m, m0, m1, m2, px[q], py, ccur[q]);
+                    if (sky[q]) P.color[pixel[q]] = ccur[q];
+                }
+            }
+        }
+        /* without SKY the skybox's fragments are left to rz_sky_kernel, which looks at the references of every pixel */
+        if (!SKY && P.ref_scanned && !__any(listed))
+            for (int q = 0; q < PPL; q++) if (valid[q]) P.ref[pixel[q]] = ref_of[q];
+        if (__any(listed)) {
+            /* the block holds blinn or pbr fragments: its references are written -- all of them, the
+             * family's shade kernel looks at every pixel of a listed block -- and the block goes on the
+             * work list of each family it holds (parts chosen by the block's index in the batch, so
+             * that no part can get more than its even share) */
+            for (int q = 0; q < PPL; q++) if (valid[q]) P.ref[pixel[q]] = ref_of[q];
+            const uint32_t block_x = (uint32_t)bx0 / (8u * PPL), block_y = (uint32_t)by0 / 8u;
+            const uint32_t index = 2u * P.tile_off + block_y * 2u * (uint32_t)P.tiles_x + block_x;
+            for (uint32_t f = 0; f < 2; f++) {
+                bool mine_f = false;
+                for (int q = 0; q < PPL; q++) mine_f |= ((ref_of[q] >> 28) & 3u) == f;
+                if (!__any(mine_f)) continue;
+                if (lane == 0) {
+                    const uint32_t part = f * RZ_QUEUE_WAYS + (index & (RZ_QUEUE_WAYS - 1u));
+                    const uint32_t at = atomicAdd(&P.queue_counts[part * RZ_QUEUE_PAD], 1u);
+                    if (at < P.queue_capacity)
+                        P.queue[(size_t)part * P.queue_capacity + at] = RZ_BLOCK_ITEM(blockIdx.z, block_y, block_x);
+                    else
+                        atomicOr(&P.control[2], (uint32_t)RZ_ERR_QUEUE_OVERFLOW);
+                }
+            }
+        }
+    }
+}
+
 /* K5  per-family fragment kernels for passes rasterised with SPLIT = true:
  * every lane shades the one fragment its pixel refers to. */
 template <int FAMILY, bool NARROW = false>
@@ -1566,9 +1914,11 @@ __global__ void __launch_bounds__(256 / PPL) rz_sky_kernel(const PassParams *__r
     }
 }
 
-/* over the family's work list of tiles: a fixed number of workgroups strides over it, so no wave
- * is spent on a tile without work */
-template <int FAMILY, bool NARROW>
+/* over the family's work list: a fixed number of workgroups strides over it, so no wave is spent on
+ * pixels without work.  The list holds 32x8 tiles (one per workgroup and turn, a wave takes two rows
+ * of 32 pixels) or, with BLOCKS, the 16x8 blocks rz_strip_kernel lists (two per workgroup and turn,
+ * a wave takes four rows of 16 pixels). */
+template <int FAMILY, bool NARROW, bool BLOCKS>
 __global__ void __launch_bounds__(256) rz_shade_list_kernel(const PassParams *__restrict__ passes,
         const TriRec *__restrict__ tri_base, const TriRec *__restrict__ fan_base,
         const float *__restrict__ vary_base, const float *__restrict__ fan_vary_base,
@@ -1580,13 +1930,24 @@ __global__ void __launch_bounds__(256) rz_shade_list_kernel(const PassParams *__
     uint32_t longest = my_count;
     for (int off = 32; off > 0; off >>= 1) longest = max(longest, (uint32_t)__shfl_xor((int)longest, off));
     longest = (uint32_t)__builtin_amdgcn_readfirstlane((int)longest);
-    for (uint32_t k = blockIdx.x; k < longest * RZ_QUEUE_WAYS; k += gridDim.x) {
+    constexpr uint32_t per_turn = BLOCKS ? 2u : 1u;
+    /* (wave-uniform, and said so: everything read through `k` -- the item, the pass's parameters, the
+     * draw record -- must come through scalar loads) */
+    const uint32_t half = BLOCKS ? (uint32_t)__builtin_amdgcn_readfirstlane(wave >> 1) : 0u;
+    for (uint32_t k = blockIdx.x * per_turn + half; k < longest * RZ_QUEUE_WAYS; k += gridDim.x * per_turn) {
         const uint32_t part = k & (RZ_QUEUE_WAYS - 1u), index = k / RZ_QUEUE_WAYS;
         if (index >= (uint32_t)__builtin_amdgcn_readlane((int)my_count, (int)part)) continue;
         const uint32_t item = queue_base[(size_t)(FAMILY * RZ_QUEUE_WAYS + part) * queue_capacity + index];
-        const PassParams P = passes[item >> 20];
-        shade_pixel<FAMILY, NARROW>(P, tri_base, fan_base, vary_base, fan_vary_base, upload_base, ref_base,
-                                    (int)(item & 511u) * RZ_TILE_W + (lane & 31), (int)((item >> 9) & 2047u) * RZ_TILE_H + wave * 2 + (lane >> 5));
+        if constexpr (BLOCKS) {
+            const PassParams P = passes[item >> 21];
+            const int t = (int)(threadIdx.x & 127u);
+            shade_pixel<FAMILY, NARROW>(P, tri_base, fan_base, vary_base, fan_vary_base, upload_base, ref_base,
+                                        (int)(item & 1023u) * 16 + (t & 15), (int)((item >> 10) & 2047u) * 8 + (t >> 4));
+        } else {
+            const PassParams P = passes[item >> 20];
+            shade_pixel<FAMILY, NARROW>(P, tri_base, fan_base, vary_base, fan_vary_base, upload_base, ref_base,
+                                        (int)(item & 511u) * RZ_TILE_W + (lane & 31), (int)((item >> 9) & 2047u) * RZ_TILE_H + wave * 2 + (lane >> 5));
+        }
     }
 }
 

@@ -89,5 +89,9 @@ for k in stats:
             entry["valu_insts_per_launch"] = valu
             entry["salu_insts_per_launch"] = salu
             entry["valu_issue_frac"] = valu * 4 / (1024 * entry["median_us"] * 2400.0)
+            # scalar issue: a compute unit's scalar unit takes one instruction per cycle from its four SIMDs in turn,
+            # i.e. one per SIMD every 4 cycles, like the vector unit; scalar memory instructions go through it too
+            smem = sum(c["SQ_INSTS_SMEM"]) / len(c["SQ_INSTS_SMEM"]) if "SQ_INSTS_SMEM" in c else 0.0
+            entry["salu_issue_frac"] = (salu + smem) * 4 / (1024 * entry["median_us"] * 2400.0)
         traffic["kernels"][k] = entry
 json.dump(traffic, open(os.path.join(out, "traffic.json"), "w"), indent=1)
