@@ -1297,9 +1297,14 @@ static void scratch_entries(const FlushRecord &fr, size_t plan, bool again, size
     *list_cap = std::min(pl.T * RZ_MAX_FAN * nb, std::max(std::max<size_t>(pl.T * 16, 1u << 18), g.list_highwater));
 }
 
-/* sizes the lane's scratch for the batch and (second call) writes the PassParams array; `again`: the
- * batch holds passes of a finished flush that are run a second time */
-static void prepare_batch(const Batch &b, const FlushRecord &fr, bool reserve_only, bool again) {
+/* sizes the lane's scratch for the batch and (second call) writes the PassParams array.  PREPARE_FIRST:
+ * a new flush.  PREPARE_REWRITE: the same flush once more, before anything of it was launched (the
+ * lanes' scratch has moved or the estimates were raised): only the scratch part changes.
+ * PREPARE_AGAIN: the batch holds passes of a finished flush that are run a second time, with scratch
+ * of the sizes they reported. */
+enum PrepareMode { PREPARE_FIRST, PREPARE_REWRITE, PREPARE_AGAIN };
+static void prepare_batch(const Batch &b, const FlushRecord &fr, bool reserve_only, PrepareMode mode) {
+    const bool again = mode == PREPARE_AGAIN;
     const std::vector<PassPlan> &plans = fr.plans;
     char *hb = g.ring_host + fr.at, *db = g.ring_dev + fr.at;
     Lane &L = g.lanes[b.lane];
@@ -1348,11 +1353,11 @@ static void prepare_batch(const Batch &b, const FlushRecord &fr, bool reserve_on
         Fb *fb = pl.fb;
         const int W = fb->pub.width, H = fb->pub.height;
         PassParams P;
-        if (again) {
+        if (mode != PREPARE_FIRST) {
             /* as it was submitted: target, pending clears, tables -- only the scratch below changes;
              * a pass run again waits for nothing of its flush */
             memcpy(&P, hb + fr.params_at + sizeof(PassParams) * pl.slot, sizeof P);
-            P.level = 0;
+            if (again) P.level = 0;
         } else {
             memset(&P, 0, sizeof P);
             P.color = fb->d_color;
@@ -1588,8 +1593,8 @@ static void run_again(FlushRecord &fr) {
          * list entries it reported are too few: its second run has enough blocks, reports the true
          * number of entries and may need a third. */
         for (int attempt = 0;; attempt++) {
-            prepare_batch(r, fr, true, true);
-            prepare_batch(r, fr, false, true);
+            prepare_batch(r, fr, true, PREPARE_AGAIN);
+            prepare_batch(r, fr, false, PREPARE_AGAIN);
             HIP_OK(hipMemcpyAsync(db + r.off_params, hb + r.off_params, sizeof(PassParams) * r.members.size(), hipMemcpyHostToDevice, L.stream));
             launch_batch(r, fr.plans, db);
             for (size_t i : r.members)
@@ -1625,7 +1630,8 @@ static void run_again(FlushRecord &fr) {
 
 /* Looks at the control blocks of the flushes in flight -- waiting for their lanes unless the caller
  * knows them idle -- and runs again what did not run. */
-static void settle_in_flight(bool lanes_idle) {
+static bool settle_in_flight(bool lanes_idle) {
+    bool ran_again = false;
     while (!g_in_flight.empty()) {
         FlushRecord fr = std::move(g_in_flight.back());
         g_in_flight.pop_back();
@@ -1643,11 +1649,13 @@ static void settle_in_flight(bool lanes_idle) {
                 HIP_OK(hipStreamSynchronize(g.copy_stream));
             }
             run_again(fr);
+            ran_again = true;
         }
     }
+    return ran_again;
 }
 
-static void check_passes_in_flight() { settle_in_flight(true); }
+static void check_passes_in_flight() { (void)settle_in_flight(true); }
 
 /* A framebuffer is about to be handed out and its lane has drained: its own passes of the flush in
  * flight either all ran (their control blocks came back on that lane) or the flush is settled now. */
@@ -1777,7 +1785,7 @@ struct FlushProfile {
     }
     ~FlushProfile() {
         if (!on || !flushes) return;
-        static const char *names[8] = {"plan", "batches", "tables", "scratch+params", "upload", "launches", "copies", "tail"};
+        static const char *names[8] = {"plan", "batches", "tables", "scratch+params", "upload", "wait for the flush before", "launches", "copies"};
         fprintf(stderr, "mi355r: %llu flushes, %llu passes; host microseconds per pass:", flushes, passes);
         for (int i = 0; i < 8; i++) fprintf(stderr, " %s %.2f", names[i], seconds[i] * 1e6 / (double)passes);
         fprintf(stderr, "\n");
@@ -1905,19 +1913,29 @@ extern "C" void graphics_flush(void) {
     }
     prof.mark(1);
 
-    settle_in_flight(false);        /* the flush before this one */
     fr.at = ring_alloc(total);
     char *hb = g.ring_host + fr.at, *db = g.ring_dev + fr.at;
     memset(hb + fr.flag_at, 0, 256);
     for (auto &pl : plans) fill_pass(pl, hb, db);
     prof.mark(2);
     /* scratch first, for every batch: growing a buffer moves it, and the tables written next hold its address */
-    for (auto &b : batches) prepare_batch(b, fr, true, false);
-    for (auto &b : batches) prepare_batch(b, fr, false, false);
+    for (auto &b : batches) prepare_batch(b, fr, true, PREPARE_FIRST);
+    for (auto &b : batches) prepare_batch(b, fr, false, PREPARE_FIRST);
     prof.mark(3);
     HIP_OK(hipMemcpyAsync(db + fr.flag_at, hb + fr.flag_at, total - fr.flag_at, hipMemcpyHostToDevice, g.copy_stream));
-    hipEvent_t uploaded = new_event(g.copy_stream);
     prof.mark(4);
+    /* Now the flush before this one: everything above went on while the GPU was still busy with it, and
+     * nothing has been launched yet.  If some of its passes had to run again the lanes' scratch may
+     * have grown and moved, and the estimates have been raised: this flush's parameters are written
+     * and sent once more. */
+    if (settle_in_flight(false)) {
+        HIP_OK(hipStreamSynchronize(g.copy_stream));
+        for (auto &b : batches) prepare_batch(b, fr, true, PREPARE_REWRITE);
+        for (auto &b : batches) prepare_batch(b, fr, false, PREPARE_REWRITE);
+        HIP_OK(hipMemcpyAsync(db + fr.flag_at, hb + fr.flag_at, total - fr.flag_at, hipMemcpyHostToDevice, g.copy_stream));
+    }
+    hipEvent_t uploaded = new_event(g.copy_stream);
+    prof.mark(5);
 
     bool *used = fr.used;
     for (auto &b : batches) {
@@ -1953,7 +1971,7 @@ extern "C" void graphics_flush(void) {
             hipEvent_t done = new_event(L.stream);
             for (Tex *t : sampled) t->read_events.push_back(done);
         }
-        prof.mark(5);
+        prof.mark(6);
         {
             /* the recorded copies this batch feeds, on its lane, RZ_COPY_GROUP per launch */
             std::vector<size_t> feeds;
@@ -1991,7 +2009,7 @@ extern "C" void graphics_flush(void) {
         /* the batch's control blocks come back behind it, on its lane */
         HIP_OK(hipMemcpyAsync(hb + CONTROL_BYTES * plans[b.members[0]].slot, db + CONTROL_BYTES * plans[b.members[0]].slot,
                               CONTROL_BYTES * b.members.size(), hipMemcpyDeviceToHost, L.stream));
-        prof.mark(6);
+        prof.mark(7);
     }
     prof.flushes++;
     prof.passes += plans.size();
