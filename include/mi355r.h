@@ -223,6 +223,36 @@ void graphics_draw_mesh(rz_framebuffer *framebuffer, rz_program *program,
                         const rz_vertex *vertices, int num_faces);
 void mesh_invalidate(const rz_vertex *vertices);
 
+/* Skeletal poses evaluated on the device: renderer/core/skeleton.c:231-341 (key search, lerp / slerp,
+ * joint hierarchy, inverse bind, normal matrices) for every pose a flush needs, in one kernel launch,
+ * straight into the memory the vertex kernel skins from -- instead of one serial evaluation on the host
+ * per frame plus a copy of all joint matrices per draw.  A pose source is an immutable copy of a
+ * skeleton's key tracks; joints come parents first.  pose_source_create returns NULL for a skeleton the
+ * device path does not take (more than 256 joints, a parent behind its child): the caller then poses on
+ * the host as before.
+ *   graphics_draw_mesh_posed = graphics_draw_mesh with the pose (source, frame_time) in place of the
+ *   uniform block's joint_matrices / joint_n_matrices (which are ignored).  attached < 0: the mesh is
+ *   skinned with the pose.  attached >= 0: rigid node animation as in blinn_shader.c:270-283 /
+ *   pbr_shader.c:512-525 -- the uniform block's model_matrix is the model's own transform, and the draw
+ *   uses model_matrix * joint[attached] and the normal matrix derived from that product.
+ *   pose_source_evaluate hands the matrices back (count poses, num_joints matrices each): for tests. */
+typedef struct {
+    int num_joints;
+    float max_time;                     /* time wraps: fmod(frame_time, max_time), skeleton.c:316 */
+    const int *parent;                  /* [num_joints], -1 = root */
+    const rz_mat4 *inverse_bind;        /* [num_joints] */
+    const int *key_count;               /* [num_joints][3]: translation, rotation, scale keys */
+    const float *const *key_times;      /* [num_joints][3] -> key_count floats */
+    const float *const *key_values;     /* [num_joints][3] -> key_count x (3, 4 (x y z w), 3) floats */
+} rz_skeleton_desc;
+typedef struct rz_pose_source rz_pose_source;
+rz_pose_source *pose_source_create(const rz_skeleton_desc *skeleton);
+void pose_source_release(rz_pose_source *source);
+void graphics_draw_mesh_posed(rz_framebuffer *framebuffer, rz_program *program, const rz_vertex *vertices,
+                              int num_faces, rz_pose_source *source, float frame_time, int attached);
+void pose_source_evaluate(rz_pose_source *source, const float *frame_times, int count,
+                          rz_mat4 *joint_matrices, rz_mat3 *joint_n_matrices);
+
 /* Executes everything recorded so far (asynchronously, in order). */
 void graphics_flush(void);
 /* Flushes, waits, and makes color_buffer/depth_buffer of this framebuffer

@@ -69,6 +69,9 @@ class Pipeline:
         lib.rzs_scene_info.argtypes = [P, C.POINTER(C.c_int)]
         lib.rzs_scene_shadow_buffer.restype = FB
         lib.rzs_scene_shadow_buffer.argtypes = [P]
+        lib.rzs_evaluate_poses.restype = C.c_int
+        lib.rzs_evaluate_poses.argtypes = [C.c_char_p, P, C.c_int, P, P, C.c_int]
+        lib.rzs_set_device_poses.argtypes = [C.c_int]
         lib.rzs_catalogue.restype = C.c_char_p
         lib.rzs_catalogue.argtypes = [C.c_int]
         lib.mi355r_inspect_pass.argtypes = [C.POINTER(PassInfo)]
@@ -132,6 +135,18 @@ class Pipeline:
 
     def draw(self, scene, fb, view):
         self.lib.rzs_scene_draw(scene, fb, C.byref(view))
+
+    def poses(self, ani, times, on_host=False):
+        """(joint matrices [T, J, 4, 4], normal matrices [T, J, 3, 3]) of a .ani skeleton at the given times."""
+        times = np.ascontiguousarray(times, np.float32)
+        J = self.lib.rzs_evaluate_poses(ani.encode(), None, 0, None, None, 1 if on_host else 0)
+        if J < 0:
+            raise RuntimeError(f"{ani}: the pipeline does not take this skeleton")
+        joints = np.zeros((len(times), J, 4, 4), np.float32)
+        normals = np.zeros((len(times), J, 3, 3), np.float32)
+        as_p = lambda a: a.ctypes.data_as(C.c_void_p)
+        self.lib.rzs_evaluate_poses(ani.encode(), as_p(times), len(times), as_p(joints), as_p(normals), 1 if on_host else 0)
+        return joints, normals
 
     # -- framebuffers -------------------------------------------------------
     def framebuffer(self, width, height):

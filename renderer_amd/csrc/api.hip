@@ -105,7 +105,18 @@ struct Mesh {
     int num_joints;                 /* 1 + largest joint index referenced */
 };
 
+struct rz_pose_source {
+    uint32_t *d_block;              /* the skeleton on the device (kernels.h, K0) */
+    int num_joints;
+    float max_time;
+};
+
 struct Pending {
+    /* pose evaluated on the device (graphics_draw_mesh_posed): source, wrapped time, attached joint or -1 */
+    rz_pose_source *pose = nullptr;
+    float pose_time = 0;
+    int pose_attached = -1;
+    size_t pose_job = 0;            /* its job of the flush (graphics_flush) */
     Fb *fb;
     rz_program *program;
     DrawRec rec;                    /* joints / vertices patched at flush */
@@ -193,6 +204,10 @@ struct Context {
     std::unordered_map<const void*, DevTex*> cubes;     /* rz_cubemap* -> DevTex[6] */
     std::unordered_map<const void*, DevIbl*> ibls;      /* rz_ibldata* -> DevIbl */
     std::unordered_map<const void*, bool> ibl_narrow;   /* ... and whether all its images have 4-byte formats */
+    std::unordered_set<rz_pose_source*> pose_sources;
+    /* joint and normal matrices of the poses a flush evaluates on the device; two pools taken in turn, so
+     * that the flush in flight keeps its poses while the next one is put together */
+    DevBuf<char> pose_pool[2];
     struct Registered { void *vs, *fs; int family; };
     std::vector<Registered> families;
     /* measurement */
@@ -914,6 +929,7 @@ static void copy_floats(float *dst, const void *src, int n) { memcpy(dst, src, s
 
 /* uniform block (host layout, host pointers) -> DrawRec (device form) */
 static void snapshot_uniforms_once(rz_program *p, Pending &pd, int num_joints);
+static bool g_ignore_host_joints = false;   /* while graphics_draw_mesh_posed takes its snapshot */
 
 /* Resolving a texture can upload it, and an upload flushes what is recorded -- recorded
  * framebuffer copies included, which changes how a texture resolved a moment ago has to be waited
@@ -1019,7 +1035,7 @@ static void snapshot_uniforms_once(rz_program *p, Pending &pd, int num_joints) {
     /* joint matrices are rewritten in place by the skeleton every frame
      * (skeleton.c:336-337): copy them now */
     pd.num_joints = 0;
-    if (joints) {
+    if (joints && !g_ignore_host_joints) {
         if (!joint_normals && !(r.flags & RZ_DRAW_SHADOW_PASS)) fatal("joint matrices without joint normal matrices");
         pd.num_joints = num_joints;
         r.flags |= RZ_DRAW_SKINNED;
@@ -1046,6 +1062,87 @@ extern "C" void graphics_draw_mesh(rz_framebuffer *fp, rz_program *program, cons
     pd.rec.vertices = m.d_vertices;
     pd.rec.num_faces = num_faces;
     g.pending.push_back(std::move(pd));
+}
+
+/* ----------------------------------------------------- poses on the device -- */
+
+extern "C" rz_pose_source *pose_source_create(const rz_skeleton_desc *sk) {
+    ensure_ready();
+    const int J = sk->num_joints;
+    if (J <= 0) fatal("pose_source_create: %d joints", J);
+    if (J > RZ_POSE_MAX_JOINTS) return nullptr;
+    for (int j = 0; j < J; j++) if (sk->parent[j] >= j) return nullptr;     /* the kernel walks joints in index order */
+    std::vector<uint32_t> block(4 + (size_t)J + 16 * (size_t)J + 4 * 3 * (size_t)J, 0u);
+    block[0] = (uint32_t)J;
+    memcpy(&block[4], sk->parent, sizeof(int) * J);
+    memcpy(&block[4 + J], sk->inverse_bind, sizeof(rz_mat4) * J);
+    const size_t tracks_at = 4 + (size_t)J + 16 * (size_t)J;
+    for (int j = 0; j < J; j++)
+        for (int k = 0; k < 3; k++) {
+            const int count = sk->key_count[3 * j + k], width = k == 1 ? 4 : 3;
+            if (count < 0) fatal("pose_source_create: joint %d has %d keys", j, count);
+            PoseTrack t;
+            t.count = count;
+            t.ascending = count > 0;
+            const float *times = sk->key_times[3 * j + k];
+            for (int i = 1; i < count; i++) if (!(times[i - 1] < times[i])) t.ascending = 0;
+            t.times_at = (uint32_t)block.size();
+            block.insert(block.end(), (const uint32_t*)times, (const uint32_t*)times + count);
+            t.values_at = (uint32_t)block.size();
+            const float *values = sk->key_values[3 * j + k];
+            block.insert(block.end(), (const uint32_t*)values, (const uint32_t*)values + (size_t)count * width);
+            memcpy(&block[tracks_at + 4 * (3 * (size_t)j + k)], &t, sizeof t);
+        }
+    rz_pose_source *src = new rz_pose_source();
+    src->num_joints = J;
+    src->max_time = sk->max_time;
+    HIP_OK(hipMalloc((void**)&src->d_block, block.size() * sizeof(uint32_t)));
+    HIP_OK(hipMemcpy(src->d_block, block.data(), block.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    g.pose_sources.insert(src);
+    return src;
+}
+
+static rz_pose_source *as_pose_source(rz_pose_source *src) {
+    if (!src || !g.pose_sources.count(src)) fatal("pose source %p was not created by this library", (void*)src);
+    return src;
+}
+
+extern "C" void pose_source_release(rz_pose_source *src) {
+    as_pose_source(src);
+    graphics_flush();
+    sync_stream();
+    HIP_OK(hipFree(src->d_block));
+    g.pose_sources.erase(src);
+    delete src;
+}
+
+/* skeleton.c:316 */
+static float wrapped_time(const rz_pose_source *src, float frame_time) { return (float)fmod(frame_time, src->max_time); }
+
+extern "C" void pose_source_evaluate(rz_pose_source *src, const float *frame_times, int count, rz_mat4 *joints, rz_mat3 *normals) {
+    as_pose_source(src);
+    if (count <= 0) return;
+    const size_t J = (size_t)src->num_joints;
+    float *d_joints, *d_normals;
+    PoseJob *d_jobs;
+    HIP_OK(hipMalloc((void**)&d_joints, sizeof(rz_mat4) * J * count));
+    HIP_OK(hipMalloc((void**)&d_normals, sizeof(rz_mat3) * J * count));
+    HIP_OK(hipMalloc((void**)&d_jobs, sizeof(PoseJob) * count));
+    std::vector<PoseJob> jobs((size_t)count);
+    for (int i = 0; i < count; i++) {
+        jobs[i].skeleton = src->d_block;
+        jobs[i].time = wrapped_time(src, frame_times[i]);
+        jobs[i].pad = 0;
+        jobs[i].joints = d_joints + (size_t)i * J * 16;
+        jobs[i].normals = d_normals + (size_t)i * J * 9;
+    }
+    HIP_OK(hipMemcpyAsync(d_jobs, jobs.data(), sizeof(PoseJob) * count, hipMemcpyHostToDevice, g.stream));
+    rz_pose_kernel<<<dim3((unsigned)count), dim3(64), 0, g.stream>>>(d_jobs);
+    HIP_OK(hipGetLastError());
+    if (joints) HIP_OK(hipMemcpyAsync(joints, d_joints, sizeof(rz_mat4) * J * count, hipMemcpyDeviceToHost, g.stream));
+    if (normals) HIP_OK(hipMemcpyAsync(normals, d_normals, sizeof(rz_mat3) * J * count, hipMemcpyDeviceToHost, g.stream));
+    HIP_OK(hipStreamSynchronize(g.stream));
+    HIP_OK(hipFree(d_joints)); HIP_OK(hipFree(d_normals)); HIP_OK(hipFree(d_jobs));
 }
 
 /* the joint matrices a program's uniform block points at right now (nullptr: not skinned) */
@@ -1088,6 +1185,32 @@ static bool same_pose(const rz_program *p, Pending &last, int need) {
         last.num_joints = need;
     }
     return true;
+}
+
+extern "C" void graphics_draw_mesh_posed(rz_framebuffer *fp, rz_program *program, const rz_vertex *vertices, int num_faces,
+                                         rz_pose_source *source, float frame_time, int attached) {
+    Fb *fb = as_fb(fp);
+    as_pose_source(source);
+    if (program->family == RZ_FAMILY_SKYBOX) fatal("graphics_draw_mesh_posed: the skybox family has no skeleton");
+    if (attached >= source->num_joints) fatal("graphics_draw_mesh_posed: attached to joint %d of %d", attached, source->num_joints);
+    if (num_faces <= 0) return;
+    Pending pd;
+    pd.fb = fb;
+    pd.program = program;
+    pd.transient = false;
+    g_ignore_host_joints = true;
+    snapshot_uniforms(program, pd, 0);
+    g_ignore_host_joints = false;
+    Mesh &m = device_mesh(vertices, num_faces);
+    if (attached < 0 && m.num_joints > source->num_joints)
+        fatal("graphics_draw_mesh_posed: the mesh refers to joint %d, the skeleton has %d", m.num_joints - 1, source->num_joints);
+    pd.rec.vertices = m.d_vertices;
+    pd.rec.num_faces = num_faces;
+    pd.pose = source;
+    pd.pose_time = wrapped_time(source, frame_time);
+    pd.pose_attached = attached;
+    if (attached < 0) pd.rec.flags |= RZ_DRAW_SKINNED;
+    g.pending.push_back(std::move(pd));
 }
 
 /* graphics.c:537: one triangle from the program's three attribute blocks.
@@ -1215,6 +1338,11 @@ static void plan_pass(PassPlan &pl, size_t &total) {
     }
 }
 
+/* where the flush being put together keeps its device-evaluated poses (graphics_flush) */
+static char *g_pose_pool = nullptr;
+static std::vector<size_t> g_pose_offsets;          /* per pose job: its matrices in the pool */
+static size_t g_attach_jobs_at = 0, g_attach_jobs_filled = 0;
+
 static void fill_pass(const PassPlan &pl, char *hb, char *db) {
     const size_t D = pl.last - pl.first;
     uint32_t *first_tri = (uint32_t*)(hb + pl.off_first);
@@ -1233,6 +1361,18 @@ static void fill_pass(const PassPlan &pl, char *hb, char *db) {
         if (pd.transient) {
             memcpy(hb + pl.verts_at[i], pd.verts.data(), pd.verts.size() * sizeof(rz_vertex));
             rec.vertices = db + pl.verts_at[i];
+        }
+        if (pd.pose) {
+            char *matrices = g_pose_pool + g_pose_offsets[pd.pose_job];
+            if (pd.pose_attached < 0) {
+                rec.joints = (const float*)matrices;
+                rec.joint_normals = (rec.flags & RZ_DRAW_SHADOW_PASS) ? nullptr : (const float*)(matrices + sizeof(rz_mat4) * pd.pose->num_joints);
+            } else {
+                AttachJob job;
+                job.draw = (DrawRec*)(db + pl.off_draws + sizeof(DrawRec) * i);
+                job.joint = (const float*)matrices + 16 * (size_t)pd.pose_attached;
+                memcpy(hb + g_attach_jobs_at + sizeof(AttachJob) * g_attach_jobs_filled++, &job, sizeof job);
+            }
         }
         memcpy(hb + pl.off_draws + sizeof(DrawRec) * i, &rec, sizeof rec);
         first_tri[i] = running;
@@ -1262,6 +1402,8 @@ struct FlushRecord {
     std::vector<Batch> batches;
     struct Copy { Tex *tex; Fb *fb; bool depth; size_t producer; };     /* producer: the plan whose pass rendered the source */
     std::vector<Copy> copies;
+    /* poses evaluated on the device for this flush: jobs (PoseJob[]) and attach jobs (AttachJob[]) in the region */
+    size_t pose_jobs_at = 0, pose_jobs = 0, attach_jobs_at = 0, attach_jobs = 0;
     bool used[MAX_LANES] = {false};
     const uint32_t *control(size_t plan) const { return (const uint32_t*)(g.ring_host + at + CONTROL_BYTES * plans[plan].slot); }
     uint32_t *control_dev(size_t plan) const { return (uint32_t*)(g.ring_dev + at + CONTROL_BYTES * plans[plan].slot); }
@@ -1848,6 +1990,57 @@ extern "C" void graphics_flush(void) {
     fr.again_at = total;
     total += sizeof(PassParams) * plans.size();
     for (auto &pl : plans) plan_pass(pl, total);
+    /* poses to evaluate on the device: one job per (source, time) of the flush, whatever the number of
+     * draws, passes and models that share it */
+    std::vector<PoseJob> pose_jobs;
+    {
+        std::unordered_map<unsigned long long, size_t> seen[1];
+        std::vector<std::pair<rz_pose_source*, size_t>> by_source;      /* small: a scene has a skeleton or two */
+        std::vector<size_t> job_joints;
+        g_pose_offsets.clear();
+        size_t pool_bytes = 0;
+        for (auto &pd : g.pending) {
+            if (!pd.pose) continue;
+            uint32_t bits;
+            memcpy(&bits, &pd.pose_time, sizeof bits);
+            size_t source_index = 0;
+            while (source_index < by_source.size() && by_source[source_index].first != pd.pose) source_index++;
+            if (source_index == by_source.size()) by_source.push_back({pd.pose, source_index});
+            const unsigned long long key = ((unsigned long long)source_index << 32) | bits;
+            auto found = seen[0].find(key);
+            if (found == seen[0].end()) {
+                found = seen[0].emplace(key, pose_jobs.size()).first;
+                PoseJob job;
+                memset(&job, 0, sizeof job);
+                job.skeleton = pd.pose->d_block;
+                job.time = pd.pose_time;
+                pose_jobs.push_back(job);
+                job_joints.push_back((size_t)pd.pose->num_joints);
+                g_pose_offsets.push_back(pool_bytes);
+                pool_bytes += ((sizeof(rz_mat4) + sizeof(rz_mat3)) * (size_t)pd.pose->num_joints + 255) & ~(size_t)255;
+            }
+            pd.pose_job = found->second;
+            if (pd.pose_attached >= 0) fr.attach_jobs++;
+        }
+        fr.pose_jobs = pose_jobs.size();
+        total = (total + 15) & ~(size_t)15;
+        fr.pose_jobs_at = total;
+        total += sizeof(PoseJob) * fr.pose_jobs;
+        fr.attach_jobs_at = total;
+        total += sizeof(AttachJob) * fr.attach_jobs;
+        /* this flush's pool: the one the flush before the flush in flight used, long finished */
+        DevBuf<char> &pool = g.pose_pool[g.flush_epoch & 1];
+        if (pool_bytes > pool.cap) {
+            if (pool.ptr) HIP_OK(hipFree(pool.ptr));
+            pool.cap = std::max(pool_bytes, pool.cap * 2);
+            HIP_OK(hipMalloc((void**)&pool.ptr, pool.cap));
+        }
+        g_pose_pool = pool.ptr;
+        for (size_t k = 0; k < pose_jobs.size(); k++) {
+            pose_jobs[k].joints = (float*)(pool.ptr + g_pose_offsets[k]);
+            pose_jobs[k].normals = (float*)(pool.ptr + g_pose_offsets[k] + sizeof(rz_mat4) * job_joints[k]);
+        }
+    }
     prof.mark(0);
 
     /* batches and lanes */
@@ -1916,7 +2109,10 @@ extern "C" void graphics_flush(void) {
     fr.at = ring_alloc(total);
     char *hb = g.ring_host + fr.at, *db = g.ring_dev + fr.at;
     memset(hb + fr.flag_at, 0, 256);
+    g_attach_jobs_at = fr.attach_jobs_at;
+    g_attach_jobs_filled = 0;
     for (auto &pl : plans) fill_pass(pl, hb, db);
+    if (fr.pose_jobs) memcpy(hb + fr.pose_jobs_at, pose_jobs.data(), sizeof(PoseJob) * fr.pose_jobs);
     prof.mark(2);
     /* scratch first, for every batch: growing a buffer moves it, and the tables written next hold its address */
     for (auto &b : batches) prepare_batch(b, fr, true, PREPARE_FIRST);
@@ -1933,6 +2129,13 @@ extern "C" void graphics_flush(void) {
         for (auto &b : batches) prepare_batch(b, fr, true, PREPARE_REWRITE);
         for (auto &b : batches) prepare_batch(b, fr, false, PREPARE_REWRITE);
         HIP_OK(hipMemcpyAsync(db + fr.flag_at, hb + fr.flag_at, total - fr.flag_at, hipMemcpyHostToDevice, g.copy_stream));
+    }
+    /* the flush's poses, and the model matrices of draws attached to a joint, behind the upload */
+    if (fr.pose_jobs) {
+        rz_pose_kernel<<<dim3((unsigned)fr.pose_jobs), dim3(64), 0, g.copy_stream>>>((const PoseJob*)(db + fr.pose_jobs_at));
+        if (fr.attach_jobs)
+            rz_attach_kernel<<<dim3((unsigned)((fr.attach_jobs + 63) / 64)), dim3(64), 0, g.copy_stream>>>((const AttachJob*)(db + fr.attach_jobs_at), (int)fr.attach_jobs);
+        HIP_OK(hipGetLastError());
     }
     hipEvent_t uploaded = new_event(g.copy_stream);
     prof.mark(5);

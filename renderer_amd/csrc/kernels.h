@@ -148,6 +148,162 @@ __global__ void __launch_bounds__(256) rz_vertex_kernel(const PassParams *__rest
 }
 
 /* ========================================================================
+ * K0  skeletal poses (renderer/core/skeleton.c:231-341), one wave per pose
+ * ======================================================================== */
+
+/* a skeleton on the device, one block of 32-bit words:
+ *   [0] joints J, [1..3] unused, parent[J], inverse_bind[J][16], tracks[J][3] (PoseTrack), key data;
+ * a track's times and values sit at word offsets from the block's start */
+struct PoseTrack { int32_t count; int32_t ascending; uint32_t times_at; uint32_t values_at; };
+struct PoseJob { const uint32_t *skeleton; float time; int32_t pad; float *joints; float *normals; };
+struct AttachJob { DrawRec *draw; const float *joint; };
+#define RZ_POSE_MAX_JOINTS 256
+
+/* skeleton.c:231-313: the first key, the last key, or the first segment [t_i, t_i+1) that holds the
+ * time with its parameter (t - t_i) / (t_i+1 - t_i); -1 / -2 = clamped to an end.  Key times that
+ * ascend strictly (checked when the skeleton is uploaded) are searched by bisection, which finds
+ * that same segment. */
+RZ_DEV int pose_segment(const PoseTrack &t, const float *times, float time, float *param) {
+    if (time <= times[0]) return -1;
+    if (time >= times[t.count - 1]) return -2;
+    if (t.ascending) {
+        int lo = 0, hi = t.count - 1;                       /* times[lo] <= time < times[hi] */
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) / 2;
+            if (time >= times[mid]) lo = mid; else hi = mid;
+        }
+        *param = (time - times[lo]) / (times[lo + 1] - times[lo]);
+        return lo;
+    }
+    for (int i = 0; i < t.count - 1; i++) {
+        const float a = times[i], b = times[i + 1];
+        if (time >= a && time < b) { *param = (time - a) / (b - a); return i; }
+    }
+    return -2;                                              /* not reached for a well-formed track */
+}
+
+RZ_DEV f3 pose_vec3(const PoseTrack &t, const uint32_t *block, float time, f3 fallback) {
+    if (t.count == 0) return fallback;
+    const float *times = (const float*)block + t.times_at, *v = (const float*)block + t.values_at;
+    float u = 0;
+    const int s = pose_segment(t, times, time, &u);
+    if (s == -1) return mk3(v[0], v[1], v[2]);
+    if (s == -2) { v += (size_t)(t.count - 1) * 3; return mk3(v[0], v[1], v[2]); }
+    v += (size_t)s * 3;
+    return mk3(d_mix(v[0], v[3], u), d_mix(v[1], v[4], u), d_mix(v[2], v[5], u));     /* vec3_lerp */
+}
+
+/* quat_slerp (maths.c:291-318): acos and sin in double, narrowed, as the C library calls there are */
+RZ_DEV f4 pose_quat(const PoseTrack &t, const uint32_t *block, float time) {
+    if (t.count == 0) return mk4(0, 0, 0, 1);
+    const float *times = (const float*)block + t.times_at, *v = (const float*)block + t.values_at;
+    float u = 0;
+    const int s = pose_segment(t, times, time, &u);
+    if (s == -1) return mk4(v[0], v[1], v[2], v[3]);
+    if (s == -2) { v += (size_t)(t.count - 1) * 4; return mk4(v[0], v[1], v[2], v[3]); }
+    v += (size_t)s * 4;
+    const f4 a = mk4(v[0], v[1], v[2], v[3]);
+    f4 b = mk4(v[4], v[5], v[6], v[7]);
+    float cosv = a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
+    if (cosv < 0) { b = mk4(-b.x, -b.y, -b.z, -b.w); cosv = -cosv; }
+    if (cosv > 1 - RZ_EPS) return mk4(d_mix(a.x, b.x, u), d_mix(a.y, b.y, u), d_mix(a.z, b.z, u), d_mix(a.w, b.w, u));
+    const float angle = (float)acos((double)cosv);
+    const float sinv = (float)sin((double)angle);
+    const float fa = (float)sin((double)((1 - u) * angle)) / sinv;
+    const float fb = (float)sin((double)(u * angle)) / sinv;
+    return mk4(fa * a.x + fb * b.x, fa * a.y + fb * b.y, fa * a.z + fb * b.z, fa * a.w + fb * b.w);
+}
+
+/* mat3_inverse_transpose (maths.c:432-467): adjugate over determinant, cofactor signs as there */
+RZ_DEV void inverse_transpose3(const float *m, float *out) {
+    float adj[9];
+    adj[0] = +(m[4] * m[8] - m[7] * m[5]);
+    adj[1] = -(m[3] * m[8] - m[6] * m[5]);
+    adj[2] = +(m[3] * m[7] - m[6] * m[4]);
+    adj[3] = -(m[1] * m[8] - m[7] * m[2]);
+    adj[4] = +(m[0] * m[8] - m[6] * m[2]);
+    adj[5] = -(m[0] * m[7] - m[6] * m[1]);
+    adj[6] = +(m[1] * m[5] - m[4] * m[2]);
+    adj[7] = -(m[0] * m[5] - m[3] * m[2]);
+    adj[8] = +(m[0] * m[4] - m[3] * m[1]);
+    const float a = +m[0] * (m[4] * m[8] - m[5] * m[7]);
+    const float b = -m[1] * (m[3] * m[8] - m[5] * m[6]);
+    const float c = +m[2] * (m[3] * m[7] - m[4] * m[6]);
+    const float det = a + b + c;
+    const float inv = 1 / det;
+    for (int k = 0; k < 9; k++) out[k] = adj[k] * inv;
+}
+
+__global__ void __launch_bounds__(64) rz_pose_kernel(const PoseJob *__restrict__ jobs) {
+    const PoseJob job = jobs[blockIdx.x];
+    __shared__ float s_world[RZ_POSE_MAX_JOINTS][16];
+    const uint32_t *block = job.skeleton;
+    const int J = (int)block[0];
+    const int *parent = (const int*)(block + 4);
+    const float *bind = (const float*)(block + 4 + J);
+    const PoseTrack *tracks = (const PoseTrack*)(block + 4 + J + 16 * J);
+    const int lane = threadIdx.x;
+    /* every joint's own transform, mat4_from_trs (maths.c:519): T * (R * S) as full products */
+    for (int j = lane; j < J; j += 64) {
+        const f3 t = pose_vec3(tracks[3 * j], block, job.time, mk3(0, 0, 0));
+        const f4 q = pose_quat(tracks[3 * j + 1], block, job.time);
+        const f3 s = pose_vec3(tracks[3 * j + 2], block, job.time, mk3(1, 1, 1));
+        const float xx = q.x * q.x, xy = q.x * q.y, xz = q.x * q.z, xw = q.x * q.w;
+        const float yy = q.y * q.y, yz = q.y * q.z, yw = q.y * q.w, zz = q.z * q.z, zw = q.z * q.w;
+        const float rm[16] = {1 - 2 * (yy + zz), 2 * (xy - zw), 2 * (xz + yw), 0,
+                              2 * (xy + zw), 1 - 2 * (xx + zz), 2 * (yz - xw), 0,
+                              2 * (xz - yw), 2 * (yz + xw), 1 - 2 * (xx + yy), 0,
+                              0, 0, 0, 1};                                          /* maths.c:492 */
+        const float sm[16] = {s.x, 0, 0, 0, 0, s.y, 0, 0, 0, 0, s.z, 0, 0, 0, 0, 1};
+        const float tm[16] = {1, 0, 0, t.x, 0, 1, 0, t.y, 0, 0, 1, t.z, 0, 0, 0, 1};
+        float rs[16], local[16];
+        mat_mul<4>(rm, sm, rs);
+        mat_mul<4>(tm, rs, local);
+        for (int k = 0; k < 16; k++) s_world[j][k] = local[k];
+    }
+    __syncthreads();
+    /* joint-to-model: parent's * own, joints in index order (a parent comes before its children), sixteen
+     * lanes one element each */
+    for (int j = 0; j < J; j++) {
+        const int p = parent[j];
+        if (p < 0) continue;                                /* uniform */
+        float acc = 0;
+        if (lane < 16) {
+            const int r = lane >> 2, c = lane & 3;
+            for (int k = 0; k < 4; k++) acc += s_world[p][r * 4 + k] * s_world[j][k * 4 + c];
+        }
+        __syncthreads();
+        if (lane < 16) s_world[j][lane] = acc;
+        __syncthreads();
+    }
+    /* joint matrix = joint-to-model * inverse bind; normal matrix = its upper 3x3, inverse-transposed */
+    for (int j = lane; j < J; j += 64) {
+        float world[16], ib[16], jm[16], n3[9], nm[9];
+        for (int k = 0; k < 16; k++) { world[k] = s_world[j][k]; ib[k] = bind[(size_t)j * 16 + k]; }
+        mat_mul<4>(world, ib, jm);
+        for (int k = 0; k < 16; k++) job.joints[(size_t)j * 16 + k] = jm[k];
+        for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) n3[r * 3 + c] = jm[r * 4 + c];
+        inverse_transpose3(n3, nm);
+        for (int k = 0; k < 9; k++) job.normals[(size_t)j * 9 + k] = nm[k];
+    }
+}
+
+/* rigid node animation (blinn_shader.c:270-283, pbr_shader.c:512-525): the draw's model matrix becomes
+ * model * joint[attached], its normal matrix the inverse transpose of that product's upper 3x3 */
+__global__ void __launch_bounds__(64) rz_attach_kernel(const AttachJob *__restrict__ jobs, int count) {
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= count) return;
+    DrawRec *D = jobs[i].draw;
+    float model[16], joint[16], out[16], n3[9], nm[9];
+    for (int k = 0; k < 16; k++) { model[k] = D->model[k]; joint[k] = jobs[i].joint[k]; }
+    mat_mul<4>(model, joint, out);
+    for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) n3[r * 3 + c] = out[r * 4 + c];
+    inverse_transpose3(n3, nm);
+    for (int k = 0; k < 16; k++) D->model[k] = out[k];
+    for (int k = 0; k < 9; k++) D->normal[k] = nm[k];
+}
+
+/* ========================================================================
  * K2  triangle setup: clip (graphics.c:161-313), fan + cull (:584-607,
  *     :324-332, :494), viewport (:338-343), bounding box (:355-364)
  * ======================================================================== */

@@ -445,6 +445,9 @@ struct rzh_skeleton {
     rz_mat4 *joint_matrices;
     rz_mat3 *normal_matrices;
     float cached_time;
+    /* the same key tracks handed to the pipeline for evaluation on the device (rzh_skeleton_pose_source) */
+    rz_pose_source *pose_source;
+    int pose_source_asked;
 };
 
 static void read_track(FILE *f, const char *label, int width, track_t *t, const char *filename) {
@@ -500,12 +503,48 @@ rzh_skeleton *rzh_skeleton_load(const char *filename) {
     memset(sk->joint_matrices, 0, sizeof(rz_mat4) * sk->num_joints);
     memset(sk->normal_matrices, 0, sizeof(rz_mat3) * sk->num_joints);
     sk->cached_time = -1;
+    sk->pose_source = NULL;
+    sk->pose_source_asked = 0;
     return sk;
+}
+
+/* The skeleton as the flat description pose_source_create takes; created on first use, NULL when the
+ * pipeline does not take this skeleton (the caller then poses it here, rzh_skeleton_update). */
+rz_pose_source *rzh_skeleton_pose_source(rzh_skeleton *sk) {
+    rz_skeleton_desc d;
+    int *parent, *counts, i, k;
+    rz_mat4 *bind;
+    const float **times, **values;
+    if (sk->pose_source_asked) return sk->pose_source;
+    sk->pose_source_asked = 1;
+    parent = (int*)xmalloc(sizeof(int) * sk->num_joints);
+    bind = (rz_mat4*)xmalloc(sizeof(rz_mat4) * sk->num_joints);
+    counts = (int*)xmalloc(sizeof(int) * 3 * sk->num_joints);
+    times = (const float**)xmalloc(sizeof(float*) * 3 * sk->num_joints);
+    values = (const float**)xmalloc(sizeof(float*) * 3 * sk->num_joints);
+    for (i = 0; i < sk->num_joints; i++) {
+        const track_t *tracks[3];
+        tracks[0] = &sk->joints[i].translation; tracks[1] = &sk->joints[i].rotation; tracks[2] = &sk->joints[i].scale;
+        parent[i] = sk->joints[i].parent;
+        bind[i] = sk->joints[i].inverse_bind;
+        for (k = 0; k < 3; k++) {
+            counts[3 * i + k] = tracks[k]->count;
+            times[3 * i + k] = tracks[k]->times;
+            values[3 * i + k] = tracks[k]->values;
+        }
+    }
+    d.num_joints = sk->num_joints;
+    d.max_time = sk->max_time;
+    d.parent = parent; d.inverse_bind = bind; d.key_count = counts; d.key_times = times; d.key_values = values;
+    sk->pose_source = pose_source_create(&d);
+    free(parent); free(bind); free(counts); free((void*)times); free((void*)values);
+    return sk->pose_source;
 }
 
 void rzh_skeleton_free(rzh_skeleton *sk) {
     int i;
     if (!sk) return;
+    if (sk->pose_source) pose_source_release(sk->pose_source);
     for (i = 0; i < sk->num_joints; i++) {
         joint_t *j = &sk->joints[i];
         free(j->translation.times); free(j->translation.values);

@@ -44,6 +44,8 @@ void rzh_skeleton_update(rzh_skeleton *skeleton, float frame_time);
 rz_mat4 *rzh_skeleton_joint_matrices(rzh_skeleton *skeleton);
 rz_mat3 *rzh_skeleton_normal_matrices(rzh_skeleton *skeleton);
 int rzh_skeleton_num_joints(rzh_skeleton *skeleton);
+/* the skeleton's key tracks as a pose source of the pipeline (include/mi355r.h); NULL if it does not take them */
+rz_pose_source *rzh_skeleton_pose_source(rzh_skeleton *skeleton);
 /* off: find key segments by the reference's linear scan (skeleton.c:231-313) even where bisection applies; for tests */
 void rzh_skeleton_use_bisection(rzh_skeleton *skeleton, int on);
 

@@ -53,6 +53,9 @@ typedef struct {                /* renderer/core/scene.h:25-40 */
     int attached;
     int opaque;
     float distance;
+    /* this frame's pose is evaluated by the pipeline (graphics_draw_mesh_posed) at this time */
+    int posed;
+    float pose_time;
 } model_t;
 
 #define RZS_SHADOW_RING 32
@@ -77,12 +80,23 @@ struct rzs_scene {              /* renderer/core/scene.h:42-52 */
 /* blinn_shader.c:264-304 and pbr_shader.c:506-547 share this prologue: the
  * skeleton is advanced to the frame time; a node-attached model folds its
  * node matrix into the model matrix and is NOT skinned. */
+static int g_per_triangle = 0;
+static int g_device_poses = 1;
+
+void rzs_set_device_poses(int on) { g_device_poses = on; }
+
 static void model_frame_matrices(model_t *m, const frame_t *f, rz_mat4 *model_matrix,
                                  rz_mat3 *normal_matrix, rz_mat4 **joints, rz_mat3 **joint_normals) {
     *model_matrix = m->transform;
     *joints = NULL;
     *joint_normals = NULL;
-    if (m->skeleton) {
+    m->posed = 0;
+    if (m->skeleton && g_device_poses && !g_per_triangle && rzh_skeleton_pose_source(m->skeleton)) {
+        /* the pipeline evaluates the pose and, for a node-attached model, folds the node's matrix into
+         * the model matrix and derives the normal matrix (graphics_draw_mesh_posed) */
+        m->posed = 1;
+        m->pose_time = f->frame_time;
+    } else if (m->skeleton) {
         rzh_skeleton_update(m->skeleton, f->frame_time);
         *joints = rzh_skeleton_joint_matrices(m->skeleton);
         *joint_normals = rzh_skeleton_normal_matrices(m->skeleton);
@@ -129,8 +143,6 @@ static void model_update(model_t *m, const frame_t *f) {
 
 /* blinn_shader.c:306-342, pbr_shader.c:549-578, skybox_shader.c:47-66: one
  * triangle per face in mesh order; the skybox takes no part in shadow passes */
-static int g_per_triangle = 0;
-
 void rzs_set_per_triangle(int on) { g_per_triangle = on; }
 
 static void model_draw(model_t *m, rz_framebuffer *fb, int shadow_pass) {
@@ -141,7 +153,10 @@ static void model_draw(model_t *m, rz_framebuffer *fb, int shadow_pass) {
     } else {
         ((rz_pbr_uniforms*)program_get_uniforms(m->program))->shadow_pass = shadow_pass;
     }
-    if (!g_per_triangle) {
+    if (m->posed) {
+        graphics_draw_mesh_posed(fb, m->program, m->mesh->vertices, m->mesh->num_faces,
+                                 rzh_skeleton_pose_source(m->skeleton), m->pose_time, m->attached);
+    } else if (!g_per_triangle) {
         graphics_draw_mesh(fb, m->program, m->mesh->vertices, m->mesh->num_faces);
     } else {
         /* the reference's own loop: three attribute blocks filled per face,
@@ -587,6 +602,27 @@ void rzs_scene_info(rzs_scene *scene, int out[8]) {
 }
 
 rz_framebuffer *rzs_scene_shadow_buffer(rzs_scene *scene) { return scene->shadow_buffer; }
+
+/* Joint and normal matrices of `count` poses of a .ani skeleton, for tests: through the pipeline's pose
+ * source (on_host == 0) or this layer's own per-frame evaluation (rzh_skeleton_update).  Returns the
+ * number of joints (also with count == 0), -1 when the pipeline does not take the skeleton. */
+int rzs_evaluate_poses(const char *ani, const float *times, int count, float *joints, float *normals, int on_host) {
+    rzh_skeleton *sk = rzh_acquire_skeleton(ani);
+    int J = rzh_skeleton_num_joints(sk), i;
+    if (!on_host) {
+        rz_pose_source *src = rzh_skeleton_pose_source(sk);
+        if (!src) J = -1;
+        else if (count > 0) pose_source_evaluate(src, times, count, (rz_mat4*)joints, (rz_mat3*)normals);
+    } else {
+        for (i = 0; i < count; i++) {
+            rzh_skeleton_update(sk, times[i]);
+            memcpy(joints + (size_t)i * J * 16, rzh_skeleton_joint_matrices(sk), sizeof(rz_mat4) * J);
+            memcpy(normals + (size_t)i * J * 9, rzh_skeleton_normal_matrices(sk), sizeof(rz_mat3) * J);
+        }
+    }
+    rzh_release_skeleton(sk);
+    return J;
+}
 
 /* ======================= views ========================================== */
 

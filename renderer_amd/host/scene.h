@@ -47,9 +47,15 @@ void rzs_orbit_view(rzs_view *view, int index, int count);
  * graphics_draw_mesh; 1 the reference's per-face loop (fill three attribute
  * blocks, graphics_draw_triangle), e.g. pbr_shader.c:561-577. */
 void rzs_set_per_triangle(int on);
+/* Skeletal poses: 1 (default) evaluated by the pipeline (graphics_draw_mesh_posed; not in per-triangle
+ * mode, whose graphics_draw_triangle takes joint matrices from the uniform block), 0 on the host per
+ * frame (rzh_skeleton_update, the reference's skeleton_update_joints). */
+void rzs_set_device_poses(int on);
 void rzs_scene_draw(rzs_scene *scene, rz_framebuffer *framebuffer, const rzs_view *view);
 /* the same without clearing the framebuffer first: the frame is drawn over what is there */
 void rzs_scene_draw_no_clear(rzs_scene *scene, rz_framebuffer *framebuffer, const rzs_view *view);
+
+int rzs_evaluate_poses(const char *ani, const float *times, int count, float *joints, float *normals, int on_host);
 
 /* info: [0] models, [1] faces, [2] has skybox, [3] shadow width, [4] shadow
  * height, [5] blended models, [6] skinned models, [7] node-attached models */
