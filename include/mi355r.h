@@ -262,6 +262,14 @@ void framebuffer_sync(rz_framebuffer *framebuffer);
 /* The same for color_buffer alone: what a blit needs (renderer/core/private.c:8-28 reads nothing
  * else), half the bytes over the bus. */
 void framebuffer_sync_color(rz_framebuffer *framebuffer);
+/* Presentation: renderer/core/private.c:8-50 (private_blit_bgr / private_blit_rgb) with the flip and
+ * the channel swap done on the device.  destination is the 4-channel image of the window surface
+ * (width x height x 4 bytes, row 0 at the TOP): pixel (r, c) of the framebuffer goes to row
+ * height - 1 - r; bytes 0..2 are written (blue, green, red when swap_red_blue, else red, green, blue),
+ * byte 3 of every destination pixel is left as it is, as in the reference.  Flushes and waits for this
+ * framebuffer only.  A maintainer replaces the body of private_blit_bgr by
+ * framebuffer_blit(src, dst->ldr_buffer, 1). */
+void framebuffer_blit(rz_framebuffer *framebuffer, unsigned char *destination, int swap_red_blue);
 /* Same for a texture written by texture_from_{color,depth}buffer. */
 void texture_sync(rz_texture *texture);
 /* texture_sync for callers that cannot allocate device memory.  No counterpart in the reference (whose

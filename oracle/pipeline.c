@@ -110,6 +110,23 @@ void framebuffer_read(rz_framebuffer *fb, void *color, void *depth) {
     if (depth) memcpy(depth, fb->depth_buffer, n * sizeof(float));
 }
 
+/* private_blit_bgr / private_blit_rgb (private.c:8-50): destination row 0 is the top of the image,
+ * three bytes per pixel are written, the fourth is left alone */
+void framebuffer_blit(rz_framebuffer *fb, unsigned char *destination, int swap_red_blue) {
+    int r, c;
+    trace_close(fb);
+    for (r = 0; r < fb->height; r++) {
+        for (c = 0; c < fb->width; c++) {
+            int flipped_r = fb->height - 1 - r;
+            const unsigned char *src = &fb->color_buffer[(r * fb->width + c) * 4];
+            unsigned char *dst = &destination[(flipped_r * fb->width + c) * 4];
+            dst[0] = swap_red_blue ? src[2] : src[0];
+            dst[1] = src[1];
+            dst[2] = swap_red_blue ? src[0] : src[2];
+        }
+    }
+}
+
 /* ======================= program (graphics.c:59-141) ==================== */
 
 #define MAX_POLY 10             /* a triangle clipped by 7 planes has <= 10 corners */

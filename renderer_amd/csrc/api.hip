@@ -208,6 +208,10 @@ struct Context {
     /* joint and normal matrices of the poses a flush evaluates on the device; two pools taken in turn, so
      * that the flush in flight keeps its poses while the next one is put together */
     DevBuf<char> pose_pool[2];
+    /* framebuffer_blit: the flipped image on the device and its page-locked landing place on the host */
+    DevBuf<uint32_t> blit_staging;
+    uint32_t *blit_host = nullptr;
+    size_t blit_host_cap = 0;
     struct Registered { void *vs, *fs; int family; };
     std::vector<Registered> families;
     /* measurement */
@@ -443,6 +447,36 @@ static void read_framebuffer(Fb *fb, void *color, void *depth, hipMemcpyKind kin
     if (color) HIP_OK(hipMemcpyAsync(color, fb->d_color, n * 4, kind, st));
     if (depth) HIP_OK(hipMemcpyAsync(depth, fb->d_depth, n * sizeof(float), kind, st));
     HIP_OK(hipStreamSynchronize(st));
+}
+
+/* private.c:8-50 */
+extern "C" void framebuffer_blit(rz_framebuffer *p, unsigned char *destination, int swap_red_blue) {
+    Fb *fb = as_fb(p);
+    if (!destination) fatal("framebuffer_blit: no destination");
+    graphics_flush();
+    HIP_OK(hipStreamSynchronize(g.lanes[fb->lane < 0 ? 0 : fb->lane].stream));
+    settle_framebuffer(fb);
+    apply_pending_clear(fb);
+    const int w = fb->pub.width, h = fb->pub.height;
+    const size_t n = (size_t)w * h;
+    hipStream_t st = g.lanes[fb->lane < 0 ? 0 : fb->lane].stream;
+    reserve(g.blit_staging, n, st);
+    if (n > g.blit_host_cap) {
+        if (g.blit_host) HIP_OK(hipHostFree(g.blit_host));
+        HIP_OK(hipHostMalloc((void**)&g.blit_host, n * sizeof(uint32_t), hipHostMallocDefault));
+        g.blit_host_cap = n;
+    }
+    rz_blit_kernel<<<dim3((unsigned)((w + 63) / 64), (unsigned)h), dim3(64), 0, st>>>(fb->d_color, g.blit_staging.ptr, w, h, swap_red_blue ? 1 : 0);
+    HIP_OK(hipGetLastError());
+    HIP_OK(hipMemcpyAsync(g.blit_host, g.blit_staging.ptr, n * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    HIP_OK(hipStreamSynchronize(st));
+    /* three bytes per pixel are the blit's, the fourth stays the destination's (private.c:23-25 writes [0..2] only) */
+    for (size_t i = 0; i < n; i++) {
+        uint32_t old;
+        memcpy(&old, destination + 4 * i, 4);
+        old = (old & 0xff000000u) | g.blit_host[i];
+        memcpy(destination + 4 * i, &old, 4);
+    }
 }
 
 extern "C" void framebuffer_read(rz_framebuffer *p, void *color, void *depth) {

@@ -2144,6 +2144,16 @@ __global__ void rz_buffers_to_textures_kernel(const CopyJobs jobs) {
     }
 }
 
+/* private_blit_bgr / private_blit_rgb (private.c:8-50): vertical flip, optional red/blue swap; the
+ * fourth byte of the staged pixel is zero (the host keeps the destination's own) */
+__global__ void rz_blit_kernel(const uint32_t *__restrict__ color, uint32_t *__restrict__ staged, int w, int h, int swap) {
+    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y;
+    if (x >= w || y >= h) return;
+    const uint32_t c = color[(size_t)y * w + x];
+    const uint32_t r = c & 0xffu, g = (c >> 8) & 0xffu, b = (c >> 16) & 0xffu;
+    staged[(size_t)(h - 1 - y) * w + x] = swap ? (b | (g << 8) | (r << 16)) : (r | (g << 8) | (b << 16));
+}
+
 /* row-major float4 image -> device layout (8x8 tiles where the size allows) */
 __global__ void rz_texture_tile_kernel(const float4 *linear, float4 *texels, int w, int h, int flags, int mbits) {
     int x = blockIdx.x * 16 + (threadIdx.x & 15), y = blockIdx.y * 16 + (threadIdx.x >> 4);

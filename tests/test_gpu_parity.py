@@ -290,3 +290,33 @@ def test_gpu_framebuffer_copies_into_textures(gpu, oracle, recorded):
     assert np.array_equal(gd[..., 0], gf[1]) and np.array_equal(gd[..., 1], gf[1]) and np.array_equal(gd[..., 2], gf[1])
     assert np.all(gd[..., 3] == 1)
     assert np.array_equal(od[..., 0], of[1]) and np.array_equal(oc, of[0].astype(np.float32) / np.float32(255.0))
+
+
+@pytest.mark.parametrize("size", [(320, 180), (67, 33)])
+def test_gpu_blit_equals_the_reference_blit(gpu, oracle, size):
+    """framebuffer_blit (private.c:8-50): vertical flip, red/blue swap or not, and the destination's fourth
+    byte left alone -- against the restated host loop, on a destination filled with noise."""
+    w, h = size
+    out = []
+    for pipe in (gpu, oracle):
+        pipe.lib.framebuffer_blit.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        scene = pipe.open_scene("helmet")
+        fb = pipe.framebuffer(w, h)
+        pipe.draw(scene, fb, pipe.orbit_view(4, 16))
+        images = []
+        for swap in (1, 0):
+            dst = np.random.default_rng(5).integers(0, 256, (h, w, 4)).astype(np.uint8)
+            pipe.lib.framebuffer_blit(C.cast(fb, C.c_void_p), dst.ctypes.data_as(C.c_void_p), swap)
+            images.append(dst)
+        frame = pipe.read(fb)
+        out.append((images, frame))
+        pipe.release(fb)
+        pipe.close_scene(scene)
+    (gi, gf), (oi, of) = out
+    noise = np.random.default_rng(5).integers(0, 256, (h, w, 4)).astype(np.uint8)
+    for g, o, swap in zip(gi, oi, (1, 0)):
+        assert np.array_equal(g[..., 3], noise[..., 3])
+        order = [2, 1, 0] if swap else [0, 1, 2]
+        assert np.array_equal(g[..., :3], gf[0][::-1, :, order])       # the library's own frame, flipped
+        assert np.array_equal(o[..., :3], of[0][::-1, :, order])
+        assert (g[..., :3] != o[..., :3]).any(axis=2).sum() <= max(2, w * h * 2e-4)   # colour bar of the frames themselves
