@@ -282,7 +282,7 @@ void texture_sync(rz_texture *texture);
  * (graphics_flush) -- a recorded copy is not submitted here, because submitting sizes scratch.  One
  * staging array per GPU, shared by all calls on it: calls that overlap on one GPU race.
  * Returns RZ_NOALLOC_OK, or a negative code after a message on stderr (nothing is written then). */
-enum { RZ_NOALLOC_OK = 0, RZ_NOALLOC_TOO_LARGE = -1, RZ_NOALLOC_NOT_SUBMITTED = -2 };
+enum { RZ_NOALLOC_OK = 0, RZ_NOALLOC_TOO_LARGE = -1, RZ_NOALLOC_NOT_SUBMITTED = -2, RZ_NOALLOC_NO_HOST_IMAGE = -3 };
 int texture_sync_noalloc(rz_texture *texture);
 /* Tells the library that texture->buffer was modified by the host. */
 void texture_invalidate(rz_texture *texture);
@@ -370,6 +370,15 @@ unsigned long long mi355r_passes_run_again(void);
  * image.c:329-347) and, for a non-zero result, the packed words
  * r | g << 8 | b << 16 | a-or-e << 24 in packed[count]. */
 int mi355r_pack_texels(const rz_vec4 *texels, size_t count, unsigned int *packed);
+
+/* Ingest without the float detour (texture.c:32-128 with image.c:315-347).  A loader that has the
+ * file's bytes in hand -- 8-bit channels of a TGA, RGBE quads of a Radiance file -- already holds one of
+ * the formats above and hands the words over as they are: format 4, 8 or 16 as mi355r_pack_texels
+ * names them, words[width * height] = r | g << 8 | b << 16 | a-or-e << 24, row 0 = bottom.  The image
+ * goes to the device at once; texture->buffer stays NULL until texture_sync(texture) asks for it (the
+ * device then decodes to the very floats the reference's conversion produces).  Returns NULL when the
+ * library keeps float images only (MI355R_PACK=0): the loader then fills texture_create's buffer. */
+rz_texture *texture_create_packed(int width, int height, int format, const unsigned int *words);
 
 #ifdef __cplusplus
 }

@@ -543,6 +543,7 @@ extern "C" void texture_release(rz_texture *p) {                    /* texture.c
 
 extern "C" void texture_invalidate(rz_texture *p) {
     Tex *t = as_tex(p);
+    if (!t->pub.buffer) fatal("texture_invalidate: the texture's host image was never asked for (texture_sync), so it cannot have been modified");
     t->device_stale = true;
     t->host_stale = false;
 }
@@ -696,11 +697,44 @@ static DevTex dev_tex(rz_texture *p) {
     return d;
 }
 
+/* texture_create_packed: the image arrives in a 4-byte device format, straight from the file's bytes */
+extern "C" rz_texture *texture_create_packed(int width, int height, int format, const unsigned int *words) {
+    ensure_ready();
+    if (!g.pack_textures) return nullptr;
+    if (width <= 0 || height <= 0) fatal("texture size %dx%d", width, height);
+    if (format != RZ_TEX_UNORM8 && format != RZ_TEX_SRGB8 && format != RZ_TEX_RGBE8) fatal("texture_create_packed: format %d", format);
+    Tex *t = new Tex();
+    t->pub.width = width;
+    t->pub.height = height;
+    t->pub.buffer = nullptr;            /* made by texture_sync when somebody asks for the floats */
+    t->d_data = nullptr;
+    t->d_bytes = 0;
+    t->flags = 0;
+    t->mbits = 0;
+    t->write_lane = -1;
+    t->write_event = nullptr;
+    g.texs.insert(t);
+    const size_t n = (size_t)width * height;
+    device_image(t, format, sizeof(uint32_t));
+    uint32_t *staging;
+    HIP_OK(hipMalloc((void**)&staging, n * sizeof(uint32_t)));
+    HIP_OK(hipMemcpyAsync(staging, words, n * sizeof(uint32_t), hipMemcpyHostToDevice, g.stream));
+    rz_texture_tile32_kernel<<<dim3((width + 15) / 16, (height + 15) / 16), dim3(256), 0, g.stream>>>(
+        staging, (uint32_t*)t->d_data, width, height, t->flags);
+    HIP_OK(hipGetLastError());
+    HIP_OK(hipStreamSynchronize(g.stream));
+    HIP_OK(hipFree(staging));
+    t->device_stale = false;
+    t->host_stale = true;
+    return &t->pub;
+}
+
 extern "C" void texture_sync(rz_texture *p) {
     Tex *t = as_tex(p);
     if (!t->host_stale) return;
     int w = t->pub.width, h = t->pub.height;
     size_t bytes = (size_t)w * h * sizeof(float4);
+    if (!t->pub.buffer) t->pub.buffer = (rz_vec4*)calloc((size_t)w * h, sizeof(rz_vec4));
     graphics_flush();
     sync_stream();
     float4 *staging;
@@ -1887,9 +1921,14 @@ extern "C" int texture_sync_noalloc(rz_texture *p) {
         fprintf(stderr, "mi355r: texture_sync_noalloc: the copy into this texture is still recorded; call graphics_flush first\n");
         return RZ_NOALLOC_NOT_SUBMITTED;
     }
-    if (!t->d_data || t->write_lane < 0) fatal("texture_sync_noalloc: the texture has no device image written by the GPU");
+    if (!t->d_data) fatal("texture_sync_noalloc: the texture has no device image");
+    if (!t->pub.buffer) {
+        /* an image that came in packed (texture_create_packed) and whose floats nobody has asked for yet: texture_sync makes the host image */
+        fprintf(stderr, "mi355r: texture_sync_noalloc: the texture has no host image yet; call texture_sync once\n");
+        return RZ_NOALLOC_NO_HOST_IMAGE;
+    }
     float4 *staging = scratch_on_device(g.device);
-    hipStream_t st = g.lanes[t->write_lane].stream;             /* behind the copy that wrote the image */
+    hipStream_t st = g.lanes[t->write_lane < 0 ? 0 : t->write_lane].stream;     /* behind the copy that wrote the image */
     /* the passes of the flush in flight that fed the copy: if one of them ran out of scratch, the
      * image is not there yet and settling the flush may allocate */
     HIP_OK(hipStreamSynchronize(st));

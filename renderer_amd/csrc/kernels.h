@@ -2174,7 +2174,10 @@ __global__ void rz_texture_untile_kernel(const void *texels, float4 *linear, int
     if (x >= w || y >= h) return;
     uint32_t i = texel_index(w, flags, x, y);
     float4 v;
-    if (flags & RZ_TEX_R32F) { float d = ((const float*)texels)[i]; v = make_float4(d, d, d, 1.0f); }
+    if (flags & RZ_TEX_NARROW) {            /* one word per texel: decoded to the floats the reference's texture holds */
+        const f4 t = decode_word(flags, ((const float*)texels)[i]);
+        v = make_float4(t.x, t.y, t.z, t.w);
+    }
     else v = ((const float4*)texels)[i];
     linear[(size_t)y * w + x] = v;
 }

@@ -54,7 +54,7 @@ static rzh_image *image_new(int w, int h, int channels, int is_hdr) {
     rzh_image *im = (rzh_image*)xmalloc(sizeof *im);
     size_t n = (size_t)w * h * channels;
     im->is_hdr = is_hdr; im->width = w; im->height = h; im->channels = channels;
-    im->ldr = NULL; im->hdr = NULL;
+    im->ldr = NULL; im->hdr = NULL; im->rgbe = NULL;
     if (is_hdr) { im->hdr = (float*)xmalloc(n * sizeof(float)); memset(im->hdr, 0, n * sizeof(float)); }
     else { im->ldr = (unsigned char*)xmalloc(n); memset(im->ldr, 0, n); }
     return im;
@@ -62,7 +62,7 @@ static rzh_image *image_new(int w, int h, int channels, int is_hdr) {
 
 void rzh_image_free(rzh_image *im) {
     if (!im) return;
-    free(im->ldr); free(im->hdr); free(im);
+    free(im->ldr); free(im->hdr); free(im->rgbe); free(im);
 }
 
 /* whole file in memory: the decoders below walk a byte cursor */
@@ -198,9 +198,11 @@ static rzh_image *load_hdr(const char *filename) {
     if (!read_text_line(&c, line, RZ_LINE) || sscanf(line, "-Y %d +X %d", &h, &w) != 2 || w <= 0 || h <= 0)
         die("bad hdr resolution", filename);
     im = image_new(w, h, 3, 1);
+    im->rgbe = (unsigned char*)xmalloc((size_t)w * h * 4);
     chan = (unsigned char*)xmalloc((size_t)w * 4);
     for (i = 0; i < h; i++) {
         float *row = im->hdr + (size_t)(h - 1 - i) * w * 3;
+        unsigned char *quads = im->rgbe + (size_t)(h - 1 - i) * w * 4;
         int rle = 0;
         if (w >= 8 && w <= 0x7fff) {
             if (c.size - c.pos < 4) die("truncated hdr", filename);
@@ -231,12 +233,14 @@ static rzh_image *load_hdr(const char *filename) {
             for (x = 0; x < w; x++) {
                 unsigned char px[4];
                 for (k = 0; k < 4; k++) px[k] = chan[k * w + x];
+                memcpy(quads + x * 4, px, 4);
                 rgbe_decode(px, row + x * 3);
             }
         } else {
             for (x = 0; x < w; x++) {
                 unsigned char px[4];
                 for (k = 0; k < 4; k++) px[k] = next_byte(&c);
+                memcpy(quads + x * 4, px, 4);
                 rgbe_decode(px, row + x * 3);
             }
         }
@@ -302,10 +306,53 @@ static void fill_texture_from_image(rz_texture *tex, const rzh_image *im, rz_usa
     }
 }
 
+/* The image in one of the pipeline's 4-byte formats, straight from the file's bytes -- what
+ * fill_texture_from_image computes is then a function of those bytes alone:
+ *   8-bit file, data or LDR colour usage: channel = byte / 255.0f                          -> format 4
+ *   8-bit file, HDR colour usage: rgb = (float)pow(byte / 255.0f, 2.2), alpha = byte / 255.0f -> format 8
+ *   .hdr file, any usage but LDR colour: rgb = mantissa * 2^(e - 136) (rgbe_decode), alpha 1  -> format 16
+ * (luminance replicated, absent alpha = 255).  An .hdr file used as LDR colour is tone-mapped and has
+ * no such format.  Returns the format and the words, or 0. */
+static int packed_image(const rzh_image *im, rz_usage usage, unsigned int **words_out) {
+    size_t n = (size_t)im->width * im->height, i;
+    unsigned int *words;
+    int ch = im->channels;
+    if (im->is_hdr && (usage == RZ_USAGE_LDR_COLOR || ch != 3 || !im->rgbe)) return 0;
+    words = (unsigned int*)xmalloc(n * sizeof *words);
+    if (im->is_hdr) {
+        for (i = 0; i < n; i++) {
+            const unsigned char *q = im->rgbe + i * 4;
+            /* exponent byte 0 means black whatever the mantissas say (image.c:320-322) */
+            words[i] = q[3] == 0 ? 0u : (unsigned)q[0] | ((unsigned)q[1] << 8) | ((unsigned)q[2] << 16) | ((unsigned)q[3] << 24);
+        }
+        *words_out = words;
+        return 16;
+    }
+    for (i = 0; i < n; i++) {
+        const unsigned char *p = im->ldr + i * ch;
+        unsigned r, g, b, a = 255;
+        if (ch <= 2) { r = g = b = p[0]; if (ch == 2) a = p[1]; }
+        else { r = p[0]; g = p[1]; b = p[2]; if (ch == 4) a = p[3]; }
+        words[i] = r | (g << 8) | (b << 16) | (a << 24);
+    }
+    *words_out = words;
+    return usage == RZ_USAGE_HDR_COLOR ? 8 : 4;
+}
+
 /* texture.c:108 */
 rz_texture *texture_from_file(const char *filename, rz_usage usage) {
     rzh_image *im = rzh_image_load(filename);
-    rz_texture *tex = texture_create(im->width, im->height);
+    rz_texture *tex = NULL;
+    unsigned int *words = NULL;
+    int format = packed_image(im, usage, &words);
+    if (format) {
+        /* a pipeline that keeps such images takes the bytes as they are; one that works on floats
+         * (the CPU oracle) says no and gets the reference's float image below */
+        tex = texture_create_packed(im->width, im->height, format, words);
+        free(words);
+        if (tex) { rzh_image_free(im); return tex; }
+    }
+    tex = texture_create(im->width, im->height);
     fill_texture_from_image(tex, im, usage);
     texture_invalidate(tex);
     rzh_image_free(im);

@@ -21,6 +21,7 @@ typedef struct {
     int width, height, channels;
     unsigned char *ldr;
     float *hdr;
+    unsigned char *rgbe;        /* .hdr files: the file's own quads (mantissas + shared exponent), width * height * 4, same row order as hdr */
 } rzh_image;
 
 rzh_image *rzh_image_load(const char *filename);    /* .tga or .hdr */

@@ -143,3 +143,40 @@ def test_gpu_alternative_code_paths_give_the_same_frames(gpu, env):
     r = subprocess.run([sys.executable, "-c", VARIANT_SCRIPT % (REPO, os.path.join(REPO, "tests"))],
                        env=dict(os.environ, **env), capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "DIFFS 0" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+def test_gpu_images_ingested_from_file_bytes_decode_to_the_reference_floats(gpu, oracle):
+    """texture_from_file on the GPU library hands the file's bytes to the device as they are
+    (texture_create_packed) and never builds the float image; texture_sync then asks the device to decode
+    it.  Those floats must be, bit for bit, what the reference's conversion (texture.c:32-128) produces
+    from the same file, which the oracle's loader computes on the host: 8-bit data, colour and
+    single-channel maps, Radiance maps, and a tone-mapped sky face (which has no packed form)."""
+    class Texture(C.Structure):
+        _fields_ = [("width", C.c_int), ("height", C.c_int), ("buffer", C.POINTER(C.c_float))]
+    T = C.POINTER(Texture)
+    cases = [("helmet/helmet_basecolor.tga", 2), ("helmet/helmet_metalness.tga", 1), ("helmet/helmet_normal.tga", 1),
+             ("helmet/helmet_emission.tga", 2), ("common/brdf_lut.hdr", 3), ("workshop/i_px.hdr", 2), ("workshop/m0_py.hdr", 2),
+             ("workshop/m1_nz.hdr", 0), ("azura/hair_diffuse.tga", 0), ("azura/body_diffuse.tga", 0), ("helmet/helmet_occlusion.tga", 1)]
+    import os
+    from renderer_amd.binding import ASSETS
+    images = {}
+    for pipe in (gpu, oracle):
+        lib = pipe.lib
+        lib.texture_from_file.restype = T
+        lib.texture_from_file.argtypes = [C.c_char_p, C.c_int]
+        lib.texture_release.argtypes = [T]
+        lib.texture_sync.argtypes = [T]
+        for name, usage in cases:
+            if not os.path.exists(os.path.join(ASSETS, name)):
+                continue
+            tex = lib.texture_from_file(name.encode(), usage)
+            if pipe is gpu and (usage != 0 or name.endswith(".tga")):
+                assert not tex.contents.buffer            # no float image until somebody asks
+            lib.texture_sync(tex)
+            n = tex.contents.width * tex.contents.height
+            images.setdefault((name, usage), []).append(np.ctypeslib.as_array(tex.contents.buffer, (n, 4)).copy())
+            lib.texture_release(tex)
+    assert len(images) >= 8
+    for key, (got, want) in images.items():
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), key
