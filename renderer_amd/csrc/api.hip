@@ -504,8 +504,11 @@ static int log2_exact(int v) {
 
 static void choose_layout(int w, int h, int *flags, int *mbits) {
     *mbits = 0;
-    if (w % 8 == 0 && h % 8 == 0) *flags |= RZ_TEX_TILED;
-    else *flags &= ~RZ_TEX_TILED;
+    static const int layout = getenv("MI355R_TEX_LAYOUT") ? atoi(getenv("MI355R_TEX_LAYOUT")) : 0;
+    *flags &= ~RZ_TEX_LAYOUT;
+    if (layout == 1 && w % 16 == 0 && h % 16 == 0) *flags |= RZ_TEX_TILE16;
+    else if (layout == 2 && w % 8 == 0 && h % 8 == 0) *flags |= RZ_TEX_MORTON;
+    else if (w % 8 == 0 && h % 8 == 0) *flags |= RZ_TEX_TILED;
 }
 
 static void drop_derived_handles();

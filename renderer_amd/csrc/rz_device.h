@@ -43,7 +43,11 @@ enum { RZ_FMT_RGBA32F = 0, RZ_FMT_R32F = 1 };
  *           alpha = byte / 255.0f
  *   RGBE8   3 mantissa bytes + shared exponent byte e,         Radiance .hdr maps
  *           rgb = (float)mantissa * 2^(e - 136), alpha = 1 */
-enum { RZ_TEX_TILED = 1, RZ_TEX_R32F = 2, RZ_TEX_UNORM8 = 4, RZ_TEX_SRGB8 = 8, RZ_TEX_RGBE8 = 16 };
+enum { RZ_TEX_TILED = 1, RZ_TEX_R32F = 2, RZ_TEX_UNORM8 = 4, RZ_TEX_SRGB8 = 8, RZ_TEX_RGBE8 = 16,
+       /* layouts tried against the 8x8 row-major tiles (MI355R_TEX_LAYOUT=1 / 2): 16x16 tiles; 8x8 tiles with the
+        * texel's column and row bits interleaved (Z order) */
+       RZ_TEX_TILE16 = 32, RZ_TEX_MORTON = 64,
+       RZ_TEX_LAYOUT = RZ_TEX_TILED | RZ_TEX_TILE16 | RZ_TEX_MORTON };
 
 /* a sampled image; data == nullptr means "no map bound" */
 struct DevTex {

@@ -170,6 +170,16 @@ RZ_DEV uint32_t texel_index(int w, int flags, int c, int r) {
         uint32_t tile = ((uint32_t)r >> 3) * ((uint32_t)w >> 3) + ((uint32_t)c >> 3);
         return (tile << 6) | (((uint32_t)r & 7u) << 3) | ((uint32_t)c & 7u);
     }
+    if (flags & RZ_TEX_TILE16) {
+        uint32_t tile = ((uint32_t)r >> 4) * ((uint32_t)w >> 4) + ((uint32_t)c >> 4);
+        return (tile << 8) | (((uint32_t)r & 15u) << 4) | ((uint32_t)c & 15u);
+    }
+    if (flags & RZ_TEX_MORTON) {
+        uint32_t tile = ((uint32_t)r >> 3) * ((uint32_t)w >> 3) + ((uint32_t)c >> 3);
+        const uint32_t x = (uint32_t)c, y = (uint32_t)r;
+        const uint32_t z = (x & 1u) | ((y & 1u) << 1) | ((x & 2u) << 1) | ((y & 2u) << 2) | ((x & 4u) << 2) | ((y & 4u) << 3);
+        return (tile << 6) | z;
+    }
     return (uint32_t)r * (uint32_t)w + (uint32_t)c;
 }
 
@@ -238,14 +248,14 @@ struct MapCell { int w, h, tiled; uint32_t index; float u, v; };
 RZ_DEV MapCell first_cell(const DevTex &t, float x, float y) {
     MapCell m;
     m.u = x - floorf(x); m.v = y - floorf(y);                   /* repeat addressing, texture.c:160-167 */
-    m.w = t.data ? t.w : 1; m.h = t.data ? t.h : 1; m.tiled = t.data ? (t.flags & RZ_TEX_TILED) : 0;
+    m.w = t.data ? t.w : 1; m.h = t.data ? t.h : 1; m.tiled = t.data ? (t.flags & RZ_TEX_LAYOUT) : 0;
     m.index = texel_cell(m.w, m.h, m.tiled, m.u, m.v);
     return m;
 }
 template <bool NARROW>
 RZ_DEV TexelT<NARROW> load_like(const DevTex &t, const MapCell &m) {
     if (!t.data) return load_cell<NARROW>(nullptr, 0, 0u);
-    if (t.w == m.w && t.h == m.h && (t.flags & RZ_TEX_TILED) == m.tiled) return load_cell<NARROW>(t.data, t.flags, m.index);
+    if (t.w == m.w && t.h == m.h && (t.flags & RZ_TEX_LAYOUT) == m.tiled) return load_cell<NARROW>(t.data, t.flags, m.index);
     return load_cell<NARROW>(t.data, t.flags, texel_cell(t.w, t.h, t.flags, m.u, m.v));
 }
 
