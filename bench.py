@@ -30,6 +30,7 @@ WIDTH, HEIGHT = 1920, 1080
 SCENE = "helmet"
 ORBIT = 128                 # views on the orbit circle
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E
+GATHER_CHANNELS = 3         # N > 1: frames travel as RGB8 (a draw never writes the alpha byte, graphics.c:466-468)
 KERNEL_SYMBOL = {"vertex": "rz_vertex_kernel", "setup": "rz_setup_kernel", "bin": "rz_bin_fill_kernel",
                  "raster": "rz_strip_kernel<2, false>", "shade_skybox": "rz_sky_kernel<2>",
                  "shade_blinn": "rz_shade_list_kernel<0, true, true>", "shade_pbr": "rz_shade_list_kernel<1, true, true>"}
@@ -99,7 +100,7 @@ def calibrate_split(gpu, orbit, scene, B, world, rank, device, dist, torch):
     which the peers' frames arrive when all of them send at once (both measured here, on B frames)."""
     fbs = [gpu.framebuffer(WIDTH, HEIGHT) for _ in range(B)]
     views = [gpu.orbit_view(i % ORBIT, ORBIT) for i in range(B)]
-    trial = orbit.FrameGather(B, HEIGHT, WIDTH, device, rank, world, depth=1)
+    trial = orbit.FrameGather(B, HEIGHT, WIDTH, device, rank, world, depth=1, channels=GATHER_CHANNELS)
 
     def fence():
         trial.drain()
@@ -125,11 +126,9 @@ def calibrate_split(gpu, orbit, scene, B, world, rank, device, dist, torch):
         gpu.release(fb)
     del trial
     # rank 0 renders R frames in R * render_s / B, a peer delivers P frames in P * gather_s / B: equal times
-    total = B * world
     if not (render_s > 0 and gather_s > 0):
         return B, None
-    peer = int(total / (gather_s / render_s + (world - 1)))
-    peer = max(1, min(B, peer))
+    peer = orbit.split_for(render_s, gather_s, B, world)
     return peer, {"render_ms_per_frame": render_s / B * 1e3, "delivery_ms_per_frame": gather_s / B * 1e3}
 
 
@@ -185,7 +184,8 @@ def main():
     mine = last - first
     fbs = [gpu.framebuffer(WIDTH, HEIGHT) for _ in range(mine)]
     views = [gpu.orbit_view(i % ORBIT, ORBIT) for i in range(first, last)]
-    gather = orbit.FrameGather(peer_frames, HEIGHT, WIDTH, device, rank, world, root_frames=B * world - peer_frames * (world - 1))
+    gather = orbit.FrameGather(peer_frames, HEIGHT, WIDTH, device, rank, world, root_frames=B * world - peer_frames * (world - 1),
+                               channels=GATHER_CHANNELS)
 
     def step(with_gather=True):
         orbit.render_views(gpu, scene, fbs, views)
@@ -257,13 +257,13 @@ def main():
             "config": {"workload": f"pbr helmet + blurred skybox, {WIDTH}x{HEIGHT}, {B} orbit views per step and GPU "
                                    f"(eye 1.5*(sin a, 0.3, cos a), {ORBIT}-view circle)",
                        "frames_per_step": B * world, "triangles_per_frame": faces,
-                       "gather": ("%s gather of RGBA8 frames to rank 0, overlapped with the next step's rendering"
+                       "gather": ("%s gather of RGB8 frames to rank 0, overlapped with the next step's rendering"
                                   % ("rccl" if on_device else args.backend)) if world > 1 else "none",
                        "split": ({"frames_on_rank_0": mine, "frames_per_peer": peer_frames, "calibration": split}
                                  if world > 1 else None)},
             "ms_per_frame": elapsed / total_frames * 1e3,
             "render_only_fps": (total_frames / render_only) if render_only else None,
-            "gathered_gb_per_s": (args.steps * peer_frames * (world - 1) * WIDTH * HEIGHT * 4 / elapsed / 1e9) if world > 1 else None,
+            "gathered_gb_per_s": (args.steps * peer_frames * (world - 1) * WIDTH * HEIGHT * GATHER_CHANNELS / elapsed / 1e9) if world > 1 else None,
             "shaded_fragments_per_frame": shaded_per_frame,
             "shaded_mfrags_per_s": shaded_per_frame * fps / 1e6,
             "fragments_shaded_on_device_per_frame": counters[8] / mine,

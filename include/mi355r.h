@@ -293,6 +293,12 @@ void framebuffer_read(rz_framebuffer *framebuffer, void *color_rgba8, void *dept
 void framebuffer_read_device(rz_framebuffer *framebuffer, void *color_rgba8_dev,
                              void *depth_f32_dev);
 
+/* The finished colour image without its alpha bytes, into device memory: width * height * 3 bytes, RGB,
+ * row 0 = bottom.  draw_fragment never writes alpha (graphics.c:466-468), so the fourth byte of every
+ * pixel is whatever the last clear put there: a receiver that knows the clear colour loses nothing,
+ * and a gather of frames over GPU links moves a quarter less. */
+void framebuffer_read_device_rgb(rz_framebuffer *framebuffer, void *color_rgb8_dev);
+
 /* Explicit family registration for hosts whose shader functions are not
  * visible as dynamic symbols. */
 void program_register_family(rz_vertex_shader *vs, rz_fragment_shader *fs,

@@ -84,6 +84,7 @@ class Pipeline:
             lib.mi355r_init.argtypes = [C.c_int]
             lib.mi355r_init.restype = C.c_int
             lib.framebuffer_read_device.argtypes = [FB, P, P]
+            lib.framebuffer_read_device_rgb.argtypes = [FB, P]
             lib.mi355r_get_counters.argtypes = [C.POINTER(C.c_ulonglong)]
             lib.mi355r_enable_counters.argtypes = [C.c_int]
             lib.mi355r_stream.restype = P

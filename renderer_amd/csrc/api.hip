@@ -449,6 +449,20 @@ static void read_framebuffer(Fb *fb, void *color, void *depth, hipMemcpyKind kin
     HIP_OK(hipStreamSynchronize(st));
 }
 
+extern "C" void framebuffer_read_device_rgb(rz_framebuffer *p, void *rgb) {
+    Fb *fb = as_fb(p);
+    if (!rgb || ((uintptr_t)rgb & 3u)) fatal("framebuffer_read_device_rgb: the destination must be a 4-byte aligned device pointer");
+    graphics_flush();
+    HIP_OK(hipStreamSynchronize(g.lanes[fb->lane < 0 ? 0 : fb->lane].stream));
+    settle_framebuffer(fb);
+    apply_pending_clear(fb);
+    const size_t n = (size_t)fb->pub.width * fb->pub.height;
+    hipStream_t st = g.lanes[fb->lane < 0 ? 0 : fb->lane].stream;
+    rz_strip_alpha_kernel<<<dim3((unsigned)((n / 4 + 1 + 255) / 256)), dim3(256), 0, st>>>(fb->d_color, (uint32_t*)rgb, n);
+    HIP_OK(hipGetLastError());
+    HIP_OK(hipStreamSynchronize(st));
+}
+
 /* private.c:8-50 */
 extern "C" void framebuffer_blit(rz_framebuffer *p, unsigned char *destination, int swap_red_blue) {
     Fb *fb = as_fb(p);

@@ -2144,6 +2144,25 @@ __global__ void rz_buffers_to_textures_kernel(const CopyJobs jobs) {
     }
 }
 
+/* RGBA8 -> RGB8, four pixels (16 bytes in, 12 out) per thread */
+__global__ void rz_strip_alpha_kernel(const uint32_t *__restrict__ color, uint32_t *__restrict__ rgb, size_t pixels) {
+    const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;         /* group of four pixels */
+    if (q * 4 >= pixels) return;
+    if (q * 4 + 4 <= pixels) {
+        const uint4 c = ((const uint4*)color)[q];
+        const uint32_t a = c.x & 0xffffffu, b = c.y & 0xffffffu, d = c.z & 0xffffffu, e = c.w & 0xffffffu;
+        rgb[q * 3 + 0] = a | (b << 24);
+        rgb[q * 3 + 1] = (b >> 8) | (d << 16);
+        rgb[q * 3 + 2] = (d >> 16) | (e << 8);
+    } else {
+        unsigned char *out = (unsigned char*)rgb;
+        for (size_t p = q * 4; p < pixels; p++) {
+            const uint32_t c = color[p];
+            out[p * 3] = (unsigned char)c; out[p * 3 + 1] = (unsigned char)(c >> 8); out[p * 3 + 2] = (unsigned char)(c >> 16);
+        }
+    }
+}
+
 /* private_blit_bgr / private_blit_rgb (private.c:8-50): vertical flip, optional red/blue swap; the
  * fourth byte of the staged pixel is zero (the host keeps the destination's own) */
 __global__ void rz_blit_kernel(const uint32_t *__restrict__ color, uint32_t *__restrict__ staged, int w, int h, int swap) {

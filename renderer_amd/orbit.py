@@ -48,17 +48,42 @@ def render_views(pipe, scene, framebuffers, views):
 
 
 def frames_to_tensor(pipe, framebuffers, count, out):
-    """Copies `count` finished RGBA8 frames into the torch uint8 tensor `out` [>=count, H, W, 4].
-    Device tensors are filled on the device (framebuffer_read_device), host tensors through
-    framebuffer_read."""
+    """Copies `count` finished frames into the torch uint8 tensor `out` [>=count, H, W, 4 or 3]: RGBA8 as
+    the framebuffer holds it, or RGB8 (the alpha byte is never written by a draw, graphics.c:466-468, so
+    a gather can leave it behind).  Device tensors are filled on the device (framebuffer_read_device /
+    framebuffer_read_device_rgb), host tensors through framebuffer_read."""
     frame_bytes = out[0].numel()
+    channels = out.shape[-1]
     for i in range(count):
         dst = C.c_void_p(out.data_ptr() + i * frame_bytes)
-        if out.is_cuda:
+        if out.is_cuda and channels == 3:
+            pipe.lib.framebuffer_read_device_rgb(framebuffers[i], dst)
+        elif out.is_cuda:
             pipe.lib.framebuffer_read_device(framebuffers[i], dst, None)
+        elif channels == 3:
+            import torch
+            h, w = out.shape[1], out.shape[2]
+            rgba = np.empty((h, w, 4), np.uint8)
+            pipe.lib.framebuffer_read(framebuffers[i], rgba.ctypes.data_as(C.c_void_p), None)
+            out[i].copy_(torch.from_numpy(np.ascontiguousarray(rgba[..., :3])))
         else:
             pipe.lib.framebuffer_read(framebuffers[i], dst, None)
     return out
+
+
+def split_for(render_s, delivery_s, frames, world):
+    """Frames per peer and step for the gather-aware split (shard_views_rooted).  A step is frames * world
+    views; rank 0 renders `frames` views in render_s, and `frames` views per peer arrive on rank 0 in
+    delivery_s when all peers send at once.  With P views per peer rank 0 renders the other
+    frames * world - (world - 1) * P, which takes as long as the delivery of P views from each peer when
+        P = frames * world / (delivery_s / render_s + world - 1),
+    clamped to [1, frames] (frames = the even split)."""
+    if world < 2:
+        return frames
+    if not (render_s > 0 and delivery_s > 0):
+        return frames
+    peer = int(frames * world / (delivery_s / render_s + (world - 1)))
+    return max(1, min(frames, peer))
 
 
 def gather_frames(local, rank, world, dst=0):
@@ -78,7 +103,7 @@ class FrameGather:
     the transfer of one step overlaps the rendering of the next.  Rank 0 ends up with
     `received(slot)` = list over ranks of that step's frames.  world == 1: nothing is moved."""
 
-    def __init__(self, frames, height, width, device, rank, world, depth=2, root_frames=None):
+    def __init__(self, frames, height, width, device, rank, world, depth=2, root_frames=None, channels=4):
         """frames: slot size of the collective (the largest block a rank sends).  root_frames: the
         gather-aware split (shard_views_rooted) -- rank 0's block has that many frames and does not
         go through the collective: rank 0 copies it into a buffer of its own per slot (`own(slot)`),
@@ -89,12 +114,12 @@ class FrameGather:
         self.on_device = torch.device(device).type == "cuda"
         self.slots = self.inbox = self.work = self.kept = None
         if world > 1:
-            shape = (frames, height, width, 4)
+            shape = (frames, height, width, channels)
             self.slots = [torch.empty(shape, dtype=torch.uint8, device=device) for _ in range(depth)]
             self.inbox = [[torch.empty(shape, dtype=torch.uint8, device=device) for _ in range(world)] if rank == 0 else None
                           for _ in range(depth)]
             if self.rooted and rank == 0:
-                self.kept = [torch.empty((root_frames, height, width, 4), dtype=torch.uint8, device=device) for _ in range(depth)]
+                self.kept = [torch.empty((root_frames, height, width, channels), dtype=torch.uint8, device=device) for _ in range(depth)]
             self.work = [None] * depth
 
     def _finish(self, slot):

@@ -17,7 +17,8 @@ from renderer_amd.binding import Pipeline                       # noqa: E402
 def main():
     total, width, height = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
     name = sys.argv[4] if len(sys.argv) > 4 else "helmet"
-    peer_frames = int(sys.argv[5]) if len(sys.argv) > 5 else None    # given: the gather-aware split
+    peer_frames = int(sys.argv[5]) if len(sys.argv) > 5 and sys.argv[5] != "-" else None    # given: the gather-aware split
+    channels = int(sys.argv[6]) if len(sys.argv) > 6 else 4          # 3: frames travel without their alpha byte
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     dist.init_process_group("gloo", rank=rank, world_size=world)
     pipe = Pipeline(os.path.join(REPO, "oracle", "liboracle.so"))
@@ -25,11 +26,11 @@ def main():
     if peer_frames is None:
         first, last = orbit.shard_views(total, rank, world)
         block = max(orbit.shard_views(total, r, world)[1] - orbit.shard_views(total, r, world)[0] for r in range(world))
-        pipeline = orbit.FrameGather(block, height, width, "cpu", rank, world)
+        pipeline = orbit.FrameGather(block, height, width, "cpu", rank, world, channels=channels)
     else:
         first, last = orbit.shard_views_rooted(total, rank, world, peer_frames)
         block = last - first
-        pipeline = orbit.FrameGather(peer_frames, height, width, "cpu", rank, world, root_frames=total - peer_frames * (world - 1))
+        pipeline = orbit.FrameGather(peer_frames, height, width, "cpu", rank, world, root_frames=total - peer_frames * (world - 1), channels=channels)
     fbs = [pipe.framebuffer(width, height) for _ in range(block)]
     views = [pipe.orbit_view(i, total) for i in range(first, last)]
     # the pipelined gather bench.py uses, three steps through two slots: the last step is the one checked
@@ -50,7 +51,7 @@ def main():
         ok = len(frames) == total and float(t.item()) == float(world)
         for i, frame in enumerate(frames):
             want, _ = pipe.render(scene, width, height, pipe.orbit_view(i, total))
-            ok = ok and np.array_equal(frame.numpy(), want)
+            ok = ok and np.array_equal(frame.numpy(), want[..., :channels])
         print("ORBIT_OK" if ok else "ORBIT_MISMATCH", flush=True)
     dist.barrier()
     dist.destroy_process_group()

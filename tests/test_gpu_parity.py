@@ -320,3 +320,30 @@ def test_gpu_blit_equals_the_reference_blit(gpu, oracle, size):
         assert np.array_equal(g[..., :3], gf[0][::-1, :, order])       # the library's own frame, flipped
         assert np.array_equal(o[..., :3], of[0][::-1, :, order])
         assert (g[..., :3] != o[..., :3]).any(axis=2).sum() <= max(2, w * h * 2e-4)   # colour bar of the frames themselves
+
+
+@pytest.mark.parametrize("size", [(320, 180), (67, 33), (5, 1)])
+def test_gpu_frames_without_their_alpha_bytes(gpu, size):
+    """framebuffer_read_device_rgb: the colour image as RGB8 in device memory (what the multi-GPU gather
+    moves), for pixel counts that are and are not multiples of four."""
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    hip.hipMemset.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    hip.hipFree.argtypes = [C.c_void_p]
+    w, h = size
+    scene = gpu.open_scene("helmet")
+    fb = gpu.framebuffer(w, h)
+    gpu.draw(scene, fb, gpu.orbit_view(6, 16))
+    n = h * w * 3 + 8
+    dev = C.c_void_p()
+    assert hip.hipMalloc(C.byref(dev), n) == 0 and hip.hipMemset(dev, 7, n) == 0
+    gpu.lib.framebuffer_read_device_rgb(fb, dev)
+    got = np.zeros(n, np.uint8)
+    assert hip.hipMemcpy(got.ctypes.data_as(C.c_void_p), dev, n, 2) == 0        # device to host
+    hip.hipFree(dev)
+    color, _ = gpu.read(fb)
+    assert np.array_equal(got[:h * w * 3].reshape(h, w, 3), color[..., :3])
+    assert np.all(got[h * w * 3:] == 7)                  # nothing behind the image is touched
+    gpu.release(fb)
+    gpu.close_scene(scene)

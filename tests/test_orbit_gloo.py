@@ -37,10 +37,33 @@ def test_rooted_shards_partition_the_views():
         shard_views_rooted(8, 0, 4, 3)
 
 
-@pytest.mark.parametrize("world,total,scene,peer", [(2, 5, "helmet", None), (2, 4, "helmet", None), (2, 6, "buster", None),
-                                                    (2, 6, "helmet", 2), (3, 7, "helmet", 1)],
-                         ids=["helmet-5", "helmet-4", "buster-animated-6", "helmet-6-rooted-2", "helmet-7-of-3-rooted-1"])
-def test_gloo_orbit_gather(oracle, world, total, scene, peer):
+def test_gather_aware_split_arithmetic():
+    """split_for with injected times: peers = frames * world / (delivery / render + world - 1), clamped."""
+    from renderer_amd.orbit import split_for, shard_views_rooted
+    assert split_for(1.0, 1.0, 128, 1) == 128                      # one rank: nothing to split
+    assert split_for(1.0, 1.0, 128, 2) == 128                      # a link as fast as the renderer: even split
+    assert split_for(1.0, 3.0, 128, 2) == 64                       # 256 / (3 + 1)
+    assert split_for(1.0, 7.0, 128, 8) == 73                       # 1024 / (7 + 7) = 73.1
+    assert split_for(1.0, 1e9, 128, 4) == 1                        # a dead link still gets one frame per peer
+    assert split_for(1.0, 0.01, 128, 4) == 128                     # never more than the even split
+    assert split_for(0.0, 1.0, 128, 4) == 128 and split_for(1.0, float("nan"), 128, 4) == 128
+    for world in (2, 4, 8):
+        for ratio in (0.5, 2.0, 5.5, 40.0):
+            p = split_for(1.0, ratio, 128, world)
+            root = 128 * world - p * (world - 1)
+            first, last = shard_views_rooted(128 * world, 0, world, p)
+            assert last - first == root >= p
+            # rank 0's rendering and a peer's delivery take the same time to within one frame of either
+            if 1 < p < 128:
+                assert abs(root * 1.0 - p * ratio) <= max(1.0, ratio) * world
+
+
+@pytest.mark.parametrize("world,total,scene,peer,channels", [(2, 5, "helmet", None, 4), (2, 4, "helmet", None, 3), (2, 6, "buster", None, 4),
+                                                             (2, 6, "helmet", 2, 4), (3, 7, "helmet", 1, 3), (4, 11, "helmet", 2, 3),
+                                                             (4, 9, "buster", None, 3)],
+                         ids=["helmet-5", "helmet-4-rgb", "buster-animated-6", "helmet-6-rooted-2", "helmet-7-of-3-rooted-1-rgb",
+                              "helmet-11-of-4-rooted-2-rgb", "buster-9-of-4-rgb"])
+def test_gloo_orbit_gather(oracle, world, total, scene, peer, channels):
     """helmet: the benchmark's scene; buster: the animated scene of the batch-render configuration
     (every view has its own frame time, so every rank evaluates its own poses).  rooted: the
     gather-aware split bench.py uses for N > 1 (peers render `peer` views each, rank 0 the rest and
@@ -53,7 +76,7 @@ def test_gloo_orbit_gather(oracle, world, total, scene, peer):
     for rank in range(world):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="1")
-        procs.append(subprocess.Popen([sys.executable, os.path.join(REPO, "tests", "orbit_worker.py"), str(total), "96", "54", scene] + ([str(peer)] if peer is not None else []),
+        procs.append(subprocess.Popen([sys.executable, os.path.join(REPO, "tests", "orbit_worker.py"), str(total), "96", "54", scene, str(peer) if peer is not None else "-", str(channels)],
                                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     outs = []
     for p in procs:
