@@ -1746,8 +1746,8 @@ static void launch_batch(const Batch &b, const std::vector<PassPlan> &plans, cha
             sky_done = g.strip_sky;
             auto kernel = g.strip_sky ? (g.strip == 8 ? rz_strip_kernel<8, true> : g.strip == 4 ? rz_strip_kernel<4, true> : g.strip == 2 ? rz_strip_kernel<2, true> : rz_strip_kernel<1, true>)
                                       : (g.strip == 8 ? rz_strip_kernel<8, false> : g.strip == 4 ? rz_strip_kernel<4, false> : g.strip == 2 ? rz_strip_kernel<2, false> : rz_strip_kernel<1, false>);
-            kernel<<<dim3((unsigned)max_tiles_x, (rows + 8u * g.strip - 1u) / (8u * g.strip), n), dim3(128), 0, st>>>(
-                passes, L.bin_list.ptr, L.bin_boxes.ptr, L.vary.ptr, L.fan_vary.ptr, db, L.bin_range.ptr);
+            kernel<<<dim3((unsigned)max_tiles_x * n, (rows + 8u * g.strip - 1u) / (8u * g.strip)), dim3(128), 0, st>>>(
+                passes, L.bin_list.ptr, L.bin_boxes.ptr, L.vary.ptr, L.fan_vary.ptr, db, L.bin_range.ptr, n);
         }
         stamp();
         if ((b.families & (1 << RZ_FAMILY_SKYBOX)) && !sky_done) {

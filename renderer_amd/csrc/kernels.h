@@ -1602,19 +1602,27 @@ template <int STRIP, bool SKY>
 __global__ void __launch_bounds__(128) rz_strip_kernel(const PassParams *__restrict__ passes,
         const BinEntry *__restrict__ list_base, const uint2 *__restrict__ box_base,
         const float *__restrict__ vary_base, const float *__restrict__ fan_vary_base,
-        const char *__restrict__ upload_base, const uint2 *__restrict__ bin_range_base) {
+        const char *__restrict__ upload_base, const uint2 *__restrict__ bin_range_base, uint32_t num_passes) {
     constexpr int PPL = 2;
     static_assert(RZ_BIN % (8 * STRIP) == 0, "a strip lies inside one bin");
-    const PassParams P = passes[blockIdx.z];
-    const int sy0 = (int)blockIdx.y * 8 * STRIP;
-    if ((int)blockIdx.x >= P.tiles_x || sy0 >= P.height) return;
+    /* Workgroups start in the order of their index.  The pass is the fastest part of it, and columns and
+     * rows count outwards from the middle of the frame: what takes long -- the strips a model lies in,
+     * usually in the middle -- starts first in every pass of the batch, and what is still running when
+     * the launch ends are the cheap strips at the frames' borders (grid: x = pass + passes * column, y = row). */
+    const uint32_t pass_index = blockIdx.x % num_passes, column_turn = blockIdx.x / num_passes;
+    const uint32_t columns = gridDim.x / num_passes, rows = gridDim.y;
+    const uint32_t tile_column = (column_turn & 1u) ? (columns - 1u) / 2u + (column_turn + 1u) / 2u : (columns - 1u) / 2u - (column_turn + 1u) / 2u;
+    const uint32_t strip_row = (blockIdx.y & 1u) ? (rows - 1u) / 2u + (blockIdx.y + 1u) / 2u : (rows - 1u) / 2u - (blockIdx.y + 1u) / 2u;
+    const PassParams P = passes[pass_index];
+    const int sy0 = (int)strip_row * 8 * STRIP;
+    if ((int)tile_column >= P.tiles_x || sy0 >= P.height) return;
     if (P.control[2] != 0u) return;                             /* out of scratch, or left out: the pass is run again later */
     const BinEntry *list_table = list_base + P.list_off;
     const float *vary_table = vary_base + (size_t)P.tri_off * 3 * RZ_VARY_STRIDE;
     const float *fan_vary_table = fan_vary_base + (size_t)P.fan_off * RZ_MAX_POLY * RZ_VARY_STRIDE;
     const DrawRec *draw_table = (const DrawRec*)(upload_base + P.draws_off);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int tx0 = (int)blockIdx.x * RZ_TILE_W;
+    const int tx0 = (int)tile_column * RZ_TILE_W;
     const int bx0 = tx0 + wave * 8 * PPL, bx1 = bx0 + 8 * PPL - 1;
     int px[PPL];
     for (int q = 0; q < PPL; q++) px[q] = bx0 + 8 * q + (lane & 7);
@@ -1920,7 +1928,7 @@ __global__ void __launch_bounds__(128) rz_strip_kernel(const PassParams *__restr
                     const uint32_t part = f * RZ_QUEUE_WAYS + (index & (RZ_QUEUE_WAYS - 1u));
                     const uint32_t at = atomicAdd(&P.queue_counts[part * RZ_QUEUE_PAD], 1u);
                     if (at < P.queue_capacity)
-                        P.queue[(size_t)part * P.queue_capacity + at] = RZ_BLOCK_ITEM(blockIdx.z, block_y, block_x);
+                        P.queue[(size_t)part * P.queue_capacity + at] = RZ_BLOCK_ITEM(pass_index, block_y, block_x);
                     else
                         atomicOr(&P.control[2], (uint32_t)RZ_ERR_QUEUE_OVERFLOW);
                 }

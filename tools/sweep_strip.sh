@@ -1,6 +1,6 @@
 # helmet bench under the strip kernel's variants
 mkdir -p gpurun_out
-for v in "MI355R_STRIP=0" "MI355R_STRIP=2" "MI355R_STRIP=1" "MI355R_STRIP=8"; do
+for v in "MI355R_STRIP=2" "MI355R_STRIP=4" "MI355R_STRIP=8" "MI355R_STRIP=1"; do
   env $v timeout -k 10 200 python bench.py --steps 10 --warmup 2 --no-cpu --no-other > gpurun_out/bench_sweep.json || exit 1
   python - "$v" <<'PY'
 import json, sys
