@@ -8,7 +8,7 @@ import os
 import numpy as np
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-GPU_LIB = os.path.join(REPO, "renderer_amd", "libmi355r.so")
+GPU_LIB = os.environ.get("MI355R_LIB") or os.path.join(REPO, "renderer_amd", "libmi355r.so")     # MI355R_LIB: another build, for A/B measurements
 ASSETS = os.path.join(REPO, "assets")
 SCENES = os.path.join(REPO, "scenes")
 

@@ -66,6 +66,7 @@ struct Fb {
     uint32_t *d_color;
     float *d_depth;
     int lane;                       /* execution lane of the last pass into it, -1 = none yet */
+    uint32_t longest_list = 0;      /* entries of the longest bin list among its passes of the last settled flush */
     bool clear_color_pending, clear_depth_pending;
     uint32_t clear_color;
     float clear_depth;
@@ -168,7 +169,9 @@ struct Context {
     int micro_min_list = 256;               /* MI355R_MICRO_MIN_LIST: ... only in bins with at least this many list entries */
     int sky_pixels_per_lane = 2;            /* MI355R_SKY_PPL=1: the one-pixel-per-lane skybox kernel */
     bool strip_sky = false;                 /* MI355R_STRIP_SKY=1: rz_strip_kernel shades skybox fragments in place (measured: slower) */
-    int strip = 2;                          /* MI355R_STRIP: 16x8 blocks a wave of rz_strip_kernel takes (8, 4, 2, 1); 0 = rz_visibility_kernel + rz_sky_kernel */
+    unsigned strip_long = 2048;             /* MI355R_STRIP_LONG: a batch whose framebuffers had a bin list of this many entries in their last frame takes one block per wave,
+                                             * of half as many two; 0, or MI355R_STRIP set = always `strip` */
+    int strip = 4;                          /* MI355R_STRIP: 16x8 blocks a wave of rz_strip_kernel takes (8, 4, 2, 1); 0 = rz_visibility_kernel + rz_sky_kernel */
     /* passes with blended draws: 0 = whole through the ordered kernel, 1 = visibility first and the ordered kernel only for
      * the tiles that need it, 2 = the latter for large framebuffers (MI355R_SPLIT_BLEND=0 / 1; measured: 4K frames gain 8 %,
      * 1080p frames lose as much to the three extra launches) */
@@ -292,9 +295,11 @@ extern "C" int mi355r_init(int device) {
         env = getenv("MI355R_SKY_PPL");
         if (env) g.sky_pixels_per_lane = atoi(env) == 1 ? 1 : 2;
         env = getenv("MI355R_STRIP");
-        if (env) { const int v = atoi(env); g.strip = (v == 8 || v == 4 || v == 2 || v == 1) ? v : 0; }
+        if (env) { const int v = atoi(env); g.strip = (v == 8 || v == 4 || v == 2 || v == 1) ? v : 0; g.strip_long = 0; }
         env = getenv("MI355R_STRIP_SKY");
         if (env) g.strip_sky = atoi(env) != 0;
+        env = getenv("MI355R_STRIP_LONG");
+        if (env) g.strip_long = (unsigned)atoi(env);
         env = getenv("MI355R_SPLIT_BLEND");
         if (env) g.split_blend = atoi(env) != 0 ? 1 : 0;
         g.monolithic = getenv("MI355R_MONOLITHIC") != nullptr;
@@ -1683,6 +1688,9 @@ static void launch_batch(const Batch &b, const std::vector<PassPlan> &plans, cha
     };
     const dim3 vgrid((unsigned)((max_T * 3 + 255) / 256), n), tgrid((unsigned)((max_T + 255) / 256), n);
     const dim3 tiles((unsigned)max_tiles_x, (unsigned)max_tiles_y, n);
+    /* tile_order (kernels.h): whole bins, i.e. an even number of tile columns and a multiple of a bin's tile rows */
+    const unsigned bin_columns = (unsigned)(max_tiles_x + 1) / 2, bin_rows = (unsigned)(max_tiles_y * RZ_TILE_H + RZ_BIN - 1) / RZ_BIN;
+    const dim3 ordered_tiles(bin_columns * 2 * n, bin_rows * (RZ_BIN / RZ_TILE_H));
     /* the shade kernels stride over work lists: enough workgroups to fill the device, no more */
     size_t batch_tiles = 0;
     for (size_t i : b.members)
@@ -1720,12 +1728,12 @@ static void launch_batch(const Batch &b, const std::vector<PassPlan> &plans, cha
         auto kernel = rz_raster_kernel<false>;
         if (only == 0) kernel = narrow ? rz_raster_kernel<false, 0, true> : rz_raster_kernel<false, 0, false>;
         if (only == 1) kernel = narrow ? rz_raster_kernel<false, 1, true> : rz_raster_kernel<false, 1, false>;
-        kernel<<<tiles, dim3(256), 0, st>>>(
-            passes, L.tri.ptr, L.fan_tri.ptr, L.bin_list.ptr, L.vary.ptr, L.fan_vary.ptr, db, L.bin_range.ptr);
+        kernel<<<ordered_tiles, dim3(256), 0, st>>>(
+            passes, L.tri.ptr, L.fan_tri.ptr, L.bin_list.ptr, L.vary.ptr, L.fan_vary.ptr, db, L.bin_range.ptr, n);
         stamp(); stamp(); stamp(); stamp();
     } else {
         if (b.has_blend) {
-            rz_visibility_kernel<2, true><<<tiles, dim3(128), 0, st>>>(passes, L.bin_list.ptr, L.bin_boxes.ptr, L.vary.ptr, L.fan_vary.ptr, db, L.bin_range.ptr);
+            rz_visibility_kernel<2, true><<<ordered_tiles, dim3(128), 0, st>>>(passes, L.bin_list.ptr, L.bin_boxes.ptr, L.vary.ptr, L.fan_vary.ptr, db, L.bin_range.ptr, n);
             auto kernel = rz_raster_list_kernel<-1, false>;
             if (only == 0) kernel = narrow ? rz_raster_list_kernel<0, true> : rz_raster_list_kernel<0, false>;
             if (only == 1) kernel = narrow ? rz_raster_list_kernel<1, true> : rz_raster_list_kernel<1, false>;
@@ -1733,20 +1741,24 @@ static void launch_batch(const Batch &b, const std::vector<PassPlan> &plans, cha
                 passes, L.tri.ptr, L.fan_tri.ptr, L.bin_list.ptr, L.vary.ptr, L.fan_vary.ptr, db, L.bin_range.ptr,
                 L.queue.ptr, L.queue_counts.ptr, queue_capacity);
         } else if (g.narrow_raster)
-            rz_raster_kernel<true><<<tiles, dim3(256), 0, st>>>(
-                passes, L.tri.ptr, L.fan_tri.ptr, L.bin_list.ptr, L.vary.ptr, L.fan_vary.ptr, db, L.bin_range.ptr);
+            rz_raster_kernel<true><<<ordered_tiles, dim3(256), 0, st>>>(
+                passes, L.tri.ptr, L.fan_tri.ptr, L.bin_list.ptr, L.vary.ptr, L.fan_vary.ptr, db, L.bin_range.ptr, n);
         else if (g.pixels_per_lane == 4)
-            rz_visibility_kernel<4><<<tiles, dim3(64), 0, st>>>(passes, L.bin_list.ptr, L.bin_boxes.ptr, L.vary.ptr, L.fan_vary.ptr, db, L.bin_range.ptr);
+            rz_visibility_kernel<4><<<ordered_tiles, dim3(64), 0, st>>>(passes, L.bin_list.ptr, L.bin_boxes.ptr, L.vary.ptr, L.fan_vary.ptr, db, L.bin_range.ptr, n);
         else if (g.strip == 0)
-            rz_visibility_kernel<2><<<tiles, dim3(128), 0, st>>>(passes, L.bin_list.ptr, L.bin_boxes.ptr, L.vary.ptr, L.fan_vary.ptr, db, L.bin_range.ptr);
+            rz_visibility_kernel<2><<<ordered_tiles, dim3(128), 0, st>>>(passes, L.bin_list.ptr, L.bin_boxes.ptr, L.vary.ptr, L.fan_vary.ptr, db, L.bin_range.ptr, n);
         else {
             /* visibility and skybox shading together, a strip of 16x8 blocks per wave: the default */
             in_strips = true;
-            const unsigned rows = (unsigned)max_tiles_y * RZ_TILE_H;
+            uint32_t longest = 0;
+            for (size_t i : b.members) longest = std::max(longest, plans[i].fb->longest_list);
+            const int strip = !g.strip_long ? g.strip : longest >= g.strip_long ? 1 : longest >= g.strip_long / 2 ? std::min(g.strip, 2) : g.strip;
+            const unsigned strips_per_bin = RZ_BIN / (8u * strip);
             sky_done = g.strip_sky;
-            auto kernel = g.strip_sky ? (g.strip == 8 ? rz_strip_kernel<8, true> : g.strip == 4 ? rz_strip_kernel<4, true> : g.strip == 2 ? rz_strip_kernel<2, true> : rz_strip_kernel<1, true>)
-                                      : (g.strip == 8 ? rz_strip_kernel<8, false> : g.strip == 4 ? rz_strip_kernel<4, false> : g.strip == 2 ? rz_strip_kernel<2, false> : rz_strip_kernel<1, false>);
-            kernel<<<dim3((unsigned)max_tiles_x * n, (rows + 8u * g.strip - 1u) / (8u * g.strip)), dim3(128), 0, st>>>(
+            auto kernel = g.strip_sky ? (strip == 8 ? rz_strip_kernel<8, true> : strip == 4 ? rz_strip_kernel<4, true> : strip == 2 ? rz_strip_kernel<2, true> : rz_strip_kernel<1, true>)
+                                      : (strip == 8 ? rz_strip_kernel<8, false> : strip == 4 ? rz_strip_kernel<4, false> : strip == 2 ? rz_strip_kernel<2, false> : rz_strip_kernel<1, false>);
+            if (g.verbose) fprintf(stderr, "mi355r: batch of %u passes, longest bin list last time %u entries, strips of %d\n", n, longest, strip);
+            kernel<<<dim3(bin_columns * 2 * n, bin_rows * strips_per_bin), dim3(128), 0, st>>>(
                 passes, L.bin_list.ptr, L.bin_boxes.ptr, L.vary.ptr, L.fan_vary.ptr, db, L.bin_range.ptr, n);
         }
         stamp();
@@ -1865,10 +1877,12 @@ static bool settle_in_flight(bool lanes_idle) {
         if (!lanes_idle)
             for (int l = 0; l < MAX_LANES; l++) if (fr.used[l]) HIP_OK(hipStreamSynchronize(g.lanes[l].stream));
         bool failed = false;
+        for (size_t i = 0; i < fr.plans.size(); i++) fr.plans[i].fb->longest_list = 0;
         for (size_t i = 0; i < fr.plans.size(); i++) {
             const uint32_t *c = fr.control(i);
             failed = failed || c[2] != 0;
             g.host_counters[3] += c[1];
+            fr.plans[i].fb->longest_list = std::max(fr.plans[i].fb->longest_list, c[4]);
         }
         if (failed) {
             if (!lanes_idle) {      /* other lanes may be busy with later work on the same framebuffers and textures */

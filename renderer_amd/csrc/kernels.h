@@ -647,6 +647,11 @@ __global__ void __launch_bounds__(64 * RZ_SCAN_SEGMENTS) rz_bin_scan_kernel(cons
         P.bin_range[bin] = make_uint2(start, total);
         s_part[0][threadIdx.x & 63] = total ? start : 0xffffffffu;
     }
+    if (segment == 0) {             /* the pass's longest list, for the host's choice of strip height next time */
+        uint32_t longest = bin < bins ? total : 0u;
+        for (int off = 32; off; off >>= 1) longest = max(longest, (uint32_t)__shfl_xor((int)longest, off));
+        if ((threadIdx.x & 63) == 0 && longest) atomicMax(&P.control[4], longest);
+    }
     __syncthreads();
     const uint32_t start = s_part[0][threadIdx.x & 63];
     if (bin >= bins || start == 0xffffffffu) return;    /* empty or overflowed bin: its entries are never written */
@@ -1233,15 +1238,40 @@ RZ_DEV void raster_tile(const PassParams &P, const uint32_t pass_index, const ui
     }
 }
 
-/* over every tile of every pass: grid x, y = tile column / row, z = pass of the batch */
+/* The order in which the workgroups of a tile kernel start (that of their index) over the tiles of a
+ * batch of passes.  The pass is the fastest part of the index, and columns and rows count outwards from
+ * the middle of the frame: what takes long -- the tiles a model lies in, usually in the middle -- starts
+ * first in every pass of the batch, and what is still running when the launch ends are the cheap tiles
+ * at the frames' borders.  (With the pass as the slowest part the last frame's long tiles were the
+ * launch's tail: 12.8 -> 11.0 us per frame in the strip kernel for the helmet at 1080p, 26.4 -> 19.6 for
+ * azura at 800x600, 80.7 -> 62.2 for dieselpunk at 4K.)  The unit of that order is the bin, not
+ * the tile: the tiles of a bin walk the same list and start next to each other.
+ * grid: x = pass + passes * column, y = row. */
+struct TileOrder { uint32_t pass, column, row; };
+RZ_DEV uint32_t outwards(uint32_t turn, uint32_t count) {      /* 0, 1, 2, .. -> middle, middle + 1, middle - 1, .. */
+    return (turn & 1u) ? (count - 1u) / 2u + (turn + 1u) / 2u : (count - 1u) / 2u - (turn + 1u) / 2u;
+}
+RZ_DEV TileOrder tile_order(uint32_t num_passes, uint32_t rows_per_bin) {
+    TileOrder o;
+    /* the grid covers whole bins: an even number of 32-pixel columns, rows_per_bin rows per bin row */
+    const uint32_t columns = gridDim.x / num_passes, rows = gridDim.y;
+    const uint32_t column_turn = blockIdx.x / num_passes;
+    o.pass = blockIdx.x % num_passes;
+    o.column = outwards(column_turn / 2u, columns / 2u) * 2u + (column_turn & 1u);
+    o.row = outwards(blockIdx.y / rows_per_bin, rows / rows_per_bin) * rows_per_bin + blockIdx.y % rows_per_bin;
+    return o;
+}
+
+/* over every tile of every pass (tile_order) */
 template <bool SPLIT, int FAMILY = -1, bool NARROW = false>
 __global__ void __launch_bounds__(256) rz_raster_kernel(const PassParams *__restrict__ passes,
         const TriRec *__restrict__ tri_base, const TriRec *__restrict__ fan_base,
         const BinEntry *__restrict__ list_base,
         const float *__restrict__ vary_base, const float *__restrict__ fan_vary_base,
-        const char *__restrict__ upload_base, const uint2 *__restrict__ bin_range_base) {
-    const PassParams P = passes[blockIdx.z];          /* by value: one burst of scalar loads up front, not one wait per field */
-    raster_tile<SPLIT, FAMILY, NARROW>(P, blockIdx.z, blockIdx.x, blockIdx.y, tri_base, fan_base, list_base, vary_base, fan_vary_base,
+        const char *__restrict__ upload_base, const uint2 *__restrict__ bin_range_base, uint32_t num_passes) {
+    const TileOrder o = tile_order(num_passes, RZ_BIN / RZ_TILE_H);
+    const PassParams P = passes[o.pass];              /* by value: one burst of scalar loads up front, not one wait per field */
+    raster_tile<SPLIT, FAMILY, NARROW>(P, o.pass, o.column, o.row, tri_base, fan_base, list_base, vary_base, fan_vary_base,
                                        upload_base, bin_range_base);
 }
 
@@ -1278,9 +1308,10 @@ template <int PPL, bool BLEND = false>
 __global__ void __launch_bounds__(256 / PPL) rz_visibility_kernel(const PassParams *__restrict__ passes,
         const BinEntry *__restrict__ list_base, const uint2 *__restrict__ box_base,
         const float *__restrict__ vary_base, const float *__restrict__ fan_vary_base,
-        const char *__restrict__ upload_base, const uint2 *__restrict__ bin_range_base) {
-    const PassParams P = passes[blockIdx.z];
-    if ((int)blockIdx.x >= P.tiles_x || (int)blockIdx.y >= P.tiles_y) return;
+        const char *__restrict__ upload_base, const uint2 *__restrict__ bin_range_base, uint32_t num_passes) {
+    const TileOrder o = tile_order(num_passes, RZ_BIN / RZ_TILE_H);
+    const PassParams P = passes[o.pass];
+    if ((int)o.column >= P.tiles_x || (int)o.row >= P.tiles_y) return;
     if (P.debug_skip == 3) return;
     if (P.control[2] != 0u) return;                             /* out of scratch, or left out: the pass is run again later */
     const BinEntry *list_table = list_base + P.list_off;
@@ -1288,7 +1319,7 @@ __global__ void __launch_bounds__(256 / PPL) rz_visibility_kernel(const PassPara
     const float *fan_vary_table = fan_vary_base + (size_t)P.fan_off * RZ_MAX_POLY * RZ_VARY_STRIDE;
     const DrawRec *draw_table = (const DrawRec*)(upload_base + P.draws_off);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int tx0 = (int)blockIdx.x * RZ_TILE_W, ty0 = (int)blockIdx.y * RZ_TILE_H;
+    const int tx0 = (int)o.column * RZ_TILE_W, ty0 = (int)o.row * RZ_TILE_H;
     const int bx0 = tx0 + wave * 8 * PPL, by0 = ty0, bx1 = bx0 + 8 * PPL - 1, by1 = by0 + 7;
     const int py = by0 + (lane >> 3);
     int px[PPL];
@@ -1536,11 +1567,11 @@ __global__ void __launch_bounds__(256 / PPL) rz_visibility_kernel(const PassPara
         if (s_ordered) {
             for (int q = 0; q < PPL; q++) if (valid[q]) P.ref[pixel[q]] = RZ_REF_NONE;     /* nothing here for the shade kernels */
             if (threadIdx.x == 0) {
-                const uint32_t tile = blockIdx.y * (uint32_t)P.tiles_x + blockIdx.x;
+                const uint32_t tile = o.row * (uint32_t)P.tiles_x + o.column;
                 const uint32_t part = RZ_ORDERED_LIST * RZ_QUEUE_WAYS + ((P.tile_off + tile) & (RZ_QUEUE_WAYS - 1u));
                 const uint32_t at = atomicAdd(&P.queue_counts[part * RZ_QUEUE_PAD], 1u);
                 if (at < P.queue_capacity)
-                    P.queue[(size_t)part * P.queue_capacity + at] = ((uint32_t)blockIdx.z << 20) | ((uint32_t)blockIdx.y << 9) | (uint32_t)blockIdx.x;
+                    P.queue[(size_t)part * P.queue_capacity + at] = ((uint32_t)o.pass << 20) | ((uint32_t)o.row << 9) | (uint32_t)o.column;
                 else
                     atomicOr(&P.control[2], (uint32_t)RZ_ERR_QUEUE_OVERFLOW);
             }
@@ -1566,14 +1597,14 @@ __global__ void __launch_bounds__(256 / PPL) rz_visibility_kernel(const PassPara
         for (int q = 0; q < PPL; q++) mine |= ((ref_of[q] >> 28) & 3u) == f;
         if (!__any(mine)) continue;
         if (lane == 0) {
-            const uint32_t tile = blockIdx.y * (uint32_t)P.tiles_x + blockIdx.x;
+            const uint32_t tile = o.row * (uint32_t)P.tiles_x + o.column;
             const uint32_t before = atomicOr(&P.tile_listed[tile], 1u << f);
             if (!(before >> f & 1u)) {
                 /* by the tile's index in the batch: no part can get more than its even share */
                 const uint32_t part = f * RZ_QUEUE_WAYS + ((P.tile_off + tile) & (RZ_QUEUE_WAYS - 1u));
                 const uint32_t at = atomicAdd(&P.queue_counts[part * RZ_QUEUE_PAD], 1u);
                 if (at < P.queue_capacity)
-                    P.queue[(size_t)part * P.queue_capacity + at] = ((uint32_t)blockIdx.z << 20) | ((uint32_t)blockIdx.y << 9) | (uint32_t)blockIdx.x;
+                    P.queue[(size_t)part * P.queue_capacity + at] = ((uint32_t)o.pass << 20) | ((uint32_t)o.row << 9) | (uint32_t)o.column;
                 else
                     atomicOr(&P.control[2], (uint32_t)RZ_ERR_QUEUE_OVERFLOW);
             }
@@ -1592,6 +1623,16 @@ __global__ void __launch_bounds__(256 / PPL) rz_visibility_kernel(const PassPara
  * the whole strip.  The first group of the next block's candidates is requested before the current
  * block's epilogue, which hides its latency behind the epilogue's arithmetic.
  *
+ * How tall a strip should be depends on the lists.  Where they are short (sky, background) the fixed
+ * costs of a wave and of starting its workgroup are what counts, and tall strips win (helmet at 1080p,
+ * longest list 700 entries: 12.9 / 12.5 / 11.7 us per frame with 1 / 2 / 4 blocks).  A long list makes
+ * the blocks themselves expensive: then four times as many waves, each a quarter as long, fill the
+ * device better and leave a shorter tail (azura at 800x600, a few bins of 10 000 entries and more: 19.2 /
+ * 30.6 / 46.8 us).  The host picks STRIP per batch from the longest list its framebuffers had in their
+ * last frame (control word 4, rz_bin_scan_kernel).  Deciding per bin inside one launch -- a workgroup
+ * per block, all but the first of a strip leaving at once where the list is short -- gave the long lists
+ * their waves but cost the short ones the workgroup starts again (helmet 11.9 -> 14.0 us).
+ *
  * The epilogue shades skybox fragments in place (skybox_shader.c:21-29; what rz_sky_kernel does
  * from the reference plane): the sky fills most of a frame, and writing a reference per sky pixel only
  * to read it back in the next kernel was most of this stage's memory traffic.  References are written
@@ -1605,14 +1646,8 @@ __global__ void __launch_bounds__(128) rz_strip_kernel(const PassParams *__restr
         const char *__restrict__ upload_base, const uint2 *__restrict__ bin_range_base, uint32_t num_passes) {
     constexpr int PPL = 2;
     static_assert(RZ_BIN % (8 * STRIP) == 0, "a strip lies inside one bin");
-    /* Workgroups start in the order of their index.  The pass is the fastest part of it, and columns and
-     * rows count outwards from the middle of the frame: what takes long -- the strips a model lies in,
-     * usually in the middle -- starts first in every pass of the batch, and what is still running when
-     * the launch ends are the cheap strips at the frames' borders (grid: x = pass + passes * column, y = row). */
-    const uint32_t pass_index = blockIdx.x % num_passes, column_turn = blockIdx.x / num_passes;
-    const uint32_t columns = gridDim.x / num_passes, rows = gridDim.y;
-    const uint32_t tile_column = (column_turn & 1u) ? (columns - 1u) / 2u + (column_turn + 1u) / 2u : (columns - 1u) / 2u - (column_turn + 1u) / 2u;
-    const uint32_t strip_row = (blockIdx.y & 1u) ? (rows - 1u) / 2u + (blockIdx.y + 1u) / 2u : (rows - 1u) / 2u - (blockIdx.y + 1u) / 2u;
+    const TileOrder o = tile_order(num_passes, RZ_BIN / (8 * STRIP));
+    const uint32_t pass_index = o.pass, tile_column = o.column, strip_row = o.row;
     const PassParams P = passes[pass_index];
     const int sy0 = (int)strip_row * 8 * STRIP;
     if ((int)tile_column >= P.tiles_x || sy0 >= P.height) return;
