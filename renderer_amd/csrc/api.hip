@@ -169,6 +169,7 @@ struct Context {
     int micro_min_list = 256;               /* MI355R_MICRO_MIN_LIST: ... only in bins with at least this many list entries */
     int sky_pixels_per_lane = 2;            /* MI355R_SKY_PPL=1: the one-pixel-per-lane skybox kernel */
     bool strip_sky = false;                 /* MI355R_STRIP_SKY=1: rz_strip_kernel shades skybox fragments in place (measured: slower) */
+    bool sky_bins = true;                   /* MI355R_SKY_BINS=0: bins that hold only skybox triangles go through rz_strip_kernel like any other */
     unsigned strip_long = 2048;             /* MI355R_STRIP_LONG: a batch whose framebuffers had a bin list of this many entries in their last frame takes one block per wave,
                                              * of half as many two; 0, or MI355R_STRIP set = always `strip` */
     int strip = 4;                          /* MI355R_STRIP: 16x8 blocks a wave of rz_strip_kernel takes (8, 4, 2, 1); 0 = rz_visibility_kernel + rz_sky_kernel */
@@ -298,6 +299,8 @@ extern "C" int mi355r_init(int device) {
         if (env) { const int v = atoi(env); g.strip = (v == 8 || v == 4 || v == 2 || v == 1) ? v : 0; g.strip_long = 0; }
         env = getenv("MI355R_STRIP_SKY");
         if (env) g.strip_sky = atoi(env) != 0;
+        env = getenv("MI355R_SKY_BINS");
+        if (env) g.sky_bins = atoi(env) != 0;
         env = getenv("MI355R_STRIP_LONG");
         if (env) g.strip_long = (unsigned)atoi(env);
         env = getenv("MI355R_SPLIT_BLEND");
@@ -1723,7 +1726,7 @@ static void launch_batch(const Batch &b, const std::vector<PassPlan> &plans, cha
      * blended fragments pile up and the shade kernels for the rest */
     const bool one_family = !g.generic_blend;
     const int only = !one_family ? -1 : b.families == (1 << RZ_FAMILY_BLINN) ? 0 : b.families == (1 << RZ_FAMILY_PBR) ? 1 : -1;
-    bool in_strips = false, sky_done = false;       /* the shade lists hold 16x8 blocks; skybox fragments are shaded already */
+    bool in_strips = false, sky_done = false, sky_bins = false;       /* the shade lists hold 16x8 blocks; skybox fragments are shaded already */
     if (b.has_blend && !splits_blend(batch_tiles, n)) {
         auto kernel = rz_raster_kernel<false>;
         if (only == 0) kernel = narrow ? rz_raster_kernel<false, 0, true> : rz_raster_kernel<false, 0, false>;
@@ -1757,14 +1760,18 @@ static void launch_batch(const Batch &b, const std::vector<PassPlan> &plans, cha
             sky_done = g.strip_sky;
             auto kernel = g.strip_sky ? (strip == 8 ? rz_strip_kernel<8, true> : strip == 4 ? rz_strip_kernel<4, true> : strip == 2 ? rz_strip_kernel<2, true> : rz_strip_kernel<1, true>)
                                       : (strip == 8 ? rz_strip_kernel<8, false> : strip == 4 ? rz_strip_kernel<4, false> : strip == 2 ? rz_strip_kernel<2, false> : rz_strip_kernel<1, false>);
+            /* bins with nothing but skybox triangles are left to rz_sky_kernel */
+            sky_bins = g.sky_bins && !g.strip_sky && g.sky_pixels_per_lane == 2 && (b.families & (1 << RZ_FAMILY_SKYBOX));
+            if (sky_bins) rz_sky_regions_kernel<<<dim3((unsigned)max_bins, n), dim3(64), 0, st>>>(passes, L.bin_list.ptr, L.bin_range.ptr);
             if (g.verbose) fprintf(stderr, "mi355r: batch of %u passes, longest bin list last time %u entries, strips of %d\n", n, longest, strip);
             kernel<<<dim3(bin_columns * 2 * n, bin_rows * strips_per_bin), dim3(128), 0, st>>>(
-                passes, L.bin_list.ptr, L.bin_boxes.ptr, L.vary.ptr, L.fan_vary.ptr, db, L.bin_range.ptr, n);
+                passes, L.bin_list.ptr, L.bin_boxes.ptr, L.vary.ptr, L.fan_vary.ptr, db, L.bin_range.ptr, n, sky_bins ? 1u : 0u);
         }
         stamp();
         if ((b.families & (1 << RZ_FAMILY_SKYBOX)) && !sky_done) {
             if (g.sky_pixels_per_lane == 2)     /* four per lane: 11.9 us per frame against 11.1 */
-                rz_sky_kernel<2><<<tiles, dim3(128), 0, st>>>(passes, L.tri.ptr, L.fan_tri.ptr, L.vary.ptr, L.fan_vary.ptr, db, L.ref.ptr);
+                rz_sky_kernel<2><<<tiles, dim3(128), 0, st>>>(passes, L.tri.ptr, L.fan_tri.ptr, L.vary.ptr, L.fan_vary.ptr, db, L.ref.ptr,
+                                                              L.bin_list.ptr, L.bin_range.ptr, sky_bins ? 1u : 0u);
             else
                 rz_shade_kernel<2><<<tiles, dim3(256), 0, st>>>(passes, L.tri.ptr, L.fan_tri.ptr, L.vary.ptr, L.fan_vary.ptr, db, L.ref.ptr);
         }

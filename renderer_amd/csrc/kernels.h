@@ -1612,6 +1612,48 @@ __global__ void __launch_bounds__(256 / PPL) rz_visibility_kernel(const PassPara
     }
 }
 
+/* A bin whose list holds nothing but the triangles of one skybox draw (most of a frame around a model).
+ * Lists are ascending in the triangle's index and a draw's triangles are consecutive, so the first and the
+ * last entry tell.  For such a bin rz_strip_kernel does nothing at all and rz_sky_kernel resolves
+ * visibility itself: it needs the weights of the visible triangle for the shader anyway, the few
+ * entries come through scalar loads, and depth, reference and colour make no round trip between two
+ * kernels.  Not while fragments are counted (the counts belong to the rasteriser's stage). */
+#define RZ_SKY_ONLY_MAX 8u
+RZ_DEV bool sky_only_bin(const PassParams &P, const BinEntry *list, uint32_t count) {
+    if (count == 0u || count > RZ_SKY_ONLY_MAX || P.counters || P.debug_skip) return false;
+    const uint32_t first = list[0].rec.meta, last = list[count - 1u].rec.meta;
+    return RZ_META_FAMILY(first) == 2u && RZ_META_FAMILY(last) == 2u && RZ_META_DRAW(first) == RZ_META_DRAW(last);
+}
+/* A wave of rz_sky_kernel takes a REGION of 32x4 pixels, 32 of them in a bin.  Which entries of the
+ * list can touch which region (box and conservative edge test, as rz_strip_kernel culls its blocks) is
+ * found once per bin, lane = region, by rz_sky_regions_kernel, and kept in the entry's spare word: the two triangles of a sky box face share their box, and testing both in every pixel of
+ * the face cost the sky kernel a third of its time again. */
+RZ_DEV uint32_t sky_region_of(int tx0, int ry0) { return (uint32_t)(((ry0 % RZ_BIN) / 4) * 2 + (tx0 % RZ_BIN) / RZ_TILE_W); }
+RZ_DEV void sky_bin_regions(const BinEntry *list, uint32_t count, int bin_x0, int bin_y0) {
+    const int lane = threadIdx.x & 63;
+    const int rx0 = bin_x0 + RZ_TILE_W * (lane & 1), ry0 = bin_y0 + 4 * ((lane >> 1) & 15);
+    for (uint32_t e = 0; e < count; e++) {
+        const float4 *q = (const float4*)&list[e];
+        const float4 c0 = q[1], c1 = q[2];
+        const uint2 box = entry_box(q[4]);
+        const bool hit = box_overlaps(make_uint2(box.x, box.y & 0x7fffffffu), rx0, ry0, rx0 + RZ_TILE_W - 1, ry0 + 3) &&
+                         !block_outside(c0, c1, (float)rx0 + 0.5f, (float)(rx0 + RZ_TILE_W - 1) + 0.5f, (float)ry0 + 0.5f, (float)ry0 + 3.5f);
+        const uint32_t mask = (uint32_t)__ballot(hit && lane < 32);
+        if (lane == 0) const_cast<BinEntry*>(list)[e].pad[0] = mask;
+    }
+}
+
+/* one wave per bin of every pass of the batch (grid x = bin, y = pass) */
+__global__ void __launch_bounds__(64) rz_sky_regions_kernel(const PassParams *__restrict__ passes,
+        const BinEntry *__restrict__ list_base, const uint2 *__restrict__ bin_range_base) {
+    const PassParams &P = passes[blockIdx.y];
+    if ((int)blockIdx.x >= P.bins_x * P.bins_y || P.control[2] != 0u) return;
+    const uint2 range = (bin_range_base + P.bin_off)[blockIdx.x];
+    const BinEntry *list = list_base + P.list_off + range.x;
+    if (!sky_only_bin(P, list, range.y)) return;
+    sky_bin_regions(list, range.y, (int)(blockIdx.x % (uint32_t)P.bins_x) * RZ_BIN, (int)(blockIdx.x / (uint32_t)P.bins_x) * RZ_BIN);
+}
+
 /* K4c  visibility AND skybox shading for passes without blending, a STRIP of blocks per wave.
  *
  * rz_visibility_kernel spends its time waiting: a wave lives for some 14 000 cycles and issues 700
@@ -1643,7 +1685,8 @@ template <int STRIP, bool SKY>
 __global__ void __launch_bounds__(128) rz_strip_kernel(const PassParams *__restrict__ passes,
         const BinEntry *__restrict__ list_base, const uint2 *__restrict__ box_base,
         const float *__restrict__ vary_base, const float *__restrict__ fan_vary_base,
-        const char *__restrict__ upload_base, const uint2 *__restrict__ bin_range_base, uint32_t num_passes) {
+        const char *__restrict__ upload_base, const uint2 *__restrict__ bin_range_base, uint32_t num_passes,
+        uint32_t sky_bins_elsewhere) {
     constexpr int PPL = 2;
     static_assert(RZ_BIN % (8 * STRIP) == 0, "a strip lies inside one bin");
     const TileOrder o = tile_order(num_passes, RZ_BIN / (8 * STRIP));
@@ -1681,6 +1724,7 @@ __global__ void __launch_bounds__(128) rz_strip_kernel(const PassParams *__restr
     }
     const BinEntry *list = list_table + range.x;
     const uint2 *boxes = box_base + P.list_off + range.x;
+    if (!SKY && sky_bins_elsewhere && sky_only_bin(P, list, count)) return;     /* rz_sky_kernel does all of it */
 
     /* small triangles, one per lane, into per-pixel keys in LDS: see rz_visibility_kernel */
     __shared__ unsigned long long micro_keys[256];
@@ -2039,27 +2083,113 @@ template <int PPL>
 __global__ void __launch_bounds__(256 / PPL) rz_sky_kernel(const PassParams *__restrict__ passes,
         const TriRec *__restrict__ tri_base, const TriRec *__restrict__ fan_base,
         const float *__restrict__ vary_base, const float *__restrict__ fan_vary_base,
-        const char *__restrict__ upload_base, const uint32_t *__restrict__ ref_base) {
+        const char *__restrict__ upload_base, const uint32_t *__restrict__ ref_base,
+        const BinEntry *__restrict__ list_base, const uint2 *__restrict__ bin_range_base, uint32_t sky_bins_here) {
     const PassParams P = passes[blockIdx.z];
     if ((int)blockIdx.x >= P.tiles_x || (int)blockIdx.y >= P.tiles_y) return;
     if (P.control[2] != 0u) return;                   /* the pass did not run: its reference plane holds nothing */
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = (int)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const TriRec *tri_table = tri_base + P.tri_off;
     const TriRec *fan_table = fan_base + (size_t)P.fan_off * RZ_MAX_FAN;
     const float *vary_table = vary_base + (size_t)P.tri_off * 3 * RZ_VARY_STRIDE;
     const float *fan_vary_table = fan_vary_base + (size_t)P.fan_off * RZ_MAX_POLY * RZ_VARY_STRIDE;
     const DrawRec *draw_table = (const DrawRec*)(upload_base + P.draws_off);
     const uint32_t *ref_table = ref_base + P.ref_off;
-    const int px = (int)blockIdx.x * RZ_TILE_W + (lane & 31);
+    const int tx0 = (int)blockIdx.x * RZ_TILE_W, ry0 = (int)blockIdx.y * RZ_TILE_H + wave * 2 * PPL;
+    const int px = tx0 + (lane & 31);
     int py[PPL];
     uint32_t pixel[PPL], myref[PPL];
     bool want[PPL];
     bool any_want = false;
     for (int q = 0; q < PPL; q++) {
-        py[q] = (int)blockIdx.y * RZ_TILE_H + wave * 2 * PPL + 2 * q + (lane >> 5);
+        py[q] = ry0 + 2 * q + (lane >> 5);
         pixel[q] = (uint32_t)py[q] * (uint32_t)P.width + (uint32_t)px;
-        myref[q] = (px < P.width && py[q] < P.height && !P.debug_skip) ? ref_table[pixel[q]] : RZ_REF_NONE;
     }
+    if (sky_bins_here) {
+        const uint2 range = (bin_range_base + P.bin_off)[(ry0 / RZ_BIN) * P.bins_x + tx0 / RZ_BIN];   /* {first entry, entries} */
+        const BinEntry *list = list_base + P.list_off + range.x;
+        const uint32_t count = range.y;
+        if (sky_only_bin(P, list, count)) {
+            /* visibility as in rz_strip_kernel (graphics.c:512-532), every entry through scalar loads */
+            bool valid[PPL];
+            float zcur[PPL], w[PPL][3];
+            int win[PPL];
+            for (int q = 0; q < PPL; q++) {
+                valid[q] = px < P.width && py[q] < P.height;
+                zcur[q] = P.clear_depth;
+                if (valid[q] && !P.clear_depth_pending) zcur[q] = P.depth[pixel[q]];
+                win[q] = -1;
+                w[q][0] = w[q][1] = w[q][2] = 0;
+            }
+            static_assert(PPL == 2, "a wave's region is 32x4 pixels");
+            const uint32_t region = sky_region_of(tx0, ry0);
+            for (uint32_t e = 0; e < count; e++) {
+                if (!((list[e].pad[0] >> region) & 1u)) continue;       /* uniform: sky_bin_regions */
+                const TriRec r = list[e].rec;
+                const int x0 = (int)(r.bx & 0xffffu), x1 = (int)(r.bx >> 16);
+                const int y0 = (int)(r.by & 0xffffu), y1 = (int)(r.by >> 16);
+                for (int q = 0; q < PPL; q++) {
+                    float w0, w1, w2;
+                    pixel_weights(r, px, py[q], w0, w1, w2);
+                    const bool inside = valid[q] && py[q] >= y0 && py[q] <= y1 && px >= x0 && px <= x1 &&
+                                        w0 > -RZ_EPS && w1 > -RZ_EPS && w2 > -RZ_EPS;                 /* :516-519 */
+                    const float depth = r.z[0] * w0 + r.z[1] * w1 + r.z[2] * w2;                  /* :403-408 */
+                    if (inside && depth <= zcur[q]) {                                             /* :523 */
+                        zcur[q] = depth; win[q] = (int)e;
+                        w[q][0] = w0; w[q][1] = w1; w[q][2] = w2;
+                    }
+                }
+            }
+            uint32_t ccur[PPL];
+            for (int q = 0; q < PPL; q++) {
+                want[q] = win[q] >= 0;
+                any_want |= want[q];
+                if (valid[q] && (want[q] || P.clear_depth_pending)) P.depth[pixel[q]] = zcur[q];       /* else: what was there */
+                if (valid[q] && P.clear_color_pending && !want[q]) P.color[pixel[q]] = P.clear_color;
+                /* the colour below only lends its alpha byte; under a pending clear it is the clear colour */
+                ccur[q] = P.clear_color;
+                if (want[q] && !P.clear_color_pending) ccur[q] = P.color[pixel[q]];
+            }
+            if (!__any(any_want)) return;
+            int mine = -1;
+            for (int q = PPL - 1; q >= 0; q--) if (want[q]) mine = win[q];
+            const int first = __builtin_amdgcn_readlane(mine, __ffsll((long long)__ballot(any_want)) - 1);
+            bool uniform = true;
+            for (int q = 0; q < PPL; q++) uniform = uniform && (!want[q] || win[q] == first);
+            if (__all(uniform)) {
+                const BinEntry *e = &list[first];
+                const TriRec m = e->rec;
+                const float *m0, *m1, *m2;
+                ref_varyings(e->tri, vary_table, fan_vary_table, m0, m1, m2);
+                const DrawRec &D = draw_table[RZ_META_DRAW(m.meta)];
+                for (int q = 0; q < PPL; q++) {
+                    if (!want[q]) continue;
+                    float v[4];
+                    const float q0 = m.rw[0] * w[q][0], q1 = m.rw[1] * w[q][1], q2 = m.rw[2] * w[q][2];    /* graphics.c:426-429 */
+                    const float norm = 1 / (q0 + q1 + q2);
+                    interpolate_lane<3>(m0, m1, m2, q0, q1, q2, norm, v);
+                    f4 color = fs_skybox(D, v);
+                    color = mk4(d_sat(color.x), d_sat(color.y), d_sat(color.z), d_sat(color.w));     /* graphics.c:452-468 */
+                    P.color[pixel[q]] = pack_rgb(color, ccur[q]);
+                }
+                return;
+            }
+            for (int q = 0; q < PPL; q++) {                 /* an edge of the sky box crosses the wave */
+                if (!__any(want[q])) continue;
+                TriRec m;
+                const float *m0 = vary_table, *m1 = vary_table, *m2 = vary_table;
+                if (want[q]) {
+                    m = load_tri(&list[win[q]].rec);
+                    ref_varyings(list[win[q]].tri, vary_table, fan_vary_table, m0, m1, m2);
+                }
+                shade_lanes<2>(P, draw_table, want[q], m, m0, m1, m2, px, py[q], ccur[q]);
+                if (want[q]) P.color[pixel[q]] = ccur[q];
+            }
+            return;
+        }
+    }
+    for (int q = 0; q < PPL; q++)
+        myref[q] = (px < P.width && py[q] < P.height && !P.debug_skip) ? ref_table[pixel[q]] : RZ_REF_NONE;
     for (int q = 0; q < PPL; q++) {
         want[q] = ((myref[q] >> 28) & 3u) == 2u;        /* RZ_REF_NONE reads as family 3 */
         any_want |= want[q];
