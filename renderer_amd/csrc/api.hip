@@ -87,6 +87,10 @@ struct Tex {
     std::vector<hipEvent_t> read_events;
     /* a copy from a framebuffer that is recorded but not launched yet will fill the image; and
      * the flush (Context::flush_epoch) during whose recording a draw last referred to it */
+    /* skybox faces: the bytes a fragment showing the texel leaves in a framebuffer (RZ_TEX_DISPLAY8), in the
+     * image's layout; made when the texture is first drawn as a sky, again when the image has changed */
+    uint32_t *d_display = nullptr;
+    bool display_valid = false;
     bool pending_write = false;
     unsigned long long used_epoch = ~0ull;
     unsigned long long write_seq = 0;       /* order of the writes on a lane: waiting for a later one covers the earlier ones */
@@ -163,6 +167,7 @@ struct Context {
     Lane lanes[MAX_LANES];
     int num_lanes = 1, next_lane = 0;
     size_t max_batch = 32;                  /* passes per launch sequence */
+    bool sky_bytes = true;                  /* MI355R_SKY_BYTES=0: skybox fragments fetch the face's texel and convert it themselves */
     bool pack_textures = true;              /* MI355R_PACK=0: keep every image as float4 */
     bool narrow_raster = false;             /* MI355R_NARROW_RASTER=1: one pixel per lane in the visibility pass */
     int pixels_per_lane = 2;                /* MI355R_PPL=4: a wave takes the whole 32x8 tile */
@@ -299,6 +304,8 @@ extern "C" int mi355r_init(int device) {
         if (env) { const int v = atoi(env); g.strip = (v == 8 || v == 4 || v == 2 || v == 1) ? v : 0; g.strip_long = 0; }
         env = getenv("MI355R_STRIP_SKY");
         if (env) g.strip_sky = atoi(env) != 0;
+        env = getenv("MI355R_SKY_BYTES");
+        if (env) g.sky_bytes = atoi(env) != 0;
         env = getenv("MI355R_SKY_BINS");
         if (env) g.sky_bins = atoi(env) != 0;
         env = getenv("MI355R_STRIP_LONG");
@@ -560,6 +567,7 @@ extern "C" void texture_release(rz_texture *p) {                    /* texture.c
     sync_stream();
     drop_derived_handles();
     if (t->d_data) HIP_OK(hipFree(t->d_data));
+    if (t->d_display) HIP_OK(hipFree(t->d_display));
     if (t->host_pinned) (void)hipHostUnregister(t->pub.buffer);
     free(t->pub.buffer);
     g.texs.erase(t);
@@ -584,6 +592,7 @@ static void device_image(Tex *t, int flags_wanted, size_t texel_bytes) {
         HIP_OK(hipMalloc(&t->d_data, bytes));
         t->d_bytes = bytes;
     }
+    t->display_valid = false;       /* every caller is about to write the image */
     t->flags = flags;
     t->mbits = mbits;
 }
@@ -703,6 +712,25 @@ static void upload_texture(Tex *t) {
     HIP_OK(hipFree(staging));
     t->device_stale = false;
     t->host_stale = false;
+}
+
+/* the face of a skybox as its RZ_TEX_DISPLAY8 plane; false: this image is sampled as it is (one the GPU
+ * writes: the plane would have to follow every write) */
+static bool dev_tex_display(rz_texture *p, DevTex *d) {
+    Tex *t = as_tex(p);
+    if (!g.sky_bytes || t->write_lane >= 0 || t->pending_write || !t->d_data) return false;
+    const size_t n = (size_t)t->pub.width * t->pub.height;
+    if (!t->display_valid) {
+        /* an image that was replaced has no reader left (upload_texture waited for them) */
+        if (!t->d_display) HIP_OK(hipMalloc((void**)&t->d_display, n * sizeof(uint32_t)));
+        rz_texture_display_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, g.stream>>>(t->d_data, t->d_display, n, t->flags);
+        HIP_OK(hipGetLastError());
+        HIP_OK(hipStreamSynchronize(g.stream));
+        t->display_valid = true;
+    }
+    d->data = t->d_display;
+    d->flags = (t->flags & RZ_TEX_LAYOUT) | RZ_TEX_DISPLAY8;
+    return true;
 }
 
 static DevTex dev_tex(rz_texture *p) {
@@ -1056,6 +1084,15 @@ static void snapshot_uniforms_once(rz_program *p, Pending &pd, int num_joints) {
         for (int i = 0; i < 6; i++) {
             r.maps[i] = dev_tex(u->skybox->faces[i]);
             uniform = uniform && r.maps[i].w == r.maps[0].w && r.maps[i].h == r.maps[0].h && r.maps[i].flags == r.maps[0].flags;
+        }
+        if (!p->blend) {            /* all six faces as display bytes, or none */
+            DevTex shown[6];
+            bool all = true;
+            for (int i = 0; i < 6 && all; i++) { shown[i] = r.maps[i]; all = dev_tex_display(u->skybox->faces[i], &shown[i]); }
+            if (all) {
+                for (int i = 0; i < 6; i++) { r.maps[i] = shown[i]; uniform = uniform && shown[i].flags == shown[0].flags; }
+                r.flags |= RZ_DRAW_SKY_BYTES;
+            }
         }
         if (uniform) r.flags |= RZ_DRAW_UNIFORM_CUBE;
     } else if (p->family == RZ_FAMILY_BLINN) {

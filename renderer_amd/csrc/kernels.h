@@ -880,6 +880,25 @@ RZ_DEV uint32_t pack_rgb(f4 c, uint32_t keep) {                 /* float_to_ucha
     return r | (g << 8) | (b << 16) | (keep & 0xff000000u);
 }
 
+/* What draw_fragment leaves in the framebuffer for a skybox fragment (graphics.c:452-468; the program
+ * does not blend): the shader's colour is its cube map's texel, so saturating it, scaling by 255 and
+ * truncating is a function of the texel alone -- worked out once per texel when the map is first drawn
+ * (rz_texture_display_kernel), the fragment then fetches 4 bytes instead of 16 and converts nothing. */
+RZ_DEV uint32_t sky_fragment(const DrawRec &D, const float *v, uint32_t below) {
+    if (D.flags & RZ_DRAW_SKY_BYTES) {
+        float s, t;
+        const int face = cube_face(mk3(v[0], v[1], v[2]), &s, &t);
+        DevTex f = (D.flags & RZ_DRAW_UNIFORM_CUBE) ? D.maps[0] : D.maps[face];
+        f.data = D.maps[face].data;
+        const float x = s, y = 1 - t;                               /* texture.c:257, 160-167 */
+        const uint32_t word = ((const uint32_t*)f.data)[texel_cell(f.w, f.h, f.flags, x - floorf(x), y - floorf(y))];
+        return (word & 0x00ffffffu) | (below & 0xff000000u);
+    }
+    f4 color = fs_skybox(D, v);
+    color = mk4(d_sat(color.x), d_sat(color.y), d_sat(color.z), d_sat(color.w));
+    return pack_rgb(color, below);
+}
+
 /* ---- deferred, order-exact shading ---------------------------------------
  *
  * The reference runs the fragment shader for every fragment that passes the
@@ -947,11 +966,16 @@ RZ_DEV void shade_lanes(const PassParams &P, const DrawRec *__restrict__ draw_ta
             float norm = 1 / (q0 + q1 + q2);
             bool backface = RZ_META_BACKFACE(m.meta) != 0;
             bool discard = false;
+            bool continue_to_count = false;                         /* the colour is in ccur already */
             f4 color = mk4(0, 0, 0, 0);
             if ((FAMILY < 0 || FAMILY == 2) && D.family == 2) {
                 float v[4];
                 interpolate_lane<3>(m0, m1, m2, q0, q1, q2, norm, v);
-                color = fs_skybox(D, v);
+                if (D.flags & RZ_DRAW_SKY_BYTES) {                  /* never set for a program that blends */
+                    ccur = sky_fragment(D, v, ccur);
+                    continue_to_count = true;
+                } else
+                    color = fs_skybox(D, v);
             } else if ((FAMILY < 0 || FAMILY == 0) && D.family == 0) {
                 float v[12];
                 interpolate_lane<11>(m0, m1, m2, q0, q1, q2, norm, v);
@@ -962,16 +986,18 @@ RZ_DEV void shade_lanes(const PassParams &P, const DrawRec *__restrict__ draw_ta
                 color = fs_pbr<NARROW>(D, v, backface, &discard);
             }
             /* draw_fragment (graphics.c:452-468); a discard was settled during rasterisation */
-            color = mk4(d_sat(color.x), d_sat(color.y), d_sat(color.z), d_sat(color.w));
-            if (D.flags & RZ_DRAW_BLEND) {
-                float dr = (float)(ccur & 0xffu) / 255.0f;
-                float dg = (float)((ccur >> 8) & 0xffu) / 255.0f;
-                float db = (float)((ccur >> 16) & 0xffu) / 255.0f;
-                color.x = color.x * color.w + dr * (1 - color.w);
-                color.y = color.y * color.w + dg * (1 - color.w);
-                color.z = color.z * color.w + db * (1 - color.w);
+            if (!continue_to_count) {
+                color = mk4(d_sat(color.x), d_sat(color.y), d_sat(color.z), d_sat(color.w));
+                if (D.flags & RZ_DRAW_BLEND) {
+                    float dr = (float)(ccur & 0xffu) / 255.0f;
+                    float dg = (float)((ccur >> 8) & 0xffu) / 255.0f;
+                    float db = (float)((ccur >> 16) & 0xffu) / 255.0f;
+                    color.x = color.x * color.w + dr * (1 - color.w);
+                    color.y = color.y * color.w + dg * (1 - color.w);
+                    color.z = color.z * color.w + db * (1 - color.w);
+                }
+                ccur = pack_rgb(color, ccur);
             }
-            ccur = pack_rgb(color, ccur);
         }
         if (P.counters) {       /* [8] fragments actually shaded on the device */
             unsigned long long n = (unsigned long long)__popcll(__ballot(sel));
@@ -1965,9 +1991,7 @@ __global__ void __launch_bounds__(128) rz_strip_kernel(const PassParams *__restr
                     const float q0 = m.rw[0] * w0, q1 = m.rw[1] * w1, q2 = m.rw[2] * w2;    /* graphics.c:426-429 */
                     const float norm = 1 / (q0 + q1 + q2);
                     interpolate_lane<3>(m0, m1, m2, q0, q1, q2, norm, v);
-                    f4 color = fs_skybox(D, v);
-                    color = mk4(d_sat(color.x), d_sat(color.y), d_sat(color.z), d_sat(color.w));     /* graphics.c:452-468; no blending in these passes */
-                    P.color[pixel[q]] = pack_rgb(color, ccur[q]);
+                    P.color[pixel[q]] = sky_fragment(D, v, ccur[q]);            /* no blending in these passes */
                 }
                 if (P.counters) {       /* [8] fragments shaded on the device, [9] of those, skybox */
                     unsigned long long n = 0;
@@ -2168,9 +2192,7 @@ __global__ void __launch_bounds__(256 / PPL) rz_sky_kernel(const PassParams *__r
                     const float q0 = m.rw[0] * w[q][0], q1 = m.rw[1] * w[q][1], q2 = m.rw[2] * w[q][2];    /* graphics.c:426-429 */
                     const float norm = 1 / (q0 + q1 + q2);
                     interpolate_lane<3>(m0, m1, m2, q0, q1, q2, norm, v);
-                    f4 color = fs_skybox(D, v);
-                    color = mk4(d_sat(color.x), d_sat(color.y), d_sat(color.z), d_sat(color.w));     /* graphics.c:452-468 */
-                    P.color[pixel[q]] = pack_rgb(color, ccur[q]);
+                    P.color[pixel[q]] = sky_fragment(D, v, ccur[q]);
                 }
                 return;
             }
@@ -2222,9 +2244,7 @@ __global__ void __launch_bounds__(256 / PPL) rz_sky_kernel(const PassParams *__r
             const float q0 = m.rw[0] * w0, q1 = m.rw[1] * w1, q2 = m.rw[2] * w2;    /* graphics.c:426-429 */
             const float norm = 1 / (q0 + q1 + q2);
             interpolate_lane<3>(m0, m1, m2, q0, q1, q2, norm, v);
-            f4 color = fs_skybox(D, v);
-            color = mk4(d_sat(color.x), d_sat(color.y), d_sat(color.z), d_sat(color.w));     /* graphics.c:452-468; no blending in these passes */
-            P.color[pixel[q]] = pack_rgb(color, ccur[q]);
+            P.color[pixel[q]] = sky_fragment(D, v, ccur[q]);                    /* no blending in these passes */
         }
         if (P.counters) {       /* [8] fragments shaded on the device, [9] of those, skybox */
             unsigned long long n = 0;
@@ -2361,6 +2381,17 @@ __global__ void rz_texture_tile32_kernel(const uint32_t *linear, uint32_t *texel
 }
 
 /* device layout -> row-major float4 (texture_sync) */
+/* the RZ_TEX_DISPLAY8 plane of an image, texel by texel in the image's own layout */
+__global__ void rz_texture_display_kernel(const void *texels, uint32_t *bytes, size_t count, int flags) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    f4 c;
+    if (flags & RZ_TEX_NARROW) c = decode_word(flags, __uint_as_float(((const uint32_t*)texels)[i]));
+    else { const float4 q = ((const float4*)texels)[i]; c = mk4(q.x, q.y, q.z, q.w); }
+    c = mk4(d_sat(c.x), d_sat(c.y), d_sat(c.z), d_sat(c.w));
+    bytes[i] = pack_rgb(c, 0u);
+}
+
 __global__ void rz_texture_untile_kernel(const void *texels, float4 *linear, int w, int h, int flags, int mbits) {
     int x = blockIdx.x * 16 + (threadIdx.x & 15), y = blockIdx.y * 16 + (threadIdx.x >> 4);
     if (x >= w || y >= h) return;

@@ -47,6 +47,9 @@ enum { RZ_TEX_TILED = 1, RZ_TEX_R32F = 2, RZ_TEX_UNORM8 = 4, RZ_TEX_SRGB8 = 8, R
        /* layouts tried against the 8x8 row-major tiles (MI355R_TEX_LAYOUT=1 / 2): 16x16 tiles; 8x8 tiles with the
         * texel's column and row bits interleaved (Z order) */
        RZ_TEX_TILE16 = 32, RZ_TEX_MORTON = 64,
+       /* not an image format but a plane derived from one: per texel the three bytes draw_fragment writes for
+        * its colour (saturate, * 255, truncate: graphics.c:452-468, maths.c:33), for skybox faces */
+       RZ_TEX_DISPLAY8 = 128,
        RZ_TEX_LAYOUT = RZ_TEX_TILED | RZ_TEX_TILE16 | RZ_TEX_MORTON };
 
 /* a sampled image; data == nullptr means "no map bound" */
@@ -71,7 +74,8 @@ enum {
     RZ_DRAW_SHADOW_PASS = 4,
     RZ_DRAW_SKINNED = 8,
     RZ_DRAW_UNIFORM_CUBE = 16,      /* skybox: the six faces have one size and format */
-    RZ_DRAW_NARROW_TEXELS = 32      /* blinn / pbr: every image the draw samples has a 4-byte format (or is absent) */
+    RZ_DRAW_NARROW_TEXELS = 32,     /* blinn / pbr: every image the draw samples has a 4-byte format (or is absent) */
+    RZ_DRAW_SKY_BYTES = 64          /* skybox: maps[] are the faces' RZ_TEX_DISPLAY8 planes */
 };
 
 struct DrawRec {

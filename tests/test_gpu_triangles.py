@@ -284,3 +284,109 @@ def test_gpu_invalidation_and_registered_shader_pairs(gpu, oracle):
     assert covered[0] == covered[1] > 500 and 0 < covered[2] < covered[0] // 2      # the mesh did shrink
     inside = got[0][1] < 1
     assert np.all(got[0][0][inside][:, :3] == [63, 127, 191]) and np.all(got[1][0][inside][:, :3] == [255, 31, 0])
+
+
+class Cubemap(C.Structure):
+    _fields_ = [("faces", C.POINTER(HostTexture) * 6)]
+
+
+CUBE_CORNERS = np.array([[x, y, z] for x in (-1, 1) for y in (-1, 1) for z in (-1, 1)], np.float32)
+CUBE_FACES = [(0, 1, 3, 2), (4, 6, 7, 5), (0, 4, 5, 1), (2, 3, 7, 6), (0, 2, 6, 4), (1, 5, 7, 3)]
+
+
+def look_from_inside(aspect, yaw, pitch):
+    """projection * rotation, row-major, for a camera at the cube's centre"""
+    f = 1.0 / np.tan(np.radians(35.0))
+    near, far = 0.1, 10.0
+    proj = np.array([[f / aspect, 0, 0, 0], [0, f, 0, 0],
+                     [0, 0, -(far + near) / (far - near), -2 * far * near / (far - near)], [0, 0, -1, 0]], np.float64)
+    cy, sy, cp, sp = np.cos(yaw), np.sin(yaw), np.cos(pitch), np.sin(pitch)
+    rot_y = np.array([[cy, 0, sy, 0], [0, 1, 0, 0], [-sy, 0, cy, 0], [0, 0, 0, 1]])
+    rot_x = np.array([[1, 0, 0, 0], [0, cp, -sp, 0], [0, sp, cp, 0], [0, 0, 0, 1]])
+    return (proj @ rot_x @ rot_y).astype(np.float32)
+
+
+@pytest.mark.parametrize("eight_bit", [False, True], ids=["float_faces", "eight_bit_faces"])
+def test_skybox_of_caller_made_faces_replaced_between_frames(gpu, oracle, eight_bit):
+    """A sky box seen from inside, its cube map made of six textures the caller fills by hand (values
+    below 0 and above 1 among them: draw_fragment saturates, graphics.c:452), one opaque triangle in
+    front of part of it, several views into framebuffers that are used again -- then two faces get new
+    texels (texture_invalidate) and the views are drawn once more.  Whatever the library derives from
+    a face's image has to follow the image."""
+    size, views = (320, 200), [(0.3, 0.2), (2.1, -0.4), (4.0, 1.2), (5.5, -1.3)]
+    rng = np.random.default_rng(77)
+    if eight_bit:
+        images = [rng.integers(0, 256, (32, 32, 4)).astype(np.float32) / np.float32(255) for _ in range(8)]
+    else:
+        images = [rng.uniform(-0.25, 1.5, (32, 32, 4)).astype(np.float32) for _ in range(8)]
+    results = []
+    for pipe in (gpu, oracle):
+        lib = pipe.lib
+        declare(lib)
+        P = C.c_void_p
+        lib.texture_create.restype = C.POINTER(HostTexture)
+        lib.texture_create.argtypes = [C.c_int, C.c_int]
+        lib.texture_release.argtypes = [C.POINTER(HostTexture)]
+        lib.texture_invalidate.argtypes = [C.POINTER(HostTexture)]
+        cube = Cubemap()
+        texels = []
+        for i in range(6):
+            cube.faces[i] = lib.texture_create(32, 32)
+            texels.append(np.ctypeslib.as_array(cube.faces[i].contents.buffer, (32, 32, 4)))
+            texels[i][...] = images[i]
+            lib.texture_invalidate(cube.faces[i])
+        sky = lib.program_create(fn(lib, "skybox_vertex_shader"), fn(lib, "skybox_fragment_shader"), 12, 12, 72, 1, 0)
+        su = SkyboxUniforms.from_address(lib.program_get_uniforms(sky))
+        su.skybox = C.cast(C.pointer(cube), P)
+        front = lib.program_create(fn(lib, "blinn_vertex_shader"), fn(lib, "blinn_fragment_shader"), 64, 44, 344, 1, 0)
+        bu = BlinnUniforms.from_address(lib.program_get_uniforms(front))
+        bu.light_dir[:] = [0.0, 0.0, -1.0]
+        bu.camera_pos[:] = [0.0, 0.0, 2.0]
+        bu.model_matrix[:] = IDENTITY4[:]
+        bu.normal_matrix[:] = IDENTITY3[:]
+        bu.light_vp_matrix[:] = IDENTITY4[:]
+        bu.camera_vp_matrix[:] = IDENTITY4[:]
+        bu.ambient_intensity = 1.0
+        bu.punctual_intensity = 0.0
+        bu.shininess = 4.0
+        bu.basecolor[:] = [0.9, 0.4, 0.1, 1.0]
+        fbs = [pipe.framebuffer(*size) for _ in views]
+
+        def draw_all():
+            for fb, (yaw, pitch) in zip(fbs, views):
+                lib.framebuffer_clear_color(fb, Vec4(0.0, 0.0, 0.0, 1.0))
+                lib.framebuffer_clear_depth(fb, 1.0)
+                for j, (x, y) in enumerate([(-0.3, -0.2), (0.35, -0.25), (0.05, 0.4)]):
+                    a = BlinnAttribs.from_address(lib.program_get_attribs(front, j))
+                    a.position[:] = [x, y, 0.0]
+                    a.texcoord[:] = [0.5, 0.5]
+                    a.normal[:] = [0.0, 0.0, 1.0]
+                    a.joint[:] = [0, 0, 0, 0]
+                    a.weight[:] = [0, 0, 0, 0]
+                lib.graphics_draw_triangle(C.cast(fb, P), front)
+                su.vp_matrix[:] = [float(x) for x in look_from_inside(size[0] / size[1], yaw, pitch).reshape(-1)]
+                for quad in CUBE_FACES:
+                    for tri in ((quad[0], quad[1], quad[2]), (quad[0], quad[2], quad[3])):
+                        for j in range(3):
+                            (C.c_float * 3).from_address(lib.program_get_attribs(sky, j))[:] = [float(x) for x in CUBE_CORNERS[tri[j]]]
+                        lib.graphics_draw_triangle(C.cast(fb, P), sky)
+            return [pipe.read(fb) for fb in fbs]
+
+        frames = draw_all()
+        texels[0][...] = images[6]
+        texels[3][...] = images[7]
+        lib.texture_invalidate(cube.faces[0])
+        lib.texture_invalidate(cube.faces[3])
+        frames += draw_all()
+        for fb in fbs:
+            pipe.release(fb)
+        lib.program_release(sky)
+        lib.program_release(front)
+        for i in range(6):
+            lib.texture_release(cube.faces[i])
+        results.append(frames)
+    for got, want in zip(*results):
+        assert same(got, want)
+    n = len(views)
+    assert any(not same(results[1][i], results[1][n + i]) for i in range(n))       # the new faces are in view somewhere
+    assert all(int((f[1] < 0.9).sum()) > 1000 for f in results[0])                  # the triangle in front is there

@@ -141,7 +141,7 @@ sys.exit(0 if bad == 0 else 1)
 @pytest.mark.parametrize("env", [{"MI355R_PACK": "0"}, {"MI355R_NARROW_RASTER": "1"}, {"MI355R_PPL": "4"},
                                  {"MI355R_LANES": "1", "MI355R_BATCH": "1"}, {"MI355R_MONOLITHIC": "1"},
                                  {"MI355R_MICRO_AREA": "0"}, {"MI355R_MICRO_MIN_LIST": "0"}, {"MI355R_RECORD_COPIES": "0"}, {"MI355R_STRIP": "0"}, {"MI355R_STRIP": "0", "MI355R_SKY_PPL": "1"},
-                                 {"MI355R_STRIP": "4"}, {"MI355R_SKY_BINS": "0"}, {"MI355R_STRIP": "2"}, {"MI355R_STRIP_LONG": "1"}, {"MI355R_STRIP_LONG": "600"}, {"MI355R_STRIP": "1", "MI355R_MICRO_MIN_LIST": "0"}, {"MI355R_STRIP": "0", "MI355R_MICRO_MIN_LIST": "0"}, {"MI355R_GENERIC_BLEND": "1"}, {"MI355R_TEX_LAYOUT": "1"}, {"MI355R_TEX_LAYOUT": "2"}, {"MI355R_SPLIT_BLEND": "0"}, {"MI355R_SPLIT_BLEND": "1"},
+                                 {"MI355R_STRIP": "4"}, {"MI355R_SKY_BINS": "0"}, {"MI355R_SKY_BYTES": "0"}, {"MI355R_STRIP": "2"}, {"MI355R_STRIP_LONG": "1"}, {"MI355R_STRIP_LONG": "600"}, {"MI355R_STRIP": "1", "MI355R_MICRO_MIN_LIST": "0"}, {"MI355R_STRIP": "0", "MI355R_MICRO_MIN_LIST": "0"}, {"MI355R_GENERIC_BLEND": "1"}, {"MI355R_TEX_LAYOUT": "1"}, {"MI355R_TEX_LAYOUT": "2"}, {"MI355R_SPLIT_BLEND": "0"}, {"MI355R_SPLIT_BLEND": "1"},
                                  {"MI355R_MICRO_MIN_LIST": "0", "MI355R_MICRO_AREA": "128", "MI355R_PPL": "4"}],
                          ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()))
 def test_gpu_alternative_code_paths_give_the_same_frames(gpu, env):
