@@ -77,7 +77,7 @@ __global__ void __launch_bounds__(256) rz_vertex_kernel(const PassParams *__rest
     int d = find_draw(P.first_tri, P.num_draws, gv / 3u);
     const DrawRec &D = P.draws[d];
     uint32_t local = gv - 3u * P.first_tri[d];
-    const float4 *src = (const float4*)((const char*)D.vertices + (size_t)local * 80u);
+    const float4 RZ_GLOBAL *src = (const float4 RZ_GLOBAL*)(D.vertices.as<const char>() + (size_t)local * 80u);
     float a[20];                    /* position 0-2, texcoord 3-4, normal 5-7, tangent 8-11, joint 12-15, weight 16-19 */
     for (int i = 0; i < 5; i++) {
         float4 q = src[i];
@@ -144,7 +144,7 @@ __global__ void __launch_bounds__(256) rz_vertex_kernel(const PassParams *__rest
             }
         }
     }
-    ((float4*)P.clip)[gv] = make_float4(clip.x, clip.y, clip.z, clip.w);
+    P.clip.as<float4>()[gv] = make_float4(clip.x, clip.y, clip.z, clip.w);
 }
 
 /* ========================================================================
@@ -405,7 +405,7 @@ __global__ void __launch_bounds__(256) rz_setup_kernel(const PassParams *__restr
                                 ((uint32_t)D.family << 24);
     f4 c[3];
     for (int i = 0; i < 3; i++) {
-        float4 q = ((const float4*)P.clip)[3u * t + i];
+        float4 q = P.clip.as<const float4>()[3u * t + i];
         c[i] = mk4(q.x, q.y, q.z, q.w);
     }
     uint2 empty = make_uint2(RZ_BBOX_EMPTY_X, RZ_BBOX_EMPTY_X);
@@ -891,7 +891,7 @@ RZ_DEV uint32_t sky_fragment(const DrawRec &D, const float *v, uint32_t below) {
         DevTex f = (D.flags & RZ_DRAW_UNIFORM_CUBE) ? D.maps[0] : D.maps[face];
         f.data = D.maps[face].data;
         const float x = s, y = 1 - t;                               /* texture.c:257, 160-167 */
-        const uint32_t word = ((const uint32_t*)f.data)[texel_cell(f.w, f.h, f.flags, x - floorf(x), y - floorf(y))];
+        const uint32_t word = f.data.as<const uint32_t>()[texel_cell(f.w, f.h, f.flags, x - floorf(x), y - floorf(y))];
         return (word & 0x00ffffffu) | (below & 0xff000000u);
     }
     f4 color = fs_skybox(D, v);

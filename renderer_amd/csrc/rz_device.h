@@ -23,6 +23,24 @@
 
 #include <stdint.h>
 
+/* Pointers the kernels read out of these structures point into device memory, all of them.  Typed that way
+ * (address space 1) in the device pass, the compiler addresses through them with global_load / global_store
+ * -- scalar base plus a 32-bit lane offset -- instead of building a 64-bit flat address per lane and
+ * waiting on both memory counters.  On the host the same eight bytes are an ordinary pointer. */
+#if defined(__HIP_DEVICE_COMPILE__)
+#define RZ_GLOBAL __attribute__((address_space(1)))
+#else
+#define RZ_GLOBAL
+#endif
+template <class T> struct rz_gptr {
+    typedef T RZ_GLOBAL *type;
+    type p;
+    __host__ __device__ rz_gptr &operator=(T *q) { p = (type)q; return *this; }
+    __host__ __device__ operator type() const { return p; }
+    __host__ __device__ type operator->() const { return p; }
+    template <class U> __host__ __device__ U RZ_GLOBAL *as() const { return (U RZ_GLOBAL*)p; }     /* the same address, other element type */
+};
+
 #define RZ_VARY_STRIDE 24           /* floats per vertex in vary[] (max used: 21) */
 #define RZ_MAX_POLY 10              /* corners of a triangle clipped by 7 planes */
 #define RZ_MAX_FAN 8                /* RZ_MAX_POLY - 2 */
@@ -54,7 +72,7 @@ enum { RZ_TEX_TILED = 1, RZ_TEX_R32F = 2, RZ_TEX_UNORM8 = 4, RZ_TEX_SRGB8 = 8, R
 
 /* a sampled image; data == nullptr means "no map bound" */
 struct DevTex {
-    const void *data;
+    rz_gptr<const void> data;
     int32_t w, h;
     int32_t flags;                  /* RZ_TEX_* */
     int32_t reserved;
@@ -83,9 +101,9 @@ struct DrawRec {
     int32_t flags;                  /* RZ_DRAW_* */
     int32_t num_varyings;           /* floats: 11 blinn, 21 pbr, 3 skybox */
     int32_t num_faces;
-    const void *vertices;           /* rz_vertex[3 * num_faces] on the device */
-    const float *joints;            /* mat4[] for skinning or nullptr */
-    const float *joint_normals;     /* mat3[] or nullptr */
+    rz_gptr<const void> vertices;         /* rz_vertex[3 * num_faces] on the device */
+    rz_gptr<const float> joints;          /* mat4[] for skinning or nullptr */
+    rz_gptr<const float> joint_normals;    /* mat3[] or nullptr */
     /* uniforms common to blinn and pbr (blinn_shader.h:23-34, pbr_shader.h:39-50);
      * the skybox keeps its vp matrix in camera_vp */
     float light_dir[3];
@@ -106,8 +124,8 @@ struct DrawRec {
      * pbr {basecolor|diffuse, metalness|specular, roughness|glossiness,
      *      normal, occlusion, emission} */
     DevTex maps[6];
-    const DevIbl *ibl;
-    const DevTex *skybox;           /* 6 faces (the same six are in maps[] of a skybox draw) */
+    rz_gptr<const DevIbl> ibl;
+    rz_gptr<const DevTex> skybox;         /* 6 faces (the same six are in maps[] of a skybox draw) */
     int32_t workflow;               /* 0 metal-rough, 1 spec-gloss */
     float alpha_cutoff;
     int32_t layer_view;
@@ -147,37 +165,37 @@ struct BinEntry {
 
 struct PassParams {
     /* target */
-    uint32_t *color;                /* RGBA8, row 0 = bottom */
-    float *depth;
+    rz_gptr<uint32_t> color;                /* RGBA8, row 0 = bottom */
+    rz_gptr<float> depth;
     int32_t width, height;
     int32_t clear_color_pending, clear_depth_pending;
     uint32_t clear_color;
     float clear_depth;
     /* geometry */
-    const DrawRec *draws;
-    const uint32_t *first_tri;      /* num_draws + 1 */
+    rz_gptr<const DrawRec> draws;
+    rz_gptr<const uint32_t> first_tri;      /* num_draws + 1 */
     int32_t num_draws, num_tris;
-    float *clip;                    /* float4 per vertex */
-    float *vary;
-    TriRec *tri;
-    uint2 *bbox;
-    TriRec *fan_tri;                /* fan_capacity * RZ_MAX_FAN */
-    float *fan_vary;                /* fan_capacity * RZ_MAX_POLY * RZ_VARY_STRIDE */
+    rz_gptr<float> clip;                    /* float4 per vertex */
+    rz_gptr<float> vary;
+    rz_gptr<TriRec> tri;
+    rz_gptr<uint2> bbox;
+    rz_gptr<TriRec> fan_tri;                /* fan_capacity * RZ_MAX_FAN */
+    rz_gptr<float> fan_vary;                /* fan_capacity * RZ_MAX_POLY * RZ_VARY_STRIDE */
     int32_t fan_capacity;
-    uint32_t *clip_list;            /* triangles queued for the clipper (count in control[3]) */
+    rz_gptr<uint32_t> clip_list;            /* triangles queued for the clipper (count in control[3]) */
     /* binning */
     int32_t bins_x, bins_y;
-    uint32_t *bin_counts;           /* [chunks of 64 triangles][bins]: entries, then first entry */
-    uint2 *bin_range;               /* per bin: {first entry, entries} */
-    BinEntry *bin_list;
-    uint2 *bin_boxes;               /* per list entry: x0 | x1 << 16, y0 | y1 << 16 | alpha-cutoff << 31 -- all that walking a list reads */
+    rz_gptr<uint32_t> bin_counts;           /* [chunks of 64 triangles][bins]: entries, then first entry */
+    rz_gptr<uint2> bin_range;               /* per bin: {first entry, entries} */
+    rz_gptr<BinEntry> bin_list;
+    rz_gptr<uint2> bin_boxes;               /* per list entry: x0 | x1 << 16, y0 | y1 << 16 | alpha-cutoff << 31 -- all that walking a list reads */
     uint32_t bin_capacity;
-    uint32_t *ref;                  /* per pixel: reference of the visible fragment (split passes) */
+    rz_gptr<uint32_t> ref;                  /* per pixel: reference of the visible fragment (split passes) */
     int32_t ref_scanned;            /* a shade kernel of the batch reads the references of every tile (the skybox's) */
     /* scalars written by the device: [0] fan blocks used, [1] bin entries
      * used, [2] error bits, [3] triangles queued for clipping */
-    uint32_t *control;
-    unsigned long long *counters;   /* nullptr unless counting is enabled */
+    rz_gptr<uint32_t> control;
+    rz_gptr<unsigned long long> counters;   /* nullptr unless counting is enabled */
     int32_t debug_skip;             /* measurement only (MI355R_DEBUG_SKIP): 1 no shading, 2 no coverage tests either,
                                      * 3 no rasteriser at all, 4 the rasteriser without its walk over the bin lists */
     int32_t micro_area;             /* triangles whose box covers at most this many pixels of a wave's block
@@ -191,9 +209,9 @@ struct PassParams {
      * tile x) in RZ_QUEUE_WAYS parts of queue_capacity entries; lengths in
      * queue_counts[(family * RZ_QUEUE_WAYS + part) * RZ_QUEUE_PAD]; tile_listed[tile of this pass]:
      * bit f set = the tile is on family f's list */
-    uint32_t *tile_listed;
-    uint32_t *queue;
-    uint32_t *queue_counts;
+    rz_gptr<uint32_t> tile_listed;
+    rz_gptr<uint32_t> queue;
+    rz_gptr<uint32_t> queue_counts;
     uint32_t queue_capacity;
     uint32_t tile_off;              /* tiles before this pass in the batch */
     uint32_t tri_off;               /* triangles before this pass (vertices = 3x) */
@@ -208,7 +226,7 @@ struct PassParams {
      * first), and goes on counting what it needs.  A pass that may depend on another pass of the
      * flush (level > 0) and finds the flush's word set does not run either (RZ_ERR_SKIPPED).  The
      * host runs those passes again, in order, with scratch of the sizes they reported. */
-    uint32_t *flush_flag;
+    rz_gptr<uint32_t> flush_flag;
     int32_t level;                  /* 0: depends on no other pass of its flush */
     int32_t pad_;
 };
