@@ -87,13 +87,16 @@ struct Tex {
     std::vector<hipEvent_t> read_events;
     /* a copy from a framebuffer that is recorded but not launched yet will fill the image; and
      * the flush (Context::flush_epoch) during whose recording a draw last referred to it */
-    /* skybox faces: the bytes a fragment showing the texel leaves in a framebuffer (RZ_TEX_DISPLAY8), in the
-     * image's layout; made when the texture is first drawn as a sky, again when the image has changed */
-    uint32_t *d_display = nullptr;
-    bool display_valid = false;
+    unsigned long long image_version = 0;   /* counts the times the device image was (about to be) rewritten */
     bool pending_write = false;
     unsigned long long used_epoch = ~0ull;
     unsigned long long write_seq = 0;       /* order of the writes on a lane: waiting for a later one covers the earlier ones */
+};
+
+struct CubeDisplay {
+    uint32_t *d = nullptr;                  /* six faces of face_texels words each */
+    size_t face_texels = 0;
+    unsigned long long version[6] = {};     /* Tex::image_version of the faces it was made from */
 };
 
 struct rz_program {
@@ -211,6 +214,7 @@ struct Context {
     std::unordered_set<Tex*> texs;
     std::unordered_map<const void*, Mesh> meshes;
     std::unordered_map<const void*, DevTex*> cubes;     /* rz_cubemap* -> DevTex[6] */
+    std::unordered_map<const void*, CubeDisplay> cube_displays;     /* rz_cubemap* -> its plane of display bytes */
     std::unordered_map<const void*, DevIbl*> ibls;      /* rz_ibldata* -> DevIbl */
     std::unordered_map<const void*, bool> ibl_narrow;   /* ... and whether all its images have 4-byte formats */
     std::unordered_set<rz_pose_source*> pose_sources;
@@ -567,7 +571,6 @@ extern "C" void texture_release(rz_texture *p) {                    /* texture.c
     sync_stream();
     drop_derived_handles();
     if (t->d_data) HIP_OK(hipFree(t->d_data));
-    if (t->d_display) HIP_OK(hipFree(t->d_display));
     if (t->host_pinned) (void)hipHostUnregister(t->pub.buffer);
     free(t->pub.buffer);
     g.texs.erase(t);
@@ -592,7 +595,7 @@ static void device_image(Tex *t, int flags_wanted, size_t texel_bytes) {
         HIP_OK(hipMalloc(&t->d_data, bytes));
         t->d_bytes = bytes;
     }
-    t->display_valid = false;       /* every caller is about to write the image */
+    t->image_version++;             /* every caller is about to write the image */
     t->flags = flags;
     t->mbits = mbits;
 }
@@ -712,25 +715,6 @@ static void upload_texture(Tex *t) {
     HIP_OK(hipFree(staging));
     t->device_stale = false;
     t->host_stale = false;
-}
-
-/* the face of a skybox as its RZ_TEX_DISPLAY8 plane; false: this image is sampled as it is (one the GPU
- * writes: the plane would have to follow every write) */
-static bool dev_tex_display(rz_texture *p, DevTex *d) {
-    Tex *t = as_tex(p);
-    if (!g.sky_bytes || t->write_lane >= 0 || t->pending_write || !t->d_data) return false;
-    const size_t n = (size_t)t->pub.width * t->pub.height;
-    if (!t->display_valid) {
-        /* an image that was replaced has no reader left (upload_texture waited for them) */
-        if (!t->d_display) HIP_OK(hipMalloc((void**)&t->d_display, n * sizeof(uint32_t)));
-        rz_texture_display_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, g.stream>>>(t->d_data, t->d_display, n, t->flags);
-        HIP_OK(hipGetLastError());
-        HIP_OK(hipStreamSynchronize(g.stream));
-        t->display_valid = true;
-    }
-    d->data = t->d_display;
-    d->flags = (t->flags & RZ_TEX_LAYOUT) | RZ_TEX_DISPLAY8;
-    return true;
 }
 
 static DevTex dev_tex(rz_texture *p) {
@@ -906,6 +890,47 @@ static const DevTex *dev_cube(rz_cubemap *cube) {
     return d;
 }
 
+/* A sky box's cube map as one plane of display bytes (RZ_TEX_DISPLAY8), its six faces one behind the other in
+ * the faces' own layout: made when the cube is first drawn as a sky, made again when a face's image has changed.
+ * false: the faces are sampled as they are (faces of different sizes, or one the GPU writes: the plane would
+ * have to follow every write). */
+static bool cube_display(rz_cubemap *cube, DevTex *plane) {
+    if (!g.sky_bytes) return false;
+    Tex *f[6];
+    for (int i = 0; i < 6; i++) {
+        f[i] = as_tex(cube->faces[i]);
+        if (f[i]->write_lane >= 0 || f[i]->pending_write || !f[i]->d_data) return false;
+        if (f[i]->pub.width != f[0]->pub.width || f[i]->pub.height != f[0]->pub.height ||
+            (f[i]->flags & RZ_TEX_LAYOUT) != (f[0]->flags & RZ_TEX_LAYOUT)) return false;
+    }
+    const size_t n = (size_t)f[0]->pub.width * f[0]->pub.height;
+    if (n > ((size_t)1 << 24)) return false;        /* face * texels + cell stays a 32-bit index */
+    CubeDisplay &cd = g.cube_displays[cube];
+    bool fresh = cd.d && cd.face_texels == n;
+    for (int i = 0; i < 6; i++) fresh = fresh && cd.version[i] == f[i]->image_version;
+    if (!fresh) {
+        if (cd.d) {                 /* frames that show the old plane may still be on their way */
+            graphics_flush();
+            sync_stream();
+            if (cd.face_texels != n) { HIP_OK(hipFree(cd.d)); cd.d = nullptr; }
+        }
+        if (!cd.d) HIP_OK(hipMalloc((void**)&cd.d, 6 * n * sizeof(uint32_t)));
+        cd.face_texels = n;
+        for (int i = 0; i < 6; i++) {
+            rz_texture_display_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, g.stream>>>(f[i]->d_data, cd.d + (size_t)i * n, n, f[i]->flags);
+            HIP_OK(hipGetLastError());
+            cd.version[i] = f[i]->image_version;
+        }
+        HIP_OK(hipStreamSynchronize(g.stream));
+    }
+    plane->data = cd.d;
+    plane->w = f[0]->pub.width;
+    plane->h = f[0]->pub.height;
+    plane->flags = (f[0]->flags & RZ_TEX_LAYOUT) | RZ_TEX_DISPLAY8;
+    plane->reserved = 0;
+    return true;
+}
+
 static const DevIbl *dev_ibl(rz_ibldata *ibl) {
     if (!ibl) return nullptr;
     auto it = g.ibls.find(ibl);
@@ -935,6 +960,8 @@ static const DevIbl *dev_ibl(rz_ibldata *ibl) {
 static void drop_derived_handles() {
     for (auto &kv : g.cubes) HIP_OK(hipFree(kv.second));
     for (auto &kv : g.ibls) HIP_OK(hipFree(kv.second));
+    for (auto &kv : g.cube_displays) if (kv.second.d) HIP_OK(hipFree(kv.second.d));
+    g.cube_displays.clear();
     g.cubes.clear();
     g.ibls.clear();
     g.ibl_narrow.clear();
@@ -1085,16 +1112,9 @@ static void snapshot_uniforms_once(rz_program *p, Pending &pd, int num_joints) {
             r.maps[i] = dev_tex(u->skybox->faces[i]);
             uniform = uniform && r.maps[i].w == r.maps[0].w && r.maps[i].h == r.maps[0].h && r.maps[i].flags == r.maps[0].flags;
         }
-        if (!p->blend) {            /* all six faces as display bytes, or none */
-            DevTex shown[6];
-            bool all = true;
-            for (int i = 0; i < 6 && all; i++) { shown[i] = r.maps[i]; all = dev_tex_display(u->skybox->faces[i], &shown[i]); }
-            if (all) {
-                for (int i = 0; i < 6; i++) { r.maps[i] = shown[i]; uniform = uniform && shown[i].flags == shown[0].flags; }
-                r.flags |= RZ_DRAW_SKY_BYTES;
-            }
-        }
         if (uniform) r.flags |= RZ_DRAW_UNIFORM_CUBE;
+        /* a program that blends needs the colour itself, not its bytes */
+        if (!p->blend && cube_display(u->skybox, &r.maps[0])) r.flags |= RZ_DRAW_SKY_BYTES;
     } else if (p->family == RZ_FAMILY_BLINN) {
         const rz_blinn_uniforms *u = (const rz_blinn_uniforms*)p->uniforms;
         r.num_varyings = 11;

@@ -883,15 +883,17 @@ RZ_DEV uint32_t pack_rgb(f4 c, uint32_t keep) {                 /* float_to_ucha
 /* What draw_fragment leaves in the framebuffer for a skybox fragment (graphics.c:452-468; the program
  * does not blend): the shader's colour is its cube map's texel, so saturating it, scaling by 255 and
  * truncating is a function of the texel alone -- worked out once per texel when the map is first drawn
- * (rz_texture_display_kernel), the fragment then fetches 4 bytes instead of 16 and converts nothing. */
+ * (rz_texture_display_kernel; the six faces in one plane, so that a lane's face is an offset, not a
+ * pointer to fetch), the fragment then reads 4 bytes instead of 16 and converts nothing. */
 RZ_DEV uint32_t sky_fragment(const DrawRec &D, const float *v, uint32_t below) {
     if (D.flags & RZ_DRAW_SKY_BYTES) {
+        /* maps[0]: the cube's six faces as display bytes, one behind the other (size and layout are scalars) */
         float s, t;
         const int face = cube_face(mk3(v[0], v[1], v[2]), &s, &t);
-        DevTex f = (D.flags & RZ_DRAW_UNIFORM_CUBE) ? D.maps[0] : D.maps[face];
-        f.data = D.maps[face].data;
+        const int w = D.maps[0].w, h = D.maps[0].h, flags = D.maps[0].flags;
         const float x = s, y = 1 - t;                               /* texture.c:257, 160-167 */
-        const uint32_t word = f.data.as<const uint32_t>()[texel_cell(f.w, f.h, f.flags, x - floorf(x), y - floorf(y))];
+        const uint32_t cell = texel_cell(w, h, flags, x - floorf(x), y - floorf(y));
+        const uint32_t word = D.maps[0].data.as<const uint32_t>()[__umul24((uint32_t)face, (uint32_t)(w * h)) + cell];
         return (word & 0x00ffffffu) | (below & 0xff000000u);
     }
     f4 color = fs_skybox(D, v);

@@ -293,13 +293,14 @@ RZ_DEV f4 sample_clamp(const DevTex &t, float x, float y) { return decode_texel<
  * the face index differs per lane, so the six descriptors are read per lane */
 RZ_DEV int cube_face(f3 d, float *s, float *t) {
     const float ax = fabsf(d.x), ay = fabsf(d.y), az = fabsf(d.z);
-    /* selects instead of branches: every value below is one of +-d.x, +-d.y, +-d.z, so nothing is rounded */
-    const bool x_major = ax > ay && ax > az, y_major = !x_major && ay > az;
+    /* selects only, stage by stage (z, then y over it, then x over that): every value below is one of +-d.x,
+     * +-d.y, +-d.z, so nothing is rounded, and the compiler has no nest of conditions to turn into branches */
+    const bool x_major = ax > ay && ax > az, y_major = ay > az;
     const bool px = d.x > 0, py = d.y > 0, pz = d.z > 0;
-    const float ma = x_major ? ax : (y_major ? ay : az);
-    const float sc = x_major ? (px ? -d.z : d.z) : (y_major ? d.x : (pz ? d.x : -d.x));
-    const float tc = x_major ? -d.y : (y_major ? (py ? d.z : -d.z) : -d.y);
-    const int face = x_major ? (px ? 0 : 1) : (y_major ? (py ? 2 : 3) : (pz ? 4 : 5));
+    float ma = az, sc = pz ? d.x : -d.x, tc = -d.y;
+    int face = pz ? 4 : 5;
+    if (y_major) { ma = ay; sc = d.x; tc = py ? d.z : -d.z; face = py ? 2 : 3; }
+    if (x_major) { ma = ax; sc = px ? -d.z : d.z; tc = -d.y; face = px ? 0 : 1; }
     *s = (sc / ma + 1) / 2;
     *t = (tc / ma + 1) / 2;
     return face;

@@ -61,3 +61,13 @@ __global__ void g8_whole_fragment(IO, TriRec m, const float *m0, const float *m1
     c = mk4(d_sat(c.x), d_sat(c.y), d_sat(c.z), d_sat(c.w));
     color[LANE] = pack_rgb(c, color[LANE]);
 }
+
+// the fragment as the sky kernel's own-visibility path shades it: weights kept from the depth test, display bytes
+__global__ void g9_bytes_fragment(IO, TriRec m, const float *m0, const float *m1, const float *m2, const DrawRec *D, uint32_t *color) {
+    float v[4];
+    const float w0 = in[LANE], w1 = in[LANE + 64], w2 = in[LANE + 128];
+    const float q0 = m.rw[0] * w0, q1 = m.rw[1] * w1, q2 = m.rw[2] * w2;
+    const float norm = 1 / (q0 + q1 + q2);
+    interpolate_lane<3>(m0, m1, m2, q0, q1, q2, norm, v);
+    color[LANE] = sky_fragment(*D, v, color[LANE]);
+}
