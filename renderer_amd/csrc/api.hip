@@ -153,6 +153,7 @@ struct Lane {
     DevBuf<uint2> bbox;
     DevBuf<uint32_t> clip_list, ref;
     DevBuf<uint2> bin_range;
+    DevBuf<SkyBin> sky_bins;            /* per bin of the batch: rz_sky_regions_kernel's record */
     DevBuf<uint32_t> bin_counts, queue, queue_counts, tile_listed;
     DevBuf<BinEntry> bin_list;
     DevBuf<uint2> bin_boxes;
@@ -1626,6 +1627,7 @@ static void prepare_batch(const Batch &b, const FlushRecord &fr, bool reserve_on
     reserve(L.fan_tri, fans * RZ_MAX_FAN, st);
     reserve(L.fan_vary, fans * RZ_MAX_POLY * RZ_VARY_STRIDE, st);
     reserve(L.bin_range, bins, st);
+    if (g.sky_bins) reserve(L.sky_bins, bins, st);
     reserve(L.bin_counts, matrix, st);
     /* tiles are dealt to the parts of a list by their index: a part holds at most its even share */
     /* (32x8 tiles, or the two 16x8 blocks of each that rz_strip_kernel lists) */
@@ -1760,7 +1762,13 @@ static void launch_batch(const Batch &b, const std::vector<PassPlan> &plans, cha
     {
         /* what the kernels below index without a check of their own: wrong sizes here must stop the host, not fault the GPU */
         size_t pixels = 0, tris = 0;
-        for (size_t i : b.members) { pixels += (size_t)plans[i].fb->pub.width * plans[i].fb->pub.height; tris += plans[i].T; }
+        size_t bins = 0;
+        for (size_t i : b.members) {
+            pixels += (size_t)plans[i].fb->pub.width * plans[i].fb->pub.height;
+            tris += plans[i].T;
+            bins += (size_t)((plans[i].fb->pub.width + RZ_BIN - 1) / RZ_BIN) * ((plans[i].fb->pub.height + RZ_BIN - 1) / RZ_BIN);
+        }
+        if (L.bin_range.cap < bins || (g.sky_bins && L.sky_bins.cap < bins)) fatal("per-bin scratch of lane %d is smaller than the batch it is about to run", b.lane);
         const bool uses_ref = !(b.has_blend && !splits_blend(batch_tiles, n));
         if (L.queue_counts.cap < 3 * RZ_QUEUE_WAYS * RZ_QUEUE_PAD || L.queue.cap < 3 * RZ_QUEUE_WAYS * (size_t)queue_capacity ||
             L.tile_listed.cap < batch_tiles || L.bin_boxes.cap < L.bin_list.cap || (uses_ref && (!L.ref.ptr || L.ref.cap < pixels)) || L.tri.cap < tris || L.bbox.cap < tris)
@@ -1819,16 +1827,16 @@ static void launch_batch(const Batch &b, const std::vector<PassPlan> &plans, cha
                                       : (strip == 8 ? rz_strip_kernel<8, false> : strip == 4 ? rz_strip_kernel<4, false> : strip == 2 ? rz_strip_kernel<2, false> : rz_strip_kernel<1, false>);
             /* bins with nothing but skybox triangles are left to rz_sky_kernel */
             sky_bins = g.sky_bins && !g.strip_sky && g.sky_pixels_per_lane == 2 && (b.families & (1 << RZ_FAMILY_SKYBOX));
-            if (sky_bins) rz_sky_regions_kernel<<<dim3((unsigned)max_bins, n), dim3(64), 0, st>>>(passes, L.bin_list.ptr, L.bin_range.ptr);
+            if (sky_bins) rz_sky_regions_kernel<<<dim3((unsigned)max_bins, n), dim3(64), 0, st>>>(passes, L.bin_list.ptr, L.bin_range.ptr, L.sky_bins.ptr);
             if (g.verbose) fprintf(stderr, "mi355r: batch of %u passes, longest bin list last time %u entries, strips of %d\n", n, longest, strip);
             kernel<<<dim3(bin_columns * 2 * n, bin_rows * strips_per_bin), dim3(128), 0, st>>>(
-                passes, L.bin_list.ptr, L.bin_boxes.ptr, L.vary.ptr, L.fan_vary.ptr, db, L.bin_range.ptr, n, sky_bins ? 1u : 0u);
+                passes, L.bin_list.ptr, L.bin_boxes.ptr, L.vary.ptr, L.fan_vary.ptr, db, L.bin_range.ptr, n, sky_bins ? L.sky_bins.ptr : nullptr);
         }
         stamp();
         if ((b.families & (1 << RZ_FAMILY_SKYBOX)) && !sky_done) {
             if (g.sky_pixels_per_lane == 2)     /* four per lane: 11.9 us per frame against 11.1 */
                 rz_sky_kernel<2><<<tiles, dim3(128), 0, st>>>(passes, L.tri.ptr, L.fan_tri.ptr, L.vary.ptr, L.fan_vary.ptr, db, L.ref.ptr,
-                                                              L.bin_list.ptr, L.bin_range.ptr, sky_bins ? 1u : 0u);
+                                                              L.bin_list.ptr, sky_bins ? L.sky_bins.ptr : nullptr);
             else
                 rz_shade_kernel<2><<<tiles, dim3(256), 0, st>>>(passes, L.tri.ptr, L.fan_tri.ptr, L.vary.ptr, L.fan_vary.ptr, db, L.ref.ptr);
         }

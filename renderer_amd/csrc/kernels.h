@@ -1645,41 +1645,58 @@ __global__ void __launch_bounds__(256 / PPL) rz_visibility_kernel(const PassPara
  * last entry tell.  For such a bin rz_strip_kernel does nothing at all and rz_sky_kernel resolves
  * visibility itself: it needs the weights of the visible triangle for the shader anyway, the few
  * entries come through scalar loads, and depth, reference and colour make no round trip between two
- * kernels.  Not while fragments are counted (the counts belong to the rasteriser's stage). */
+ * kernels.  Not while fragments are counted (the counts belong to the rasteriser's stage).
+ *
+ * rz_sky_regions_kernel, one wave per bin, writes a record for EVERY bin of the batch: whether it is
+ * such a bin, where its list starts, its draw, and for each of the 32 REGIONS of 32x4 pixels a wave of
+ * rz_sky_kernel takes the set of entries that can touch it (box and conservative edge test, as
+ * rz_strip_kernel culls its blocks, lane = region).  The two triangles of a sky box face share their
+ * box: testing both in every pixel of the face cost the sky kernel a third of its time again.  And a
+ * wave learns all of this in one memory round trip where reading the bin's range, then the list's ends,
+ * then entry after entry took four or more. */
 #define RZ_SKY_ONLY_MAX 8u
+struct SkyBin {
+    uint8_t entries_of_region[32];  /* bit e: entry e of the list can touch the region */
+    uint32_t count;                 /* entries of the list; 0 = not a bin of this kind */
+    uint32_t first;                 /* the list's first entry in the pass's lists */
+    uint32_t draw;                  /* the draw all entries belong to */
+    uint32_t pad[5];
+};
 RZ_DEV bool sky_only_bin(const PassParams &P, const BinEntry *list, uint32_t count) {
     if (count == 0u || count > RZ_SKY_ONLY_MAX || P.counters || P.debug_skip) return false;
     const uint32_t first = list[0].rec.meta, last = list[count - 1u].rec.meta;
     return RZ_META_FAMILY(first) == 2u && RZ_META_FAMILY(last) == 2u && RZ_META_DRAW(first) == RZ_META_DRAW(last);
 }
-/* A wave of rz_sky_kernel takes a REGION of 32x4 pixels, 32 of them in a bin.  Which entries of the
- * list can touch which region (box and conservative edge test, as rz_strip_kernel culls its blocks) is
- * found once per bin, lane = region, by rz_sky_regions_kernel, and kept in the entry's spare word: the two triangles of a sky box face share their box, and testing both in every pixel of
- * the face cost the sky kernel a third of its time again. */
 RZ_DEV uint32_t sky_region_of(int tx0, int ry0) { return (uint32_t)(((ry0 % RZ_BIN) / 4) * 2 + (tx0 % RZ_BIN) / RZ_TILE_W); }
-RZ_DEV void sky_bin_regions(const BinEntry *list, uint32_t count, int bin_x0, int bin_y0) {
-    const int lane = threadIdx.x & 63;
-    const int rx0 = bin_x0 + RZ_TILE_W * (lane & 1), ry0 = bin_y0 + 4 * ((lane >> 1) & 15);
-    for (uint32_t e = 0; e < count; e++) {
-        const float4 *q = (const float4*)&list[e];
-        const float4 c0 = q[1], c1 = q[2];
-        const uint2 box = entry_box(q[4]);
-        const bool hit = box_overlaps(make_uint2(box.x, box.y & 0x7fffffffu), rx0, ry0, rx0 + RZ_TILE_W - 1, ry0 + 3) &&
-                         !block_outside(c0, c1, (float)rx0 + 0.5f, (float)(rx0 + RZ_TILE_W - 1) + 0.5f, (float)ry0 + 0.5f, (float)ry0 + 3.5f);
-        const uint32_t mask = (uint32_t)__ballot(hit && lane < 32);
-        if (lane == 0) const_cast<BinEntry*>(list)[e].pad[0] = mask;
-    }
-}
 
-/* one wave per bin of every pass of the batch (grid x = bin, y = pass) */
+/* grid x = bin, y = pass of the batch */
 __global__ void __launch_bounds__(64) rz_sky_regions_kernel(const PassParams *__restrict__ passes,
-        const BinEntry *__restrict__ list_base, const uint2 *__restrict__ bin_range_base) {
+        const BinEntry *__restrict__ list_base, const uint2 *__restrict__ bin_range_base, SkyBin *__restrict__ sky_base) {
     const PassParams &P = passes[blockIdx.y];
     if ((int)blockIdx.x >= P.bins_x * P.bins_y || P.control[2] != 0u) return;
     const uint2 range = (bin_range_base + P.bin_off)[blockIdx.x];
     const BinEntry *list = list_base + P.list_off + range.x;
-    if (!sky_only_bin(P, list, range.y)) return;
-    sky_bin_regions(list, range.y, (int)(blockIdx.x % (uint32_t)P.bins_x) * RZ_BIN, (int)(blockIdx.x / (uint32_t)P.bins_x) * RZ_BIN);
+    const bool sky = sky_only_bin(P, list, range.y);
+    const int lane = threadIdx.x & 63;
+    const int bin_x0 = (int)(blockIdx.x % (uint32_t)P.bins_x) * RZ_BIN, bin_y0 = (int)(blockIdx.x / (uint32_t)P.bins_x) * RZ_BIN;
+    const int rx0 = bin_x0 + RZ_TILE_W * (lane & 1), ry0 = bin_y0 + 4 * ((lane >> 1) & 15);
+    uint32_t mine = 0, draw = 0;
+    if (sky) {
+        draw = RZ_META_DRAW(list[0].rec.meta);
+        for (uint32_t e = 0; e < range.y; e++) {
+            const float4 *q = (const float4*)&list[e];
+            const float4 c0 = q[1], c1 = q[2];
+            const uint2 box = entry_box(q[4]);
+            const bool hit = box_overlaps(make_uint2(box.x, box.y & 0x7fffffffu), rx0, ry0, rx0 + RZ_TILE_W - 1, ry0 + 3) &&
+                             !block_outside(c0, c1, (float)rx0 + 0.5f, (float)(rx0 + RZ_TILE_W - 1) + 0.5f, (float)ry0 + 0.5f, (float)ry0 + 3.5f);
+            mine |= (hit ? 1u : 0u) << e;
+        }
+    }
+    SkyBin *rec = sky_base + P.bin_off + blockIdx.x;
+    if (lane < 32) rec->entries_of_region[lane] = (uint8_t)mine;
+    if (lane == 32) rec->count = sky ? range.y : 0u;
+    if (lane == 33) rec->first = range.x;
+    if (lane == 34) rec->draw = draw;
 }
 
 /* K4c  visibility AND skybox shading for passes without blending, a STRIP of blocks per wave.
@@ -1714,7 +1731,7 @@ __global__ void __launch_bounds__(128) rz_strip_kernel(const PassParams *__restr
         const BinEntry *__restrict__ list_base, const uint2 *__restrict__ box_base,
         const float *__restrict__ vary_base, const float *__restrict__ fan_vary_base,
         const char *__restrict__ upload_base, const uint2 *__restrict__ bin_range_base, uint32_t num_passes,
-        uint32_t sky_bins_elsewhere) {
+        const SkyBin *__restrict__ sky_base) {
     constexpr int PPL = 2;
     static_assert(RZ_BIN % (8 * STRIP) == 0, "a strip lies inside one bin");
     const TileOrder o = tile_order(num_passes, RZ_BIN / (8 * STRIP));
@@ -1722,7 +1739,7 @@ __global__ void __launch_bounds__(128) rz_strip_kernel(const PassParams *__restr
     const PassParams P = passes[pass_index];
     const int sy0 = (int)strip_row * 8 * STRIP;
     if ((int)tile_column >= P.tiles_x || sy0 >= P.height) return;
-    if (P.control[2] != 0u) return;                             /* out of scratch, or left out: the pass is run again later */
+    const uint32_t failed = P.control[2];       /* looked at below, together with what else the pass's parameters lead to: one round trip, not three */
     const BinEntry *list_table = list_base + P.list_off;
     const float *vary_table = vary_base + (size_t)P.tri_off * 3 * RZ_VARY_STRIDE;
     const float *fan_vary_table = fan_vary_base + (size_t)P.fan_off * RZ_MAX_POLY * RZ_VARY_STRIDE;
@@ -1734,6 +1751,9 @@ __global__ void __launch_bounds__(128) rz_strip_kernel(const PassParams *__restr
     for (int q = 0; q < PPL; q++) px[q] = bx0 + 8 * q + (lane & 7);
     const int bin = (sy0 / RZ_BIN) * P.bins_x + tx0 / RZ_BIN;
     const uint2 range = (bin_range_base + P.bin_off)[bin];          /* {first entry, entries} */
+    const uint32_t elsewhere = (!SKY && sky_base) ? sky_base[P.bin_off + (uint32_t)bin].count : 0u;
+    if (failed != 0u) return;                                       /* out of scratch, or left out: the pass is run again later */
+    if (elsewhere != 0u) return;                                    /* rz_sky_kernel does all of it */
     const uint32_t count = range.y;
     if (count == 0) {               /* nothing but the pending clears (uniform over the workgroup) */
         const bool blank_refs = !SKY && P.ref_scanned;              /* a kernel that scans every pixel's reference follows */
@@ -1752,7 +1772,6 @@ __global__ void __launch_bounds__(128) rz_strip_kernel(const PassParams *__restr
     }
     const BinEntry *list = list_table + range.x;
     const uint2 *boxes = box_base + P.list_off + range.x;
-    if (!SKY && sky_bins_elsewhere && sky_only_bin(P, list, count)) return;     /* rz_sky_kernel does all of it */
 
     /* small triangles, one per lane, into per-pixel keys in LDS: see rz_visibility_kernel */
     __shared__ unsigned long long micro_keys[256];
@@ -2110,10 +2129,10 @@ __global__ void __launch_bounds__(256 / PPL) rz_sky_kernel(const PassParams *__r
         const TriRec *__restrict__ tri_base, const TriRec *__restrict__ fan_base,
         const float *__restrict__ vary_base, const float *__restrict__ fan_vary_base,
         const char *__restrict__ upload_base, const uint32_t *__restrict__ ref_base,
-        const BinEntry *__restrict__ list_base, const uint2 *__restrict__ bin_range_base, uint32_t sky_bins_here) {
+        const BinEntry *__restrict__ list_base, const SkyBin *__restrict__ sky_base) {
     const PassParams P = passes[blockIdx.z];
     if ((int)blockIdx.x >= P.tiles_x || (int)blockIdx.y >= P.tiles_y) return;
-    if (P.control[2] != 0u) return;                   /* the pass did not run: its reference plane holds nothing */
+    const uint32_t failed = P.control[2];             /* looked at below, in the same round trip as the bin's record */
     const int lane = threadIdx.x & 63, wave = (int)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const TriRec *tri_table = tri_base + P.tri_off;
     const TriRec *fan_table = fan_base + (size_t)P.fan_off * RZ_MAX_FAN;
@@ -2131,12 +2150,21 @@ __global__ void __launch_bounds__(256 / PPL) rz_sky_kernel(const PassParams *__r
         py[q] = ry0 + 2 * q + (lane >> 5);
         pixel[q] = (uint32_t)py[q] * (uint32_t)P.width + (uint32_t)px;
     }
-    if (sky_bins_here) {
-        const uint2 range = (bin_range_base + P.bin_off)[(ry0 / RZ_BIN) * P.bins_x + tx0 / RZ_BIN];   /* {first entry, entries} */
-        const BinEntry *list = list_base + P.list_off + range.x;
-        const uint32_t count = range.y;
-        if (sky_only_bin(P, list, count)) {
+    static_assert(PPL == 2, "a wave's region is 32x4 pixels");
+    const uint32_t region = sky_region_of(tx0, ry0);
+    uint32_t sky_count = 0, sky_first = 0, sky_draw = 0, sky_word = 0;
+    if (sky_base) {
+        const SkyBin &bin = sky_base[P.bin_off + (uint32_t)((ry0 / RZ_BIN) * P.bins_x + tx0 / RZ_BIN)];
+        sky_count = bin.count; sky_first = bin.first; sky_draw = bin.draw;
+        sky_word = ((const uint32_t*)bin.entries_of_region)[region >> 2];
+    }
+    if (failed != 0u) return;                         /* the pass did not run: its reference plane holds nothing */
+    {
+        if (sky_count != 0u) {
             /* visibility as in rz_strip_kernel (graphics.c:512-532), every entry through scalar loads */
+            const uint32_t entries = (sky_word >> ((region & 3u) * 8u)) & 0xffu;
+            const BinEntry *list = list_base + P.list_off + sky_first;
+            const DrawRec &D = draw_table[sky_draw];
             bool valid[PPL];
             float zcur[PPL], w[PPL][3];
             int win[PPL];
@@ -2147,21 +2175,24 @@ __global__ void __launch_bounds__(256 / PPL) rz_sky_kernel(const PassParams *__r
                 win[q] = -1;
                 w[q][0] = w[q][1] = w[q][2] = 0;
             }
-            static_assert(PPL == 2, "a wave's region is 32x4 pixels");
-            const uint32_t region = sky_region_of(tx0, ry0);
-            for (uint32_t e = 0; e < count; e++) {
-                if (!((list[e].pad[0] >> region) & 1u)) continue;       /* uniform: sky_bin_regions */
-                const TriRec r = list[e].rec;
-                const int x0 = (int)(r.bx & 0xffffu), x1 = (int)(r.bx >> 16);
-                const int y0 = (int)(r.by & 0xffffu), y1 = (int)(r.by >> 16);
+            TriRec m;                                       /* the entry taken last, and its reference */
+            uint32_t m_ref = 0;
+            int m_at = -1;
+            for (uint32_t rest = entries; rest; rest &= rest - 1u) {
+                const int e = __ffs((int)rest) - 1;
+                m = list[e].rec;
+                m_ref = list[e].tri;
+                m_at = e;
+                const int x0 = (int)(m.bx & 0xffffu), x1 = (int)(m.bx >> 16);
+                const int y0 = (int)(m.by & 0xffffu), y1 = (int)(m.by >> 16);
                 for (int q = 0; q < PPL; q++) {
                     float w0, w1, w2;
-                    pixel_weights(r, px, py[q], w0, w1, w2);
+                    pixel_weights(m, px, py[q], w0, w1, w2);
                     const bool inside = valid[q] && py[q] >= y0 && py[q] <= y1 && px >= x0 && px <= x1 &&
                                         w0 > -RZ_EPS && w1 > -RZ_EPS && w2 > -RZ_EPS;                 /* :516-519 */
-                    const float depth = r.z[0] * w0 + r.z[1] * w1 + r.z[2] * w2;                  /* :403-408 */
+                    const float depth = m.z[0] * w0 + m.z[1] * w1 + m.z[2] * w2;                  /* :403-408 */
                     if (inside && depth <= zcur[q]) {                                             /* :523 */
-                        zcur[q] = depth; win[q] = (int)e;
+                        zcur[q] = depth; win[q] = e;
                         w[q][0] = w0; w[q][1] = w1; w[q][2] = w2;
                     }
                 }
@@ -2183,11 +2214,9 @@ __global__ void __launch_bounds__(256 / PPL) rz_sky_kernel(const PassParams *__r
             bool uniform = true;
             for (int q = 0; q < PPL; q++) uniform = uniform && (!want[q] || win[q] == first);
             if (__all(uniform)) {
-                const BinEntry *e = &list[first];
-                const TriRec m = e->rec;
+                if (first != m_at) { m = list[first].rec; m_ref = list[first].tri; }       /* usually the only entry of the region */
                 const float *m0, *m1, *m2;
-                ref_varyings(e->tri, vary_table, fan_vary_table, m0, m1, m2);
-                const DrawRec &D = draw_table[RZ_META_DRAW(m.meta)];
+                ref_varyings(m_ref, vary_table, fan_vary_table, m0, m1, m2);
                 for (int q = 0; q < PPL; q++) {
                     if (!want[q]) continue;
                     float v[4];
@@ -2200,13 +2229,13 @@ __global__ void __launch_bounds__(256 / PPL) rz_sky_kernel(const PassParams *__r
             }
             for (int q = 0; q < PPL; q++) {                 /* an edge of the sky box crosses the wave */
                 if (!__any(want[q])) continue;
-                TriRec m;
+                TriRec mq;
                 const float *m0 = vary_table, *m1 = vary_table, *m2 = vary_table;
                 if (want[q]) {
-                    m = load_tri(&list[win[q]].rec);
+                    mq = load_tri(&list[win[q]].rec);
                     ref_varyings(list[win[q]].tri, vary_table, fan_vary_table, m0, m1, m2);
                 }
-                shade_lanes<2>(P, draw_table, want[q], m, m0, m1, m2, px, py[q], ccur[q]);
+                shade_lanes<2>(P, draw_table, want[q], mq, m0, m1, m2, px, py[q], ccur[q]);
                 if (want[q]) P.color[pixel[q]] = ccur[q];
             }
             return;
