@@ -542,7 +542,7 @@ static void choose_layout(int w, int h, int *flags, int *mbits) {
     *flags &= ~RZ_TEX_LAYOUT;
     if (layout == 1 && w % 16 == 0 && h % 16 == 0) *flags |= RZ_TEX_TILE16;
     else if (layout == 2 && w % 8 == 0 && h % 8 == 0) *flags |= RZ_TEX_MORTON;
-    else if (w % 8 == 0 && h % 8 == 0) *flags |= RZ_TEX_TILED;
+    else if (w % 8 == 0 && h % 8 == 0 && w < (1 << 24) && h < (1 << 24)) *flags |= RZ_TEX_TILED;   /* texel_index multiplies tile counts with 24 bits */
 }
 
 static void drop_derived_handles();

@@ -167,7 +167,7 @@ RZ_DEV f3 m3v3(const float *m, f3 v) {                                          
  * locality for a handful of integer operations.  Other sizes stay row-major. */
 RZ_DEV uint32_t texel_index(int w, int flags, int c, int r) {
     if (flags & RZ_TEX_TILED) {
-        uint32_t tile = ((uint32_t)r >> 3) * ((uint32_t)w >> 3) + ((uint32_t)c >> 3);
+        uint32_t tile = __umul24((uint32_t)r >> 3, (uint32_t)w >> 3) + ((uint32_t)c >> 3);      /* sides stay below 2^16: a full-rate multiply */
         return (tile << 6) | (((uint32_t)r & 7u) << 3) | ((uint32_t)c & 7u);
     }
     if (flags & RZ_TEX_TILE16) {
@@ -216,8 +216,8 @@ __device__ float4 rz_zero_texel;        /* what an absent map reads */
 RZ_DEV uint32_t texel_cell(int w, int h, int flags, float u, float v) {
     int c = (int)((float)(w - 1) * u);
     int r = (int)((float)(h - 1) * v);
-    c = c < 0 ? 0 : (c > w - 1 ? w - 1 : c);            /* never taken for finite coordinates */
-    r = r < 0 ? 0 : (r > h - 1 ? h - 1 : r);
+    c = max(0, min(c, w - 1));                          /* never needed for finite coordinates */
+    r = max(0, min(r, h - 1));
     return texel_index(w, flags, c, r);
 }
 
