@@ -948,7 +948,7 @@ RZ_DEV void pixel_weights(const TriRec &r, int px, int py, float &w0, float &w1,
  * draw are shaded together under that draw's (wave-uniform) record.
  * FAMILY >= 0 compiles only that family's shader (per-family kernels),
  * FAMILY < 0 all three. */
-template <int FAMILY, bool NARROW = false>
+template <int FAMILY, bool NARROW = false, class TABLES = GlobalTables>
 RZ_DEV void shade_lanes(const PassParams &P, const DrawRec *__restrict__ draw_table, bool want,
                         const TriRec &m, const float *m0, const float *m1, const float *m2,
                         int px, int py, uint32_t &ccur) {
@@ -981,11 +981,11 @@ RZ_DEV void shade_lanes(const PassParams &P, const DrawRec *__restrict__ draw_ta
             } else if ((FAMILY < 0 || FAMILY == 0) && D.family == 0) {
                 float v[12];
                 interpolate_lane<11>(m0, m1, m2, q0, q1, q2, norm, v);
-                color = fs_blinn<NARROW>(D, v, backface, &discard);
+                color = fs_blinn<NARROW, TABLES>(D, v, backface, &discard);
             } else if ((FAMILY < 0 || FAMILY == 1) && D.family == 1) {
                 float v[24];
                 interpolate_lane<21>(m0, m1, m2, q0, q1, q2, norm, v);
-                color = fs_pbr<NARROW>(D, v, backface, &discard);
+                color = fs_pbr<NARROW, TABLES>(D, v, backface, &discard);
             }
             /* draw_fragment (graphics.c:452-468); a discard was settled during rasterisation */
             if (!continue_to_count) {
@@ -2063,7 +2063,7 @@ __global__ void __launch_bounds__(128) rz_strip_kernel(const PassParams *__restr
 
 /* K5  per-family fragment kernels for passes rasterised with SPLIT = true:
  * every lane shades the one fragment its pixel refers to. */
-template <int FAMILY, bool NARROW = false>
+template <int FAMILY, bool NARROW = false, class TABLES = GlobalTables>
 RZ_DEV void shade_pixel(const PassParams &P, const TriRec *__restrict__ tri_base, const TriRec *__restrict__ fan_base,
                         const float *__restrict__ vary_base, const float *__restrict__ fan_vary_base,
                         const char *__restrict__ upload_base, const uint32_t *__restrict__ ref_base,
@@ -2099,7 +2099,7 @@ RZ_DEV void shade_pixel(const PassParams &P, const TriRec *__restrict__ tri_base
         }
     }
     if (want) fetch_ref(myref, tri_table, fan_table, vary_table, fan_vary_table, m, m0, m1, m2);
-    shade_lanes<FAMILY, NARROW>(P, draw_table, want, m, m0, m1, m2, px, py, ccur);
+    shade_lanes<FAMILY, NARROW, TABLES>(P, draw_table, want, m, m0, m1, m2, px, py, ccur);
     if (want) P.color[pixel] = ccur;
 }
 
@@ -2305,6 +2305,7 @@ __global__ void __launch_bounds__(256) rz_shade_list_kernel(const PassParams *__
         const char *__restrict__ upload_base, const uint32_t *__restrict__ ref_base,
         const uint32_t *__restrict__ queue_base, const uint32_t *__restrict__ queue_counts, uint32_t queue_capacity) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    LdsTables::fill();              /* a workgroup shades many blocks: the tables' copy is paid once */
     /* lane q holds the length of part q of this family's list */
     const uint32_t my_count = min(queue_counts[(FAMILY * RZ_QUEUE_WAYS + lane) * RZ_QUEUE_PAD], queue_capacity);
     uint32_t longest = my_count;
@@ -2321,12 +2322,12 @@ __global__ void __launch_bounds__(256) rz_shade_list_kernel(const PassParams *__
         if constexpr (BLOCKS) {
             const PassParams P = passes[item >> 21];
             const int t = (int)(threadIdx.x & 127u);
-            shade_pixel<FAMILY, NARROW>(P, tri_base, fan_base, vary_base, fan_vary_base, upload_base, ref_base,
-                                        (int)(item & 1023u) * 16 + (t & 15), (int)((item >> 10) & 2047u) * 8 + (t >> 4));
+            shade_pixel<FAMILY, NARROW, LdsTables>(P, tri_base, fan_base, vary_base, fan_vary_base, upload_base, ref_base,
+                                                   (int)(item & 1023u) * 16 + (t & 15), (int)((item >> 10) & 2047u) * 8 + (t >> 4));
         } else {
             const PassParams P = passes[item >> 20];
-            shade_pixel<FAMILY, NARROW>(P, tri_base, fan_base, vary_base, fan_vary_base, upload_base, ref_base,
-                                        (int)(item & 511u) * RZ_TILE_W + (lane & 31), (int)((item >> 9) & 2047u) * RZ_TILE_H + wave * 2 + (lane >> 5));
+            shade_pixel<FAMILY, NARROW, LdsTables>(P, tri_base, fan_base, vary_base, fan_vary_base, upload_base, ref_base,
+                                                   (int)(item & 511u) * RZ_TILE_W + (lane & 31), (int)((item >> 9) & 2047u) * RZ_TILE_H + wave * 2 + (lane >> 5));
         }
     }
 }

@@ -103,7 +103,38 @@ struct SrgbTables {
     double inv[32];         /* 1 / (1 + i/32) */
 };
 __device__ SrgbTables rz_srgb_tables;
+/* (float)pow(k / 255.0f, 2.2) for every byte k (texture.c:32-62 with maths.c:37-39), filled by the host */
+__device__ float rz_srgb8_table[256];
 
+/* Where a shader reads the small tables from.  A lookup is a memory round trip on a fragment's
+ * dependency chain (texel -> table -> colour, colour -> table -> byte): from global memory it costs
+ * what a texel fetch costs, from LDS a tenth.  A kernel that runs long enough to pay for the copy
+ * (the persistent shade kernels) copies the tables into LDS once per workgroup and shades with
+ * LdsTables; the others read the global copies. */
+struct GlobalTables {
+    RZ_DEV float srgb8(uint32_t k) { return rz_srgb8_table[k]; }
+    RZ_DEV double pow2(int i) { return rz_srgb_tables.pow2[i]; }
+    RZ_DEV double m0(int i) { return rz_srgb_tables.m0[i]; }
+    RZ_DEV double inv(int i) { return rz_srgb_tables.inv[i]; }
+};
+__shared__ SrgbTables rz_lds_srgb_tables;
+__shared__ float rz_lds_srgb8_table[256];
+struct LdsTables {
+    RZ_DEV float srgb8(uint32_t k) { return rz_lds_srgb8_table[k]; }
+    RZ_DEV double pow2(int i) { return rz_lds_srgb_tables.pow2[i]; }
+    RZ_DEV double m0(int i) { return rz_lds_srgb_tables.m0[i]; }
+    RZ_DEV double inv(int i) { return rz_lds_srgb_tables.inv[i]; }
+    /* by every thread of the workgroup, before the first lookup */
+    RZ_DEV void fill() {
+        const uint32_t *src = (const uint32_t*)&rz_srgb_tables;
+        uint32_t *dst = (uint32_t*)&rz_lds_srgb_tables;
+        for (uint32_t i = threadIdx.x; i < sizeof(SrgbTables) / 4; i += blockDim.x) dst[i] = src[i];
+        for (uint32_t i = threadIdx.x; i < 256u; i += blockDim.x) rz_lds_srgb8_table[i] = rz_srgb8_table[i];
+        __syncthreads();
+    }
+};
+
+template <class TABLES = GlobalTables>
 RZ_DEV float d_srgb(float v) {
     if (v == 0.0f) return 0.0f;
     if (!(v > 0.0f && v <= 1.0f)) return d_powf_outlined(v, 1 / 2.2);       /* NaN, out of the display range */
@@ -116,12 +147,12 @@ RZ_DEV float d_srgb(float v) {
     const int i = (int)(mant >> 47);
     const double m = __longlong_as_double((long long)(0x3ff0000000000000ull | mant));
     const double m0 = __longlong_as_double((long long)(0x3ff0000000000000ull | ((unsigned long long)i << 47)));
-    const double r = (m - m0) * rz_srgb_tables.inv[i];
+    const double r = (m - m0) * TABLES::inv(i);
     double q = c9;
     q = fma(q, r, c8); q = fma(q, r, c7); q = fma(q, r, c6); q = fma(q, r, c5);
     q = fma(q, r, c4); q = fma(q, r, c3); q = fma(q, r, c2); q = fma(q, r, c1);
     q = fma(q, r, 1.0);
-    return (float)((rz_srgb_tables.pow2[e + 149] * rz_srgb_tables.m0[i]) * q);
+    return (float)((TABLES::pow2(e + 149) * TABLES::m0(i)) * q);
 }
 RZ_DEV float d_aces(float v) {                                                 /* maths.c:49 */
     float a = 2.51f, b = 0.03f, c = 2.43f, d = 0.59f, e = 0.14f;
@@ -192,9 +223,6 @@ RZ_DEV float d_unorm8(uint32_t k) {
     return __builtin_fmaf(__builtin_fmaf(-q, 255.0f, f), r, q);
 }
 
-/* (float)pow(k / 255.0f, 2.2) for every byte k (texture.c:32-62 with maths.c:37-39), filled by the host */
-__device__ float rz_srgb8_table[256];
-
 /* A sample is taken in two steps so that a shader can put all the loads of
  * one dependency level in flight before it waits for the first: load_*()
  * computes the address and issues ONE 16-byte load in straight-line code
@@ -264,23 +292,24 @@ RZ_DEV TexelT<NARROW> load_repeat(const DevTex &t, float x, float y) { return lo
 template <bool NARROW>
 RZ_DEV TexelT<NARROW> load_clamp(const DevTex &t, float x, float y) { return load_texel<NARROW>(t, d_sat(x), d_sat(y)); }
 
+template <class TABLES = GlobalTables>
 RZ_DEV f4 decode_word(int flags, float word) {
     if (flags & RZ_TEX_R32F) return mk4(word, word, word, 1.0f);
     const uint32_t p = __float_as_uint(word);
     const uint32_t b0 = p & 0xffu, b1 = (p >> 8) & 0xffu, b2 = (p >> 16) & 0xffu, b3 = p >> 24;
     if (flags & RZ_TEX_UNORM8) return mk4(d_unorm8(b0), d_unorm8(b1), d_unorm8(b2), d_unorm8(b3));
-    if (flags & RZ_TEX_SRGB8) return mk4(rz_srgb8_table[b0], rz_srgb8_table[b1], rz_srgb8_table[b2], d_unorm8(b3));
+    if (flags & RZ_TEX_SRGB8) return mk4(TABLES::srgb8(b0), TABLES::srgb8(b1), TABLES::srgb8(b2), d_unorm8(b3));
     const float factor = ldexpf(1.0f, (int)b3 - 136);           /* image.c:329-347; a zero texel is stored as four zero bytes */
     return mk4((float)b0 * factor, (float)b1 * factor, (float)b2 * factor, 1.0f);
 }
 
-template <bool NARROW>
+template <bool NARROW, class TABLES = GlobalTables>
 RZ_DEV f4 decode_texel(const DevTex &t, const TexelT<NARROW> &x) {
     if constexpr (NARROW) {
-        return decode_word(t.flags, __uint_as_float(x.word));
+        return decode_word<TABLES>(t.flags, __uint_as_float(x.word));
     } else {
         if (t.flags & RZ_TEX_NARROW)
-            return decode_word(t.flags, x.sel == 0 ? x.q.x : (x.sel == 1 ? x.q.y : (x.sel == 2 ? x.q.z : x.q.w)));
+            return decode_word<TABLES>(t.flags, x.sel == 0 ? x.q.x : (x.sel == 1 ? x.q.y : (x.sel == 2 ? x.q.z : x.q.w)));
         return mk4(x.q.x, x.q.y, x.q.z, x.q.w);
     }
 }
@@ -342,7 +371,7 @@ RZ_DEV bool in_shadow(const DrawRec &D, const TexelT<NARROW> &texel, f3 depth_po
 /* ---- blinn: varyings = world_position[3] depth_position[3] texcoord[2] normal[3]
  *      (blinn_shader.h:16-21) --------------------------------------------- */
 
-template <bool NARROW>
+template <bool NARROW, class TABLES = GlobalTables>
 RZ_DEV f4 fs_blinn(const DrawRec &D, const float *v, bool backface, bool *discard) {
     float tu = v[6], tv = v[7];
     if (D.flags & RZ_DRAW_SHADOW_PASS) {                        /* blinn_shader.c:101-115 */
@@ -361,16 +390,16 @@ RZ_DEV f4 fs_blinn(const DrawRec &D, const float *v, bool backface, bool *discar
     f3 diffuse = mk3(D.base[0], D.base[1], D.base[2]);
     float alpha = D.base[3];
     if (D.maps[0].data) {
-        f4 s = decode_texel<NARROW>(D.maps[0], t0);
+        f4 s = decode_texel<NARROW, TABLES>(D.maps[0], t0);
         diffuse = mul3(diffuse, xyz(s));
         alpha *= s.w;
     }
     f3 specular = mk3(0, 0, 0);
-    if (D.maps[1].data) specular = xyz(decode_texel<NARROW>(D.maps[1], t1));
+    if (D.maps[1].data) specular = xyz(decode_texel<NARROW, TABLES>(D.maps[1], t1));
     f3 normal = unit3(mk3(v[8], v[9], v[10]));
     if (backface) normal = neg3(normal);
     f3 emission = mk3(0, 0, 0);
-    if (D.maps[2].data) emission = xyz(decode_texel<NARROW>(D.maps[2], t2));
+    if (D.maps[2].data) emission = xyz(decode_texel<NARROW, TABLES>(D.maps[2], t2));
 
     if (D.alpha_cutoff > 0 && alpha < D.alpha_cutoff) {         /* :220-222 */
         *discard = true;
@@ -411,7 +440,7 @@ struct Surface {
 
 RZ_DEV float largest3(f3 v) { return v.x > v.y && v.x > v.z ? v.x : (v.y > v.z ? v.y : v.z); }   /* pbr_shader.c:184 */
 
-template <bool NARROW>
+template <bool NARROW, class TABLES = GlobalTables>
 RZ_DEV Surface pbr_surface(const DrawRec &D, const float *v, bool backface) {
     Surface s;
     float tu = v[19], tv = v[20];
@@ -424,12 +453,12 @@ RZ_DEV Surface pbr_surface(const DrawRec &D, const float *v, bool backface) {
         float metal = D.metalness, rough = D.roughness;
         s.alpha = D.base[3];
         if (D.maps[0].data) {
-            f4 t = decode_texel<NARROW>(D.maps[0], t0);
+            f4 t = decode_texel<NARROW, TABLES>(D.maps[0], t0);
             base = mul3(base, xyz(t));
             s.alpha *= t.w;
         }
-        if (D.maps[1].data) metal *= decode_texel<NARROW>(D.maps[1], t1).x;
-        if (D.maps[2].data) rough *= decode_texel<NARROW>(D.maps[2], t2).x;
+        if (D.maps[1].data) metal *= decode_texel<NARROW, TABLES>(D.maps[1], t1).x;
+        if (D.maps[2].data) rough *= decode_texel<NARROW, TABLES>(D.maps[2], t2).x;
         s.diffuse = scale3(base, (1 - 0.04f) * (1 - metal));
         s.specular = mix3(mk3(0.04f, 0.04f, 0.04f), base, metal);
         s.roughness = rough;
@@ -439,18 +468,18 @@ RZ_DEV Surface pbr_surface(const DrawRec &D, const float *v, bool backface) {
         float gloss = D.glossiness;
         s.alpha = D.base[3];
         if (D.maps[0].data) {
-            f4 t = decode_texel<NARROW>(D.maps[0], t0);
+            f4 t = decode_texel<NARROW, TABLES>(D.maps[0], t0);
             diff = mul3(diff, xyz(t));
             s.alpha *= t.w;
         }
-        if (D.maps[1].data) spec = mul3(spec, xyz(decode_texel<NARROW>(D.maps[1], t1)));
-        if (D.maps[2].data) gloss *= decode_texel<NARROW>(D.maps[2], t2).x;
+        if (D.maps[1].data) spec = mul3(spec, xyz(decode_texel<NARROW, TABLES>(D.maps[1], t1)));
+        if (D.maps[2].data) gloss *= decode_texel<NARROW, TABLES>(D.maps[2], t2).x;
         s.diffuse = scale3(diff, 1 - largest3(spec));
         s.specular = spec;
         s.roughness = 1 - gloss;
     }
     if (D.maps[3].data) {                                       /* normal map, :224-243 */
-        f4 t = decode_texel<NARROW>(D.maps[3], t3);
+        f4 t = decode_texel<NARROW, TABLES>(D.maps[3], t3);
         f3 tn = mk3(t.x * 2 - 1, t.y * 2 - 1, t.z * 2 - 1);
         /* TBN has tangent, bitangent, normal as COLUMNS */
         f3 wn = mk3(v[13] * tn.x + v[16] * tn.y + v[10] * tn.z,
@@ -461,8 +490,8 @@ RZ_DEV Surface pbr_surface(const DrawRec &D, const float *v, bool backface) {
         s.normal = unit3(mk3(v[10], v[11], v[12]));
     }
     if (backface) s.normal = neg3(s.normal);
-    s.occlusion = D.maps[4].data ? decode_texel<NARROW>(D.maps[4], t4).x : 1.0f;           /* :259-264 */
-    s.emission = D.maps[5].data ? xyz(decode_texel<NARROW>(D.maps[5], t5)) : mk3(0, 0, 0);
+    s.occlusion = D.maps[4].data ? decode_texel<NARROW, TABLES>(D.maps[4], t4).x : 1.0f;           /* :259-264 */
+    s.emission = D.maps[5].data ? xyz(decode_texel<NARROW, TABLES>(D.maps[5], t5)) : mk3(0, 0, 0);
     return s;
 }
 
@@ -521,8 +550,9 @@ RZ_DEV f3 pbr_light(const Surface &s, f3 light, f3 n, f3 view) {
     return mk3(0, 0, 0);
 }
 
+template <class TABLES = GlobalTables>
 RZ_DEV f4 display_encode(f3 c, float alpha) {                    /* :401-406 */
-    return mk4(d_srgb(d_aces(c.x)), d_srgb(d_aces(c.y)), d_srgb(d_aces(c.z)), alpha);
+    return mk4(d_srgb<TABLES>(d_aces(c.x)), d_srgb<TABLES>(d_aces(c.y)), d_srgb<TABLES>(d_aces(c.z)), alpha);
 }
 
 /* layer inspector (:408-438) */
@@ -532,15 +562,16 @@ RZ_DEV bool right_of_band_edge(int edge, float px, float py) {
     float sx = (1 - space * 0.5f) - offset, ex = (space * (5 - 0.5f)) - offset;
     return (px - sx) * (1.0f - 0.0f) - (py - 0.0f) * (ex - sx) > 0;
 }
+template <class TABLES = GlobalTables>
 RZ_DEV f4 layer_color(int layer, const Surface &s) {
-    if (layer == 1) return display_encode(s.diffuse, s.alpha);
-    if (layer == 2) return display_encode(s.specular, s.alpha);
+    if (layer == 1) return display_encode<TABLES>(s.diffuse, s.alpha);
+    if (layer == 2) return display_encode<TABLES>(s.specular, s.alpha);
     if (layer == 3) return mk4(s.roughness, s.roughness, s.roughness, s.alpha);
     if (layer == 4) return mk4(s.occlusion, s.occlusion, s.occlusion, s.alpha);
     return mk4(s.normal.x * 0.5f + 0.5f, s.normal.y * 0.5f + 0.5f, s.normal.z * 0.5f + 0.5f, s.alpha);
 }
 
-template <bool NARROW>
+template <bool NARROW, class TABLES = GlobalTables>
 RZ_DEV f4 fs_pbr(const DrawRec &D, const float *v, bool backface, bool *discard) {
     if (D.flags & RZ_DRAW_SHADOW_PASS) {                        /* pbr_shader.c:113-136 */
         if (D.alpha_cutoff > 0) {
@@ -551,18 +582,18 @@ RZ_DEV f4 fs_pbr(const DrawRec &D, const float *v, bool backface, bool *discard)
         return mk4(0, 0, 0, 0);
     }
     const TexelT<NARROW> tshadow = load_shadow<NARROW>(D, mk3(v[3], v[4], v[5]));
-    Surface s = pbr_surface<NARROW>(D, v, backface);                    /* :446-490 */
+    Surface s = pbr_surface<NARROW, TABLES>(D, v, backface);                    /* :446-490 */
     float sxn = v[6] / v[9] * 0.5f + 0.5f;
     float syn = v[7] / v[9] * 0.5f + 0.5f;
     if (D.alpha_cutoff > 0 && s.alpha < D.alpha_cutoff) {
         *discard = true;
         return mk4(0, 0, 0, 0);
     } else if (D.layer_view > 0) {
-        return layer_color(D.layer_view, s);
+        return layer_color<TABLES>(D.layer_view, s);
     } else if (D.layer_view == 0 && !right_of_band_edge(0, sxn, syn)) {
         int edge;
         for (edge = 1; edge < 5; edge++) if (right_of_band_edge(edge, sxn, syn)) break;
-        return layer_color(edge, s);
+        return layer_color<TABLES>(edge, s);
     } else {
         f3 cam = mk3(D.camera_pos[0], D.camera_pos[1], D.camera_pos[2]);
         f3 view = unit3(sub3(cam, mk3(v[0], v[1], v[2])));
@@ -574,7 +605,7 @@ RZ_DEV f4 fs_pbr(const DrawRec &D, const float *v, bool backface, bool *discard)
             if (!in_shadow<NARROW>(D, tshadow, mk3(v[3], v[4], v[5]), n_dot_l))
                 color = add3(color, scale3(pbr_light(s, light, s.normal, view), D.punctual));
         }
-        return display_encode(color, s.alpha);
+        return display_encode<TABLES>(color, s.alpha);
     }
 }
 
