@@ -2227,16 +2227,34 @@ __global__ void __launch_bounds__(256 / PPL) rz_sky_kernel(const PassParams *__r
                 }
                 return;
             }
-            for (int q = 0; q < PPL; q++) {                 /* an edge of the sky box crosses the wave */
+            /* An edge or the diagonal of a sky box face crosses the region (one region in five): the lanes drew
+             * from two or three entries.  Each lane takes the reciprocal w and the corner varyings of ITS entry --
+             * entry by entry through scalar loads, kept by the lanes that drew from it -- and all are shaded
+             * together: per-lane gathers of records and varyings made the texture data path this kernel's bound. */
+            for (int q = 0; q < PPL; q++) {
                 if (!__any(want[q])) continue;
-                TriRec mq;
-                const float *m0 = vary_table, *m1 = vary_table, *m2 = vary_table;
-                if (want[q]) {
-                    mq = load_tri(&list[win[q]].rec);
-                    ref_varyings(list[win[q]].tri, vary_table, fan_vary_table, m0, m1, m2);
+                float rw[3] = {0, 0, 0}, c0[3] = {0, 0, 0}, c1[3] = {0, 0, 0}, c2[3] = {0, 0, 0};
+                for (uint32_t rest = entries; rest; rest &= rest - 1u) {
+                    const int e = __ffs((int)rest) - 1;
+                    const bool mine = want[q] && win[q] == e;
+                    if (!__any(mine)) continue;
+                    const BinEntry *entry = &list[e];
+                    const float r0 = entry->rec.rw[0], r1 = entry->rec.rw[1], r2 = entry->rec.rw[2];
+                    const float *e0, *e1, *e2;
+                    ref_varyings(entry->tri, vary_table, fan_vary_table, e0, e1, e2);
+                    for (int i = 0; i < 3; i++) {
+                        const float a = e0[i], b = e1[i], c = e2[i];
+                        if (mine) { c0[i] = a; c1[i] = b; c2[i] = c; }
+                    }
+                    if (mine) { rw[0] = r0; rw[1] = r1; rw[2] = r2; }
                 }
-                shade_lanes<2>(P, draw_table, want[q], mq, m0, m1, m2, px, py[q], ccur[q]);
-                if (want[q]) P.color[pixel[q]] = ccur[q];
+                if (want[q]) {
+                    const float q0 = rw[0] * w[q][0], q1 = rw[1] * w[q][1], q2 = rw[2] * w[q][2];    /* graphics.c:426-429 */
+                    const float norm = 1 / (q0 + q1 + q2);
+                    float v[4];
+                    for (int i = 0; i < 3; i++) v[i] = (c0[i] * q0 + c1[i] * q1 + c2[i] * q2) * norm;   /* :431-434 */
+                    P.color[pixel[q]] = sky_fragment(D, v, ccur[q]);
+                }
             }
             return;
         }
