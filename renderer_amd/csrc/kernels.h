@@ -935,6 +935,21 @@ RZ_DEV void interpolate_lane(const float *v0, const float *v1, const float *v2,
     }
 }
 
+/* The same for corners that are the same for every lane (one triangle under the whole wave).  The varyings
+ * were written by an earlier launch and nothing in this one changes them: read through the constant
+ * address space, which is how the compiler is told so -- the loads then go through the scalar unit; as
+ * ordinary global loads they went through the vector memory pipeline (its data path was the sky kernel's
+ * bound), because the choice between a triangle's and a fan's varyings hides where the pointer came from. */
+#define RZ_CONSTANT __attribute__((address_space(4)))
+typedef float rz_float4 __attribute__((ext_vector_type(4)));
+RZ_DEV void interpolate_uniform3(const float *v0, const float *v1, const float *v2,
+                                 float q0, float q1, float q2, float norm, float *out) {
+    const rz_float4 a = *(const rz_float4 RZ_CONSTANT*)v0, b = *(const rz_float4 RZ_CONSTANT*)v1, c = *(const rz_float4 RZ_CONSTANT*)v2;
+    out[0] = (a.x * q0 + b.x * q1 + c.x * q2) * norm;
+    out[1] = (a.y * q0 + b.y * q1 + c.y * q2) * norm;
+    out[2] = (a.z * q0 + b.z * q1 + c.z * q2) * norm;
+}
+
 /* barycentric weights of the pixel centre (graphics.c:385-397, 514) */
 RZ_DEV void pixel_weights(const TriRec &r, int px, int py, float &w0, float &w1, float &w2) {
     float apx = ((float)px + 0.5f) - r.ax, apy = ((float)py + 0.5f) - r.ay;
@@ -2011,7 +2026,7 @@ __global__ void __launch_bounds__(128) rz_strip_kernel(const PassParams *__restr
                     pixel_weights(m, px[q], py, w0, w1, w2);
                     const float q0 = m.rw[0] * w0, q1 = m.rw[1] * w1, q2 = m.rw[2] * w2;    /* graphics.c:426-429 */
                     const float norm = 1 / (q0 + q1 + q2);
-                    interpolate_lane<3>(m0, m1, m2, q0, q1, q2, norm, v);
+                    interpolate_uniform3(m0, m1, m2, q0, q1, q2, norm, v);
                     P.color[pixel[q]] = sky_fragment(D, v, ccur[q]);            /* no blending in these passes */
                 }
                 if (P.counters) {       /* [8] fragments shaded on the device, [9] of those, skybox */
@@ -2222,7 +2237,7 @@ __global__ void __launch_bounds__(256 / PPL) rz_sky_kernel(const PassParams *__r
                     float v[4];
                     const float q0 = m.rw[0] * w[q][0], q1 = m.rw[1] * w[q][1], q2 = m.rw[2] * w[q][2];    /* graphics.c:426-429 */
                     const float norm = 1 / (q0 + q1 + q2);
-                    interpolate_lane<3>(m0, m1, m2, q0, q1, q2, norm, v);
+                    interpolate_uniform3(m0, m1, m2, q0, q1, q2, norm, v);
                     P.color[pixel[q]] = sky_fragment(D, v, ccur[q]);
                 }
                 return;
@@ -2242,9 +2257,11 @@ __global__ void __launch_bounds__(256 / PPL) rz_sky_kernel(const PassParams *__r
                     const float r0 = entry->rec.rw[0], r1 = entry->rec.rw[1], r2 = entry->rec.rw[2];
                     const float *e0, *e1, *e2;
                     ref_varyings(entry->tri, vary_table, fan_vary_table, e0, e1, e2);
-                    for (int i = 0; i < 3; i++) {
-                        const float a = e0[i], b = e1[i], c = e2[i];
-                        if (mine) { c0[i] = a; c1[i] = b; c2[i] = c; }
+                    const rz_float4 a = *(const rz_float4 RZ_CONSTANT*)e0, b = *(const rz_float4 RZ_CONSTANT*)e1, c = *(const rz_float4 RZ_CONSTANT*)e2;
+                    if (mine) {
+                        c0[0] = a.x; c0[1] = a.y; c0[2] = a.z;
+                        c1[0] = b.x; c1[1] = b.y; c1[2] = b.z;
+                        c2[0] = c.x; c2[1] = c.y; c2[2] = c.z;
                     }
                     if (mine) { rw[0] = r0; rw[1] = r1; rw[2] = r2; }
                 }
@@ -2292,7 +2309,7 @@ __global__ void __launch_bounds__(256 / PPL) rz_sky_kernel(const PassParams *__r
             pixel_weights(m, px, py[q], w0, w1, w2);
             const float q0 = m.rw[0] * w0, q1 = m.rw[1] * w1, q2 = m.rw[2] * w2;    /* graphics.c:426-429 */
             const float norm = 1 / (q0 + q1 + q2);
-            interpolate_lane<3>(m0, m1, m2, q0, q1, q2, norm, v);
+            interpolate_uniform3(m0, m1, m2, q0, q1, q2, norm, v);
             P.color[pixel[q]] = sky_fragment(D, v, ccur[q]);                    /* no blending in these passes */
         }
         if (P.counters) {       /* [8] fragments shaded on the device, [9] of those, skybox */
