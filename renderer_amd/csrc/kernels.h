@@ -83,7 +83,8 @@ __global__ void __launch_bounds__(256) rz_vertex_kernel(const PassParams *__rest
         float4 q = src[i];
         a[4 * i] = q.x; a[4 * i + 1] = q.y; a[4 * i + 2] = q.z; a[4 * i + 3] = q.w;
     }
-    float *vary = P.vary + (size_t)gv * RZ_VARY_STRIDE;
+    float vary[RZ_VARY_STRIDE];     /* put together in registers, stored as whole groups of four below */
+    for (int k = 0; k < RZ_VARY_STRIDE; k++) vary[k] = 0;
     f4 pos = mk4(a[0], a[1], a[2], 1.0f);
     f4 clip;
 
@@ -104,7 +105,7 @@ __global__ void __launch_bounds__(256) rz_vertex_kernel(const PassParams *__rest
         f4 light_space = m4v4(D.light_vp, world);
         if (D.flags & RZ_DRAW_SHADOW_PASS) {                    /* shadow_vertex_shader */
             clip = light_space;
-            int tc = D.family == 0 ? 6 : 19;
+            int tc = D.family == 0 ? RZ_BV_TEXCOORD : RZ_PV_TEXCOORD;
             vary[tc] = a[3]; vary[tc + 1] = a[4];
         } else {
             float nmat[9];
@@ -117,34 +118,38 @@ __global__ void __launch_bounds__(256) rz_vertex_kernel(const PassParams *__rest
             }
             clip = m4v4(D.camera_vp, world);
             f3 n = m3v3(nmat, mk3(a[5], a[6], a[7]));
-            vary[0] = world.x; vary[1] = world.y; vary[2] = world.z;
-            vary[3] = light_space.x; vary[4] = light_space.y; vary[5] = light_space.z;
+            vary[0] = world.x; vary[1] = world.y; vary[2] = world.z;           /* RZ_PV_WORLD == 0 */
             if (D.family == 0) {                                /* blinn common_vertex_shader */
+                vary[3] = light_space.x; vary[4] = light_space.y; vary[5] = light_space.z;
                 n = unit3(n);
                 vary[6] = a[3]; vary[7] = a[4];
                 vary[8] = n.x; vary[9] = n.y; vary[10] = n.z;
             } else {                                            /* pbr common_vertex_shader */
-                vary[6] = clip.x; vary[7] = clip.y; vary[8] = clip.z; vary[9] = clip.w;
+                vary[RZ_PV_CLIP] = clip.x; vary[RZ_PV_CLIP + 1] = clip.y; vary[RZ_PV_CLIP + 2] = clip.z; vary[RZ_PV_CLIP + 3] = clip.w;
+                vary[RZ_PV_DEPTH] = light_space.x; vary[RZ_PV_DEPTH + 1] = light_space.y; vary[RZ_PV_DEPTH + 2] = light_space.z;
                 n = unit3(n);
-                vary[10] = n.x; vary[11] = n.y; vary[12] = n.z;
+                vary[RZ_PV_NORMAL] = n.x; vary[RZ_PV_NORMAL + 1] = n.y; vary[RZ_PV_NORMAL + 2] = n.z;
                 if (D.maps[3].data) {
                     float tm[9] = {model[0], model[1], model[2], model[4], model[5], model[6],
                                    model[8], model[9], model[10]};
                     f3 t = unit3(m3v3(tm, mk3(a[8], a[9], a[10])));
                     f3 b = scale3(cross3(n, t), a[11]);
-                    vary[13] = t.x; vary[14] = t.y; vary[15] = t.z;
-                    vary[16] = b.x; vary[17] = b.y; vary[18] = b.z;
+                    vary[RZ_PV_TANGENT] = t.x; vary[RZ_PV_TANGENT + 1] = t.y; vary[RZ_PV_TANGENT + 2] = t.z;
+                    vary[RZ_PV_BITANGENT] = b.x; vary[RZ_PV_BITANGENT + 1] = b.y; vary[RZ_PV_BITANGENT + 2] = b.z;
                 } else {
                     /* the reference leaves tangent/bitangent untouched here;
                      * nothing reads them without a normal map */
-                    vary[13] = 0; vary[14] = 0; vary[15] = 0;
-                    vary[16] = 0; vary[17] = 0; vary[18] = 0;
+                    for (int k = 0; k < 3; k++) { vary[RZ_PV_TANGENT + k] = 0; vary[RZ_PV_BITANGENT + k] = 0; }
                 }
-                vary[19] = a[3]; vary[20] = a[4];
+                vary[RZ_PV_TEXCOORD] = a[3]; vary[RZ_PV_TEXCOORD + 1] = a[4];
             }
         }
     }
     P.clip.as<float4>()[gv] = make_float4(clip.x, clip.y, clip.z, clip.w);
+    float4 RZ_GLOBAL *out = (float4 RZ_GLOBAL*)(P.vary + (size_t)gv * RZ_VARY_STRIDE);
+    const int groups = (D.num_varyings + 3) / 4;                /* 1 skybox, 3 blinn, 6 pbr */
+    for (int i = 0; i < RZ_VARY_STRIDE / 4; i++)
+        if (i < groups) out[i] = make_float4(vary[4 * i], vary[4 * i + 1], vary[4 * i + 2], vary[4 * i + 3]);
 }
 
 /* ========================================================================
@@ -950,6 +955,19 @@ RZ_DEV void interpolate_uniform3(const float *v0, const float *v1, const float *
     out[2] = (a.z * q0 + b.z * q1 + c.z * q2) * norm;
 }
 
+/* the same for floats FIRST .. NV - 1 only (whole groups of four are fetched) */
+template <int FIRST, int NV>
+RZ_DEV void interpolate_lane_from(const float *v0, const float *v1, const float *v2,
+                                  float q0, float q1, float q2, float norm, float *out) {
+    for (int i = FIRST / 4; i < (NV + 3) / 4; i++) {
+        float4 a = ((const float4*)v0)[i], b = ((const float4*)v1)[i], c = ((const float4*)v2)[i];
+        if (4 * i + 0 >= FIRST && 4 * i + 0 < NV) out[4 * i + 0] = (a.x * q0 + b.x * q1 + c.x * q2) * norm;
+        if (4 * i + 1 >= FIRST && 4 * i + 1 < NV) out[4 * i + 1] = (a.y * q0 + b.y * q1 + c.y * q2) * norm;
+        if (4 * i + 2 >= FIRST && 4 * i + 2 < NV) out[4 * i + 2] = (a.z * q0 + b.z * q1 + c.z * q2) * norm;
+        if (4 * i + 3 >= FIRST && 4 * i + 3 < NV) out[4 * i + 3] = (a.w * q0 + b.w * q1 + c.w * q2) * norm;
+    }
+}
+
 /* barycentric weights of the pixel centre (graphics.c:385-397, 514) */
 RZ_DEV void pixel_weights(const TriRec &r, int px, int py, float &w0, float &w1, float &w2) {
     float apx = ((float)px + 0.5f) - r.ax, apy = ((float)py + 0.5f) - r.ay;
@@ -999,7 +1017,10 @@ RZ_DEV void shade_lanes(const PassParams &P, const DrawRec *__restrict__ draw_ta
                 color = fs_blinn<NARROW, TABLES>(D, v, backface, &discard);
             } else if ((FAMILY < 0 || FAMILY == 1) && D.family == 1) {
                 float v[24];
-                interpolate_lane<21>(m0, m1, m2, q0, q1, q2, norm, v);
+                interpolate_lane<RZ_PV_ALWAYS>(m0, m1, m2, q0, q1, q2, norm, v);
+                for (int k = RZ_PV_ALWAYS; k < RZ_PV_COUNT; k++) v[k] = 0;
+                if (pbr_reads_positions(D))             /* uniform over the draw */
+                    interpolate_lane_from<RZ_PV_ALWAYS, RZ_PV_COUNT>(m0, m1, m2, q0, q1, q2, norm, v);
                 color = fs_pbr<NARROW, TABLES>(D, v, backface, &discard);
             }
             /* draw_fragment (graphics.c:452-468); a discard was settled during rasterisation */
@@ -1206,7 +1227,7 @@ RZ_DEV void raster_tile(const PassParams &P, const uint32_t pass_index, const ui
                 /* the shaders' discard test (blinn_shader.c:104-113, 220; pbr_shader.c:116-134, 452):
                  * alpha = base alpha * first map's alpha, from the interpolated texcoord */
                 const DrawRec &D = draw_table[RZ_META_DRAW(r.meta)];
-                const int tc = D.family == 0 ? 6 : 19;
+                const int tc = D.family == 0 ? RZ_BV_TEXCOORD : RZ_PV_TEXCOORD;
                 const float *v0, *v1, *v2;
                 ref_varyings(ref, vary_table, fan_vary_table, v0, v1, v2);
                 float q0 = r.rw[0] * w0, q1 = r.rw[1] * w1, q2 = r.rw[2] * w2;
@@ -1566,7 +1587,7 @@ __global__ void __launch_bounds__(256 / PPL) rz_visibility_kernel(const PassPara
                 /* the shaders' discard test (blinn_shader.c:104-113, 220; pbr_shader.c:116-134, 452):
                  * alpha = base alpha * first map's alpha, from the interpolated texcoord */
                 const DrawRec &D = draw_table[RZ_META_DRAW(r.meta)];
-                const int tc = D.family == 0 ? 6 : 19;
+                const int tc = D.family == 0 ? RZ_BV_TEXCOORD : RZ_PV_TEXCOORD;
                 const float *v0, *v1, *v2;
                 ref_varyings(ref, vary_table, fan_vary_table, v0, v1, v2);
                 for (int q = 0; q < PPL; q++) {
@@ -1949,7 +1970,7 @@ __global__ void __launch_bounds__(128) rz_strip_kernel(const PassParams *__restr
                     /* the shaders' discard test (blinn_shader.c:104-113, 220; pbr_shader.c:116-134, 452):
                      * alpha = base alpha * first map's alpha, from the interpolated texcoord */
                     const DrawRec &D = draw_table[RZ_META_DRAW(r.meta)];
-                    const int tc = D.family == 0 ? 6 : 19;
+                    const int tc = D.family == 0 ? RZ_BV_TEXCOORD : RZ_PV_TEXCOORD;
                     const float *v0, *v1, *v2;
                     ref_varyings(ref, vary_table, fan_vary_table, v0, v1, v2);
                     for (int q = 0; q < PPL; q++) {

@@ -42,6 +42,12 @@ template <class T> struct rz_gptr {
 };
 
 #define RZ_VARY_STRIDE 24           /* floats per vertex in vary[] (max used: 21) */
+/* Where the pbr varyings (pbr_shader.h:29-37) sit in a vertex's block: what every fragment reads in the
+ * first four groups of four floats, what only shadow mapping and the layer inspector read behind them,
+ * so that the other fragments fetch four groups per corner instead of six. */
+enum { RZ_PV_WORLD = 0, RZ_PV_NORMAL = 3, RZ_PV_TANGENT = 6, RZ_PV_BITANGENT = 9, RZ_PV_TEXCOORD = 12,
+       RZ_PV_DEPTH = 14, RZ_PV_CLIP = 17, RZ_PV_ALWAYS = 14, RZ_PV_COUNT = 21 };
+#define RZ_BV_TEXCOORD 6            /* blinn_shader.h:16-21: world position, depth position, texcoord, normal */
 #define RZ_MAX_POLY 10              /* corners of a triangle clipped by 7 planes */
 #define RZ_MAX_FAN 8                /* RZ_MAX_POLY - 2 */
 #define RZ_BIN 64                   /* bin edge in pixels */

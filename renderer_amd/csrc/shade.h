@@ -412,7 +412,7 @@ RZ_DEV f4 fs_blinn(const DrawRec &D, const float *v, bool backface, bool *discar
         float n_dot_l = dot3(normal, light);
         if (n_dot_l > 0 && !in_shadow<NARROW>(D, tshadow, mk3(v[3], v[4], v[5]), n_dot_l)) {
             f3 cam = mk3(D.camera_pos[0], D.camera_pos[1], D.camera_pos[2]);
-            f3 view = unit3(sub3(cam, mk3(v[0], v[1], v[2])));
+            f3 view = unit3(sub3(cam, mk3(v[RZ_PV_WORLD], v[RZ_PV_WORLD + 1], v[RZ_PV_WORLD + 2])));
             f3 spec = mk3(0, 0, 0);
             if (!(specular.x == 0 && specular.y == 0 && specular.z == 0)) {      /* :201-212 */
                 f3 half = unit3(add3(light, view));
@@ -443,7 +443,7 @@ RZ_DEV float largest3(f3 v) { return v.x > v.y && v.x > v.z ? v.x : (v.y > v.z ?
 template <bool NARROW, class TABLES = GlobalTables>
 RZ_DEV Surface pbr_surface(const DrawRec &D, const float *v, bool backface) {
     Surface s;
-    float tu = v[19], tv = v[20];
+    float tu = v[RZ_PV_TEXCOORD], tv = v[RZ_PV_TEXCOORD + 1];
     /* the six material texels in flight together */
     const MapCell cell = first_cell(D.maps[0].data ? D.maps[0] : D.maps[3], tu, tv);
     const TexelT<NARROW> t0 = load_like<NARROW>(D.maps[0], cell), t1 = load_like<NARROW>(D.maps[1], cell), t2 = load_like<NARROW>(D.maps[2], cell);
@@ -482,12 +482,13 @@ RZ_DEV Surface pbr_surface(const DrawRec &D, const float *v, bool backface) {
         f4 t = decode_texel<NARROW, TABLES>(D.maps[3], t3);
         f3 tn = mk3(t.x * 2 - 1, t.y * 2 - 1, t.z * 2 - 1);
         /* TBN has tangent, bitangent, normal as COLUMNS */
-        f3 wn = mk3(v[13] * tn.x + v[16] * tn.y + v[10] * tn.z,
-                    v[14] * tn.x + v[17] * tn.y + v[11] * tn.z,
-                    v[15] * tn.x + v[18] * tn.y + v[12] * tn.z);
+        const float *tg = v + RZ_PV_TANGENT, *bt = v + RZ_PV_BITANGENT, *nm = v + RZ_PV_NORMAL;
+        f3 wn = mk3(tg[0] * tn.x + bt[0] * tn.y + nm[0] * tn.z,
+                    tg[1] * tn.x + bt[1] * tn.y + nm[1] * tn.z,
+                    tg[2] * tn.x + bt[2] * tn.y + nm[2] * tn.z);
         s.normal = unit3(wn);
     } else {
-        s.normal = unit3(mk3(v[10], v[11], v[12]));
+        s.normal = unit3(mk3(v[RZ_PV_NORMAL], v[RZ_PV_NORMAL + 1], v[RZ_PV_NORMAL + 2]));
     }
     if (backface) s.normal = neg3(s.normal);
     s.occlusion = D.maps[4].data ? decode_texel<NARROW, TABLES>(D.maps[4], t4).x : 1.0f;           /* :259-264 */
@@ -571,20 +572,26 @@ RZ_DEV f4 layer_color(int layer, const Surface &s) {
     return mk4(s.normal.x * 0.5f + 0.5f, s.normal.y * 0.5f + 0.5f, s.normal.z * 0.5f + 0.5f, s.alpha);
 }
 
+/* does a fragment of this draw read the depth position (shadow map) or the clip position (layer bands)? */
+RZ_DEV bool pbr_reads_positions(const DrawRec &D) {
+    return (D.flags & RZ_DRAW_SHADOW_PASS) == 0 && (D.shadow_map.data != nullptr || D.layer_view == 0);
+}
+
 template <bool NARROW, class TABLES = GlobalTables>
 RZ_DEV f4 fs_pbr(const DrawRec &D, const float *v, bool backface, bool *discard) {
     if (D.flags & RZ_DRAW_SHADOW_PASS) {                        /* pbr_shader.c:113-136 */
         if (D.alpha_cutoff > 0) {
             float a = D.base[3];    /* basecolor_factor.w or diffuse_factor.w */
-            if (D.maps[0].data) a *= sample_repeat(D.maps[0], v[19], v[20]).w;
+            if (D.maps[0].data) a *= sample_repeat(D.maps[0], v[RZ_PV_TEXCOORD], v[RZ_PV_TEXCOORD + 1]).w;
             if (a < D.alpha_cutoff) *discard = true;
         }
         return mk4(0, 0, 0, 0);
     }
-    const TexelT<NARROW> tshadow = load_shadow<NARROW>(D, mk3(v[3], v[4], v[5]));
+    const f3 depth_position = mk3(v[RZ_PV_DEPTH], v[RZ_PV_DEPTH + 1], v[RZ_PV_DEPTH + 2]);
+    const TexelT<NARROW> tshadow = load_shadow<NARROW>(D, depth_position);
     Surface s = pbr_surface<NARROW, TABLES>(D, v, backface);                    /* :446-490 */
-    float sxn = v[6] / v[9] * 0.5f + 0.5f;
-    float syn = v[7] / v[9] * 0.5f + 0.5f;
+    float sxn = v[RZ_PV_CLIP] / v[RZ_PV_CLIP + 3] * 0.5f + 0.5f;
+    float syn = v[RZ_PV_CLIP + 1] / v[RZ_PV_CLIP + 3] * 0.5f + 0.5f;
     if (D.alpha_cutoff > 0 && s.alpha < D.alpha_cutoff) {
         *discard = true;
         return mk4(0, 0, 0, 0);
@@ -596,13 +603,13 @@ RZ_DEV f4 fs_pbr(const DrawRec &D, const float *v, bool backface, bool *discard)
         return layer_color<TABLES>(edge, s);
     } else {
         f3 cam = mk3(D.camera_pos[0], D.camera_pos[1], D.camera_pos[2]);
-        f3 view = unit3(sub3(cam, mk3(v[0], v[1], v[2])));
+        f3 view = unit3(sub3(cam, mk3(v[RZ_PV_WORLD], v[RZ_PV_WORLD + 1], v[RZ_PV_WORLD + 2])));
         f3 light = neg3(mk3(D.light_dir[0], D.light_dir[1], D.light_dir[2]));
         float n_dot_l = dot3(s.normal, light);
         f3 color = s.emission;
         if (D.ambient > 0 && D.ibl) color = add3(color, scale3(pbr_ambient<NARROW>(s, D.ibl, s.normal, view), D.ambient));
         if (D.punctual > 0 && n_dot_l > 0) {
-            if (!in_shadow<NARROW>(D, tshadow, mk3(v[3], v[4], v[5]), n_dot_l))
+            if (!in_shadow<NARROW>(D, tshadow, depth_position, n_dot_l))
                 color = add3(color, scale3(pbr_light(s, light, s.normal, view), D.punctual));
         }
         return display_encode<TABLES>(color, s.alpha);
