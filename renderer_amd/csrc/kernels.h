@@ -890,15 +890,18 @@ RZ_DEV uint32_t pack_rgb(f4 c, uint32_t keep) {                 /* float_to_ucha
  * truncating is a function of the texel alone -- worked out once per texel when the map is first drawn
  * (rz_texture_display_kernel; the six faces in one plane, so that a lane's face is an offset, not a
  * pointer to fetch), the fragment then reads 4 bytes instead of 16 and converts nothing. */
+/* where a direction's texel sits in the cube's plane of display bytes (RZ_DRAW_SKY_BYTES draws):
+ * maps[0] describes all six faces, one behind the other; size and layout are scalars */
+RZ_DEV uint32_t sky_bytes_index(const DrawRec &D, const float *v) {
+    float s, t;
+    const int face = cube_face(mk3(v[0], v[1], v[2]), &s, &t);
+    const int w = D.maps[0].w, h = D.maps[0].h, flags = D.maps[0].flags;
+    const float x = s, y = 1 - t;                                   /* texture.c:257, 160-167 */
+    return __umul24((uint32_t)face, (uint32_t)(w * h)) + texel_cell(w, h, flags, x - floorf(x), y - floorf(y));
+}
 RZ_DEV uint32_t sky_fragment(const DrawRec &D, const float *v, uint32_t below) {
     if (D.flags & RZ_DRAW_SKY_BYTES) {
-        /* maps[0]: the cube's six faces as display bytes, one behind the other (size and layout are scalars) */
-        float s, t;
-        const int face = cube_face(mk3(v[0], v[1], v[2]), &s, &t);
-        const int w = D.maps[0].w, h = D.maps[0].h, flags = D.maps[0].flags;
-        const float x = s, y = 1 - t;                               /* texture.c:257, 160-167 */
-        const uint32_t cell = texel_cell(w, h, flags, x - floorf(x), y - floorf(y));
-        const uint32_t word = D.maps[0].data.as<const uint32_t>()[__umul24((uint32_t)face, (uint32_t)(w * h)) + cell];
+        const uint32_t word = D.maps[0].data.as<const uint32_t>()[sky_bytes_index(D, v)];
         return (word & 0x00ffffffu) | (below & 0xff000000u);
     }
     f4 color = fs_skybox(D, v);
@@ -2243,15 +2246,24 @@ __global__ void __launch_bounds__(256 / PPL) rz_sky_kernel(const PassParams *__r
                 if ((entries & (entries - 1u)) == 0u && __all(every)) {
                     const float *m0, *m1, *m2;
                     ref_varyings(m_ref, vary_table, fan_vary_table, m0, m1, m2);
+                    uint32_t below[PPL], at[PPL];
+                    float v[PPL][4];
                     for (int q = 0; q < PPL; q++) {
                         P.depth[pixel[q]] = zcur[q];
-                        uint32_t below = P.clear_color;     /* only lends its alpha byte */
-                        if (!P.clear_color_pending) below = P.color[pixel[q]];
-                        float v[4];
+                        below[q] = P.clear_color;           /* only lends its alpha byte */
+                        if (!P.clear_color_pending) below[q] = P.color[pixel[q]];
                         const float q0 = m.rw[0] * w[q][0], q1 = m.rw[1] * w[q][1], q2 = m.rw[2] * w[q][2];    /* graphics.c:426-429 */
                         const float norm = 1 / (q0 + q1 + q2);
-                        interpolate_uniform3(m0, m1, m2, q0, q1, q2, norm, v);
-                        P.color[pixel[q]] = sky_fragment(D, v, below);
+                        interpolate_uniform3(m0, m1, m2, q0, q1, q2, norm, v[q]);
+                    }
+                    if (D.flags & RZ_DRAW_SKY_BYTES) {      /* both texels asked for before either is waited for */
+                        const uint32_t RZ_GLOBAL *bytes = D.maps[0].data.as<const uint32_t>();
+                        for (int q = 0; q < PPL; q++) at[q] = sky_bytes_index(D, v[q]);
+                        uint32_t word[PPL];
+                        for (int q = 0; q < PPL; q++) word[q] = bytes[at[q]];
+                        for (int q = 0; q < PPL; q++) P.color[pixel[q]] = (word[q] & 0x00ffffffu) | (below[q] & 0xff000000u);
+                    } else {
+                        for (int q = 0; q < PPL; q++) P.color[pixel[q]] = sky_fragment(D, v[q], below[q]);
                     }
                     return;
                 }
