@@ -390,3 +390,62 @@ def test_skybox_of_caller_made_faces_replaced_between_frames(gpu, oracle, eight_
     n = len(views)
     assert any(not same(results[1][i], results[1][n + i]) for i in range(n))       # the new faces are in view somewhere
     assert all(int((f[1] < 0.9).sum()) > 1000 for f in results[0])                  # the triangle in front is there
+
+
+@pytest.mark.parametrize("blend", [0, 1], ids=["opaque", "second_blended"])
+def test_two_sky_boxes_in_one_pass(gpu, oracle, blend):
+    """A sky box from inside, then triangles of a SECOND sky program (another cube map) over parts of it, all
+    in one pass and at the sky's one depth, so the later draw wins wherever it lies (graphics.c:523).  Bins
+    whose lists hold entries of both draws and bins that hold one draw's entries only sit side by side; the
+    library takes them through different kernels, the frames must not show where.  With the second program
+    blending (its texels' alpha over the first sky's bytes, graphics.c:455-463) the pass is cut in two and the
+    second sky is shaded from float texels inside the ordered kernel."""
+    size, views = (384, 256), [(0.4, 0.1), (3.3, -0.7)]
+    rng = np.random.default_rng(91)
+    first = [rng.integers(0, 256, (64, 64, 4)).astype(np.float32) / np.float32(255) for _ in range(6)]
+    second = [rng.uniform(0.0, 1.2, (16, 16, 4)).astype(np.float32) for _ in range(6)]
+    results = []
+    for pipe in (gpu, oracle):
+        lib = pipe.lib
+        declare(lib)
+        P = C.c_void_p
+        lib.texture_create.restype = C.POINTER(HostTexture)
+        lib.texture_create.argtypes = [C.c_int, C.c_int]
+        lib.texture_release.argtypes = [C.POINTER(HostTexture)]
+        lib.texture_invalidate.argtypes = [C.POINTER(HostTexture)]
+        cubes, programs = [], []
+        for images in (first, second):
+            cube = Cubemap()
+            for i, image in enumerate(images):
+                cube.faces[i] = lib.texture_create(image.shape[1], image.shape[0])
+                np.ctypeslib.as_array(cube.faces[i].contents.buffer, image.shape)[...] = image
+                lib.texture_invalidate(cube.faces[i])
+            prog = lib.program_create(fn(lib, "skybox_vertex_shader"), fn(lib, "skybox_fragment_shader"), 12, 12, 72, 1,
+                                      blend if images is second else 0)
+            SkyboxUniforms.from_address(lib.program_get_uniforms(prog)).skybox = C.cast(C.pointer(cube), P)
+            cubes.append(cube)
+            programs.append(prog)
+        frames = []
+        for yaw, pitch in views:
+            fb = pipe.framebuffer(*size)
+            lib.framebuffer_clear_color(fb, Vec4(0.2, 0.2, 0.2, 1.0))
+            lib.framebuffer_clear_depth(fb, 1.0)
+            vp = [float(x) for x in look_from_inside(size[0] / size[1], yaw, pitch).reshape(-1)]
+            for prog, quads in ((programs[0], CUBE_FACES), (programs[1], CUBE_FACES[:2])):
+                SkyboxUniforms.from_address(lib.program_get_uniforms(prog)).vp_matrix[:] = vp
+                for quad in quads:
+                    for tri in ((quad[0], quad[1], quad[2]), (quad[0], quad[2], quad[3])):
+                        for j in range(3):
+                            corner = CUBE_CORNERS[tri[j]] * (np.float32(1.0) if prog == programs[0] else np.float32(0.6))
+                            (C.c_float * 3).from_address(lib.program_get_attribs(prog, j))[:] = [float(x) for x in corner]
+                        lib.graphics_draw_triangle(C.cast(fb, P), prog)
+            frames.append(pipe.read(fb))
+            pipe.release(fb)
+        for prog in programs:
+            lib.program_release(prog)
+        for cube in cubes:
+            for i in range(6):
+                lib.texture_release(cube.faces[i])
+        results.append(frames)
+    for got, want in zip(*results):
+        assert same(got, want)
