@@ -9,12 +9,13 @@ off, so the expected result is much tighter: identical coverage and depth, and
 colour differing only where the device's double-precision pow() rounds
 differently from glibc's."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
 
 from __graft_entry__ import compare_frames
-from conftest import golden_cases, load_golden, render_case
+from conftest import REPO, golden_cases, load_golden, render_case
 
 pytestmark = pytest.mark.gpu
 
@@ -347,3 +348,14 @@ def test_gpu_frames_without_their_alpha_bytes(gpu, size):
     assert np.all(got[h * w * 3:] == 7)                  # nothing behind the image is touched
     gpu.release(fb)
     gpu.close_scene(scene)
+
+
+@pytest.mark.gpu
+def test_gpu_random_views_match_oracle():
+    """tools/fuzz_parity.py for a few dozen views: ragged sizes, cameras inside the models and near the sky
+    box, random animation times, frames rendered twice into one framebuffer."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(REPO, "tools", "fuzz_parity.py"), "40", "3"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "FUZZ 40 views 0 mismatches" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
