@@ -34,7 +34,8 @@ def refhost():
 
 
 def test_reference_host_links_against_the_gpu_library(refhost):
-    """Link line of INTEGRATION.md with -Wl,--no-undefined: nothing the reference's host calls is missing."""
+    """The reference's host (everything but core/graphics.c and core/texture.c) linked against the library with
+    -Wl,--no-undefined: nothing it calls is missing."""
     exe = refhost["mi355r"]
     assert os.path.exists(exe)
     dynamic = subprocess.run(["readelf", "-d", exe], check=True, capture_output=True, text=True).stdout
