@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Random views of every scene through the GPU library and the CPU oracle, compared bit for bit:
-tools/fuzz_parity.py [iterations] [seed].  Sizes are ragged on purpose (bins, tiles and sky regions cut by
+tools/fuzz_parity.py [iterations] [seed] [largest width].  Sizes are ragged on purpose (bins, tiles and sky regions cut by
 the frame's edges), cameras go inside the models and close to the sky box (clipping), times are random
 (animation), and every few views a frame is rendered twice into the same framebuffer (pending clears
 against a used buffer, the strip height that follows the last frame)."""
@@ -20,6 +20,7 @@ from renderer_amd.configs import CONFIGS                            # noqa: E402
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 60
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+    widest = int(sys.argv[3]) if len(sys.argv) > 3 else 520
     gpu, oracle = Pipeline(GPU_LIB), Pipeline(ORACLE_LIB)
     scenes = [(name, like) for _, name, like, _, _ in CONFIGS] + [("craftsman", None), ("drone", None)]
     opened = {}
@@ -35,7 +36,7 @@ def main():
         if opened[(name, like)] is None:
             continue
         gs, os_ = opened[(name, like)]
-        w, h = int(rng.integers(33, 520)), int(rng.integers(17, 300))
+        w, h = int(rng.integers(33, widest)), int(rng.integers(17, max(18, widest * 9 // 16)))
         radius = float(rng.choice([0.05, 0.3, 0.8, 1.5, 3.0]))
         direction = rng.normal(size=3)
         direction /= np.linalg.norm(direction)
