@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Random views of every scene through the GPU library and the CPU oracle, compared bit for bit:
-tools/fuzz_parity.py [iterations] [seed] [largest width].  Sizes are ragged on purpose (bins, tiles and sky regions cut by
+tests/fuzz_parity.py [iterations] [seed] [largest width].  Sizes are ragged on purpose (bins, tiles and sky regions cut by
 the frame's edges), cameras go inside the models and close to the sky box (clipping), times are random
 (animation), and every few views a frame is rendered twice into the same framebuffer (pending clears
 against a used buffer, the strip height that follows the last frame)."""
@@ -11,7 +11,7 @@ import numpy as np
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
-sys.path.insert(0, os.path.join(REPO, "tests"))
+sys.path.insert(0, os.path.join(REPO, "tests"))     # test infrastructure: the oracle is the checker here
 from conftest import ORACLE_LIB                                   # noqa: E402
 from renderer_amd.binding import GPU_LIB, SCENES, Pipeline         # noqa: E402
 from renderer_amd.configs import CONFIGS                            # noqa: E402

@@ -352,10 +352,10 @@ def test_gpu_frames_without_their_alpha_bytes(gpu, size):
 
 @pytest.mark.gpu
 def test_gpu_random_views_match_oracle():
-    """tools/fuzz_parity.py for a few dozen views: ragged sizes, cameras inside the models and near the sky
+    """tests/fuzz_parity.py for a few dozen views: ragged sizes, cameras inside the models and near the sky
     box, random animation times, frames rendered twice into one framebuffer."""
     import subprocess
     import sys
-    r = subprocess.run([sys.executable, os.path.join(REPO, "tools", "fuzz_parity.py"), "40", "3"],
+    r = subprocess.run([sys.executable, os.path.join(REPO, "tests", "fuzz_parity.py"), "40", "3"],
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "FUZZ 40 views 0 mismatches" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
