@@ -348,6 +348,33 @@ extern "C" int mi355r_init(int device) {
             tables.m0[i] = pow(1.0 + i / 32.0, 1 / 2.2);
             tables.inv[i] = 1.0 / (1.0 + i / 32.0);
         }
+        /* ... and the steps of d_srgb_for_bytes: the byte of v as the reference computes it (maths.c:41, :33),
+         * bisected over the positive floats, which are ordered like their bit patterns */
+        auto byte_of_linear = [](float v) { return (int)(unsigned char)((float)pow((double)v, 1 / 2.2) * 255); };
+        tables.step[0] = 0.0f;
+        for (int k = 1; k < 256; k++) {
+            uint32_t lo = 1u, hi = 0x3f800000u;             /* byte(lo) = 0 < k <= 255 = byte(1.0f) */
+            while (hi - lo > 1u) {
+                const uint32_t mid = lo + (hi - lo) / 2u;
+                float v;
+                memcpy(&v, &mid, sizeof v);
+                if (byte_of_linear(v) >= k) hi = mid; else lo = mid;
+            }
+            memcpy(&tables.step[k], &hi, sizeof(float));
+        }
+        {   /* the step function is the reference's: checked on a spread of values and around every step */
+            uint32_t state = 12345u;
+            for (int i = 0; i < 20000; i++) {
+                state = state * 1664525u + 1013904223u;
+                uint32_t bits = i < 255 * 16 ? 0u : 0x30000000u + state % (0x3f800000u - 0x30000000u);
+                if (i < 255 * 16) { memcpy(&bits, &tables.step[1 + i / 16], 4); bits += (uint32_t)(i % 16) - 8u; }
+                float v;
+                memcpy(&v, &bits, sizeof v);
+                if (!(v > 0.0f && v <= 1.0f)) continue;
+                const int k = (int)(std::upper_bound(tables.step + 1, tables.step + 256, v) - (tables.step + 1));
+                if (k != byte_of_linear(v)) fatal("the display transfer is not the step function its table says (v = %a)", (double)v);
+            }
+        }
         HIP_OK(hipMemcpyToSymbol(HIP_SYMBOL(rz_srgb_tables), &tables, sizeof tables));
     }
     init_packed_formats();

@@ -19,6 +19,7 @@
 #ifndef RZ_KERNELS_H
 #define RZ_KERNELS_H
 
+#include <type_traits>
 #include "shade.h"
 
 /* largest d with first_tri[d] <= t */
@@ -2396,6 +2397,9 @@ __global__ void __launch_bounds__(256) rz_shade_list_kernel(const PassParams *__
         const uint32_t *__restrict__ queue_base, const uint32_t *__restrict__ queue_counts, uint32_t queue_capacity) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     LdsTables::fill();              /* a workgroup shades many blocks: the tables' copy is paid once */
+    /* block lists come from rz_strip_kernel, which takes passes without blending only; tile lists may hold
+     * blended fragments (passes cut up by rz_visibility_kernel<2, true>), which need the colour itself */
+    typedef typename std::conditional<BLOCKS, LdsTablesBytes, LdsTables>::type Tables;
     /* lane q holds the length of part q of this family's list */
     const uint32_t my_count = min(queue_counts[(FAMILY * RZ_QUEUE_WAYS + lane) * RZ_QUEUE_PAD], queue_capacity);
     uint32_t longest = my_count;
@@ -2412,12 +2416,12 @@ __global__ void __launch_bounds__(256) rz_shade_list_kernel(const PassParams *__
         if constexpr (BLOCKS) {
             const PassParams P = passes[item >> 21];
             const int t = (int)(threadIdx.x & 127u);
-            shade_pixel<FAMILY, NARROW, LdsTables>(P, tri_base, fan_base, vary_base, fan_vary_base, upload_base, ref_base,
-                                                   (int)(item & 1023u) * 16 + (t & 15), (int)((item >> 10) & 2047u) * 8 + (t >> 4));
+            shade_pixel<FAMILY, NARROW, Tables>(P, tri_base, fan_base, vary_base, fan_vary_base, upload_base, ref_base,
+                                                (int)(item & 1023u) * 16 + (t & 15), (int)((item >> 10) & 2047u) * 8 + (t >> 4));
         } else {
             const PassParams P = passes[item >> 20];
-            shade_pixel<FAMILY, NARROW, LdsTables>(P, tri_base, fan_base, vary_base, fan_vary_base, upload_base, ref_base,
-                                                   (int)(item & 511u) * RZ_TILE_W + (lane & 31), (int)((item >> 9) & 2047u) * RZ_TILE_H + wave * 2 + (lane >> 5));
+            shade_pixel<FAMILY, NARROW, Tables>(P, tri_base, fan_base, vary_base, fan_vary_base, upload_base, ref_base,
+                                                (int)(item & 511u) * RZ_TILE_W + (lane & 31), (int)((item >> 9) & 2047u) * RZ_TILE_H + wave * 2 + (lane >> 5));
         }
     }
 }

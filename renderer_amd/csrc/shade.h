@@ -101,6 +101,8 @@ struct SrgbTables {
     double pow2[150];       /* (2^e)^(1/2.2), e = -149 .. 0 */
     double m0[32];          /* (1 + i/32)^(1/2.2) */
     double inv[32];         /* 1 / (1 + i/32) */
+    float step[256];        /* step[k], k >= 1: the smallest v in (0, 1] whose byte, (unsigned char)((float)pow(v, 1 / 2.2) * 255)
+                             * (maths.c:41 with maths.c:33), is at least k; found by the host with its own pow */
 };
 __device__ SrgbTables rz_srgb_tables;
 /* (float)pow(k / 255.0f, 2.2) for every byte k (texture.c:32-62 with maths.c:37-39), filled by the host */
@@ -116,6 +118,8 @@ struct GlobalTables {
     RZ_DEV double pow2(int i) { return rz_srgb_tables.pow2[i]; }
     RZ_DEV double m0(int i) { return rz_srgb_tables.m0[i]; }
     RZ_DEV double inv(int i) { return rz_srgb_tables.inv[i]; }
+    RZ_DEV float step(int k) { return rz_srgb_tables.step[k]; }
+    static constexpr bool bytes_only = false;   /* a blended fragment needs the colour itself */
 };
 __shared__ SrgbTables rz_lds_srgb_tables;
 __shared__ float rz_lds_srgb8_table[256];
@@ -124,6 +128,8 @@ struct LdsTables {
     RZ_DEV double pow2(int i) { return rz_lds_srgb_tables.pow2[i]; }
     RZ_DEV double m0(int i) { return rz_lds_srgb_tables.m0[i]; }
     RZ_DEV double inv(int i) { return rz_lds_srgb_tables.inv[i]; }
+    RZ_DEV float step(int k) { return rz_lds_srgb_tables.step[k]; }
+    static constexpr bool bytes_only = false;
     /* by every thread of the workgroup, before the first lookup */
     RZ_DEV void fill() {
         const uint32_t *src = (const uint32_t*)&rz_srgb_tables;
@@ -132,6 +138,10 @@ struct LdsTables {
         for (uint32_t i = threadIdx.x; i < 256u; i += blockDim.x) rz_lds_srgb8_table[i] = rz_srgb8_table[i];
         __syncthreads();
     }
+};
+/* ... for a kernel all of whose fragments go to the framebuffer's bytes at once, unblended (d_srgb_for_bytes) */
+struct LdsTablesBytes : LdsTables {
+    static constexpr bool bytes_only = true;
 };
 
 template <class TABLES = GlobalTables>
@@ -153,6 +163,20 @@ RZ_DEV float d_srgb(float v) {
     q = fma(q, r, c4); q = fma(q, r, c3); q = fma(q, r, c2); q = fma(q, r, c1);
     q = fma(q, r, 1.0);
     return (float)((TABLES::pow2(e + 149) * TABLES::m0(i)) * q);
+}
+/* The same for a fragment whose colour goes straight to the framebuffer's bytes (no blending): all that
+ * counts is which of 256 bytes (float)pow(v, 1 / 2.2) turns into, and that is a step function of v -- the
+ * transfer, the conversion to float, the scaling and the truncation are all monotone -- whose 255 steps the
+ * host finds with its own pow.  A fast power gives the byte within one, two table values settle it, and
+ * what is returned is the middle of that byte's interval: no double arithmetic at all. */
+template <class TABLES = GlobalTables>
+RZ_DEV float d_srgb_for_bytes(float v) {
+    if (!(v > 0.0f && v <= 1.0f)) return d_srgb<TABLES>(v);                 /* 0, NaN, out of the display range */
+    int k = (int)(__builtin_amdgcn_exp2f(__builtin_amdgcn_logf(v) * (float)(1 / 2.2)) * 255.0f);     /* v_log_f32, v_exp_f32: base 2 */
+    k = max(0, min(k, 255));
+    if (k < 255 && v >= TABLES::step(k + 1)) k++;
+    else if (k > 0 && v < TABLES::step(k)) k--;
+    return ((float)k + 0.5f) * (1.0f / 255.0f);
 }
 RZ_DEV float d_aces(float v) {                                                 /* maths.c:49 */
     float a = 2.51f, b = 0.03f, c = 2.43f, d = 0.59f, e = 0.14f;
@@ -553,7 +577,10 @@ RZ_DEV f3 pbr_light(const Surface &s, f3 light, f3 n, f3 view) {
 
 template <class TABLES = GlobalTables>
 RZ_DEV f4 display_encode(f3 c, float alpha) {                    /* :401-406 */
-    return mk4(d_srgb<TABLES>(d_aces(c.x)), d_srgb<TABLES>(d_aces(c.y)), d_srgb<TABLES>(d_aces(c.z)), alpha);
+    if constexpr (TABLES::bytes_only)
+        return mk4(d_srgb_for_bytes<TABLES>(d_aces(c.x)), d_srgb_for_bytes<TABLES>(d_aces(c.y)), d_srgb_for_bytes<TABLES>(d_aces(c.z)), alpha);
+    else
+        return mk4(d_srgb<TABLES>(d_aces(c.x)), d_srgb<TABLES>(d_aces(c.y)), d_srgb<TABLES>(d_aces(c.z)), alpha);
 }
 
 /* layer inspector (:408-438) */
