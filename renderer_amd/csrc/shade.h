@@ -376,6 +376,11 @@ RZ_DEV f4 cube_clamp(const DevTex *faces, f3 dir) {                   /* texture
 /* blinn_shader.c:178-195 == pbr_shader.c:311-328; the map's texel is loaded ahead of need */
 template <bool NARROW>
 RZ_DEV TexelT<NARROW> load_shadow(const DrawRec &D, f3 depth_position) {
+    if (!D.shadow_map.data) {       /* uniform over the draw: no address arithmetic, no load of a texel nobody looks at */
+        TexelT<NARROW> none;
+        if constexpr (NARROW) none.word = 0u; else { none.q = make_float4(0, 0, 0, 0); none.sel = 0u; }
+        return none;
+    }
     float u = (depth_position.x + 1) * 0.5f;
     float v = (depth_position.y + 1) * 0.5f;
     return load_repeat<NARROW>(D.shadow_map, u, v);
