@@ -270,6 +270,20 @@ void framebuffer_sync_color(rz_framebuffer *framebuffer);
  * framebuffer only.  A maintainer replaces the body of private_blit_bgr by
  * framebuffer_blit(src, dst->ldr_buffer, 1). */
 void framebuffer_blit(rz_framebuffer *framebuffer, unsigned char *destination, int swap_red_blue);
+
+/* ---- 2-D overlays: renderer/core/draw2d.h:8-15 ---------------------------
+ * The reference's own names and signatures (the PBR layer inspector draws its edges and labels with
+ * them, renderer/tests/test_pbr.c:71-106), executed on the device's colour image behind everything
+ * recorded for the framebuffer so far, so that a host which links these instead of core/draw2d.c
+ * needs no framebuffer_sync in front of its overlays.  Points are in [0,1]^2 with (0,0) the bottom
+ * left pixel; a point or line replaces all four bytes of the pixels it touches (draw2d.c:30-37), a
+ * texture is added byte-wise, wrapping, to red, green and blue (draw2d.c:75-93). */
+void draw2d_draw_point(rz_framebuffer *framebuffer, rz_vec4 color, rz_vec2 point);         /* draw2d.c:95 */
+void draw2d_draw_line(rz_framebuffer *framebuffer, rz_vec4 color,
+                      rz_vec2 point0, rz_vec2 point1);                                     /* draw2d.c:104 */
+void draw2d_draw_triangle(rz_framebuffer *framebuffer, rz_vec4 color,
+                          rz_vec2 point0, rz_vec2 point1, rz_vec2 point2);                 /* draw2d.c:114 */
+void draw2d_draw_texture(rz_framebuffer *framebuffer, rz_texture *texture, rz_vec2 origin); /* draw2d.c:128 */
 /* Same for a texture written by texture_from_{color,depth}buffer. */
 void texture_sync(rz_texture *texture);
 /* texture_sync for callers that cannot allocate device memory.  No counterpart in the reference (whose

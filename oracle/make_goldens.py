@@ -37,6 +37,8 @@ def run_case(case, assets, binary=None, env=None):
         cmd += ["--time", repr(float(case["time"]))]
     if "layer" in case:
         cmd += ["--layer", str(case["layer"])]
+    for op in case.get("overlay", []):        # 2-D overlays over the finished frame, in order (ref_driver.c)
+        cmd += ["--" + op[0]] + [x if isinstance(x, str) else repr(float(x)) for x in op[1:]]
     subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, env=env, timeout=300)
     raw = open(out, "rb").read()
     os.unlink(out)

@@ -127,6 +127,89 @@ void framebuffer_blit(rz_framebuffer *fb, unsigned char *destination, int swap_r
     }
 }
 
+/* ======================= 2-D overlays (draw2d.c) ======================== */
+
+/* draw2d.c:24-28: a point in [0,1]^2 -> the pixel it names, rounded to nearest */
+static void overlay_pixel(const rz_framebuffer *fb, rz_vec2 p, int *row, int *col) {
+    *row = (int)((fb->height - 1) * o_sat(p.y) + 0.5f);
+    *col = (int)((fb->width - 1) * o_sat(p.x) + 0.5f);
+}
+
+static void overlay_bytes(rz_vec4 c, unsigned char px[4]) {            /* draw2d.c:17-22 */
+    px[0] = o_to_u8(c.x); px[1] = o_to_u8(c.y); px[2] = o_to_u8(c.z); px[3] = o_to_u8(c.w);
+}
+
+/* draw2d.c:43-73: the longer axis is walked pixel by pixel, the other one is
+ * (int)(a + (b - a) * t) with t = step / distance in single precision; equal
+ * distances take the column walk.  All four bytes of a pixel are replaced. */
+static void overlay_segment(rz_framebuffer *fb, const unsigned char px[4], int r0, int c0, int r1, int c1) {
+    const int dr = abs(r0 - r1), dc = abs(c0 - c1);
+    const int along_rows = dr > dc;
+    int a0 = along_rows ? r0 : c0, a1 = along_rows ? r1 : c1;      /* the walked axis */
+    int b0 = along_rows ? c0 : r0, b1 = along_rows ? c1 : r1;      /* the derived one */
+    const int dist = along_rows ? dr : dc;
+    int a;
+    if (a0 > a1) { int t = a0; a0 = a1; a1 = t; t = b0; b0 = b1; b1 = t; }
+    for (a = a0; a <= a1; a++) {
+        int b = b0, row, col;
+        if (dist != 0) {
+            float t = (float)(a - a0) / (float)dist;
+            b = (int)(b0 + (b1 - b0) * t);
+        }
+        row = along_rows ? a : b;
+        col = along_rows ? b : a;
+        memcpy(fb->color_buffer + ((size_t)row * fb->width + col) * 4, px, 4);
+    }
+}
+
+void draw2d_draw_point(rz_framebuffer *fb, rz_vec4 color, rz_vec2 point) {          /* draw2d.c:95 */
+    unsigned char px[4];
+    int row, col;
+    trace_close(fb);
+    overlay_bytes(color, px);
+    overlay_pixel(fb, point, &row, &col);
+    overlay_segment(fb, px, row, col, row, col);
+}
+
+void draw2d_draw_line(rz_framebuffer *fb, rz_vec4 color, rz_vec2 point0, rz_vec2 point1) {  /* draw2d.c:104 */
+    unsigned char px[4];
+    int r0, c0, r1, c1;
+    trace_close(fb);
+    overlay_bytes(color, px);
+    overlay_pixel(fb, point0, &r0, &c0);
+    overlay_pixel(fb, point1, &r1, &c1);
+    overlay_segment(fb, px, r0, c0, r1, c1);
+}
+
+void draw2d_draw_triangle(rz_framebuffer *fb, rz_vec4 color, rz_vec2 point0, rz_vec2 point1, rz_vec2 point2) {  /* draw2d.c:114 */
+    unsigned char px[4];
+    int r[3], c[3], k;
+    trace_close(fb);
+    overlay_bytes(color, px);
+    overlay_pixel(fb, point0, &r[0], &c[0]);
+    overlay_pixel(fb, point1, &r[1], &c[1]);
+    overlay_pixel(fb, point2, &r[2], &c[2]);
+    for (k = 0; k < 3; k++) overlay_segment(fb, px, r[k], c[k], r[(k + 1) % 3], c[(k + 1) % 3]);
+}
+
+/* draw2d.c:75-93, 128-138: the texture's rows from its row 0 on are ADDED, byte-wise and wrapping,
+ * to red, green and blue of the pixels right of and above the origin; what sticks out is cut off */
+void draw2d_draw_texture(rz_framebuffer *fb, rz_texture *texture, rz_vec2 origin) {
+    int row, col, w, h, r, c;
+    trace_close(fb);
+    overlay_pixel(fb, origin, &row, &col);
+    w = fb->width - col;  if (texture->width < w) w = texture->width;
+    h = fb->height - row; if (texture->height < h) h = texture->height;
+    for (r = 0; r < h; r++)
+        for (c = 0; c < w; c++) {
+            const rz_vec4 *s = &texture->buffer[(size_t)r * texture->width + c];
+            unsigned char *d = &fb->color_buffer[((size_t)(row + r) * fb->width + (col + c)) * 4];
+            d[0] = (unsigned char)(d[0] + o_to_u8(s->x));
+            d[1] = (unsigned char)(d[1] + o_to_u8(s->y));
+            d[2] = (unsigned char)(d[2] + o_to_u8(s->z));
+        }
+}
+
 /* ======================= program (graphics.c:59-141) ==================== */
 
 #define MAX_POLY 10             /* a triangle clipped by 7 planes has <= 10 corners */

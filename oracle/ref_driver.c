@@ -22,6 +22,7 @@
 #include "scenes/blinn_scenes.h"
 #include "scenes/pbr_scenes.h"
 #include "scenes/scene_helper.h"
+#include "shaders/cache_helper.h"
 #include "tests/test_helper.h"
 
 #ifdef RZ_DROP_IN
@@ -82,6 +83,54 @@ static int derived_root(const char *like, mat4_t *root) {
     return 1;
 }
 
+/* 2-D overlays drawn over the finished frame through the reference's draw2d API
+ * (core/draw2d.h:8-15), the way renderer/tests/test_pbr.c:71-106 draws the layer
+ * inspector's edges and labels: --point r g b a x y | --line r g b a x0 y0 x1 y1 |
+ * --outline r g b a x0 y0 x1 y1 x2 y2 | --label file.tga x y, in command-line order */
+typedef struct {int kind; float v[10]; const char *file;} overlay_t;
+#define MAX_OVERLAYS 64
+static overlay_t g_overlays[MAX_OVERLAYS];
+static int g_num_overlays = 0;
+
+static int parse_overlay(int argc, char **argv, int *i) {
+    static const struct {const char *flag; int kind, floats;} forms[] = {
+        {"--point", 0, 6}, {"--line", 1, 8}, {"--outline", 2, 10}, {"--label", 3, 2},
+    };
+    int f, k;
+    for (f = 0; f < 4; f++) {
+        int wanted = forms[f].floats + (forms[f].kind == 3 ? 1 : 0);
+        overlay_t *o;
+        if (strcmp(argv[*i], forms[f].flag) != 0) continue;
+        if (*i + wanted >= argc || g_num_overlays == MAX_OVERLAYS) return -1;
+        o = &g_overlays[g_num_overlays++];
+        o->kind = forms[f].kind;
+        o->file = forms[f].kind == 3 ? argv[++*i] : NULL;
+        for (k = 0; k < forms[f].floats; k++) o->v[k] = (float)atof(argv[++*i]);
+        return 1;
+    }
+    return 0;
+}
+
+static void draw_overlays(framebuffer_t *fb) {
+    int i;
+    for (i = 0; i < g_num_overlays; i++) {
+        const overlay_t *o = &g_overlays[i];
+        const float *v = o->v;
+        vec4_t color = vec4_new(v[0], v[1], v[2], v[3]);
+        if (o->kind == 0) {
+            draw2d_draw_point(fb, color, vec2_new(v[4], v[5]));
+        } else if (o->kind == 1) {
+            draw2d_draw_line(fb, color, vec2_new(v[4], v[5]), vec2_new(v[6], v[7]));
+        } else if (o->kind == 2) {
+            draw2d_draw_triangle(fb, color, vec2_new(v[4], v[5]), vec2_new(v[6], v[7]), vec2_new(v[8], v[9]));
+        } else {
+            texture_t *label = cache_acquire_texture(o->file, USAGE_LDR_COLOR);      /* test_pbr.c:115-117 */
+            draw2d_draw_texture(fb, label, vec2_new(v[0], v[1]));
+            cache_release_texture(label);
+        }
+    }
+}
+
 static double now_ms(void) {
     struct timespec ts;
     clock_gettime(CLOCK_MONOTONIC, &ts);
@@ -117,6 +166,7 @@ int main(int argc, char **argv) {
         else if (!strcmp(argv[i], "--layer") && i + 1 < argc) layer = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--bench") && i + 1 < argc) timed = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--out") && i + 1 < argc) out = argv[++i];
+        else if (parse_overlay(argc, argv, &i) > 0) continue;
         else { fprintf(stderr, "bad argument: %s\n", argv[i]); return 2; }
     }
     if (scene_name == NULL) { fprintf(stderr, "--scene required\n"); return 2; }
@@ -164,6 +214,9 @@ int main(int argc, char **argv) {
         free(samples);
     }
 
+    /* in the drop-in build the overlays are the library's too (oracle/Makefile leaves core/draw2d.c
+     * out): they follow the recorded draws without a synchronisation in between */
+    draw_overlays(fb);
 #ifdef RZ_DROP_IN
     framebuffer_sync(fb);
 #endif

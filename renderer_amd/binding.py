@@ -17,6 +17,10 @@ class Vec4(C.Structure):
     _fields_ = [("x", C.c_float), ("y", C.c_float), ("z", C.c_float), ("w", C.c_float)]
 
 
+class Vec2(C.Structure):
+    _fields_ = [("x", C.c_float), ("y", C.c_float)]
+
+
 class Framebuffer(C.Structure):
     _fields_ = [("width", C.c_int), ("height", C.c_int),
                 ("color_buffer", C.POINTER(C.c_ubyte)), ("depth_buffer", C.POINTER(C.c_float))]
@@ -57,6 +61,13 @@ class Pipeline:
         lib.framebuffer_sync.argtypes = [FB]
         lib.framebuffer_read.argtypes = [FB, P, P]
         lib.graphics_flush.argtypes = []
+        lib.draw2d_draw_point.argtypes = [FB, Vec4, Vec2]
+        lib.draw2d_draw_line.argtypes = [FB, Vec4, Vec2, Vec2]
+        lib.draw2d_draw_triangle.argtypes = [FB, Vec4, Vec2, Vec2, Vec2]
+        lib.draw2d_draw_texture.argtypes = [FB, P, Vec2]
+        lib.texture_from_file.restype = P
+        lib.texture_from_file.argtypes = [C.c_char_p, C.c_int]
+        lib.texture_release.argtypes = [P]
         lib.mi355r_backend.restype = C.c_char_p
         lib.rzs_set_assets_dir.argtypes = [C.c_char_p]
         lib.rzs_scene_open.restype = P
@@ -163,9 +174,25 @@ class Pipeline:
         self.lib.framebuffer_read(fb, color.ctypes.data_as(C.c_void_p), depth.ctypes.data_as(C.c_void_p))
         return color, depth
 
-    def render(self, scene, width, height, view=None):
+    def overlay(self, fb, ops):
+        """2-D overlays (renderer/core/draw2d.h) over what the framebuffer holds, in order:
+        ["point", r, g, b, a, x, y] | ["line", r, g, b, a, x0, y0, x1, y1] |
+        ["outline", r, g, b, a, x0, y0, x1, y1, x2, y2] | ["label", file, x, y] (an LDR colour image, added)."""
+        for op in ops:
+            kind, v = op[0], op[1:]
+            if kind == "label":
+                tex = self.lib.texture_from_file(v[0].encode(), 0)         # USAGE_LDR_COLOR, texture.h:7
+                self.lib.draw2d_draw_texture(fb, tex, Vec2(v[1], v[2]))
+                self.lib.texture_release(tex)
+                continue
+            color, pts = Vec4(*v[:4]), [Vec2(v[i], v[i + 1]) for i in range(4, len(v), 2)]
+            {"point": self.lib.draw2d_draw_point, "line": self.lib.draw2d_draw_line,
+             "outline": self.lib.draw2d_draw_triangle}[kind](fb, color, *pts)
+
+    def render(self, scene, width, height, view=None, overlay=()):
         fb = self.framebuffer(width, height)
         self.draw(scene, fb, view if view is not None else self.default_view())
+        self.overlay(fb, overlay)
         out = self.read(fb)
         self.release(fb)
         return out

@@ -540,6 +540,76 @@ extern "C" void framebuffer_blit(rz_framebuffer *p, unsigned char *destination, 
     }
 }
 
+/* ---- 2-D overlays: draw2d.c ------------------------------------------------ */
+
+/* everything recorded for the framebuffer is submitted and settled; what follows on its lane comes after it */
+static hipStream_t overlay_stream(Fb *fb) {
+    graphics_flush();
+    HIP_OK(hipStreamSynchronize(g.lanes[fb->lane < 0 ? 0 : fb->lane].stream));
+    settle_framebuffer(fb);
+    apply_pending_clear(fb);
+    if (fb->lane < 0) fb->lane = 0;
+    return g.lanes[fb->lane].stream;
+}
+
+static void overlay_pixel(const Fb *fb, rz_vec2 p, int *row, int *col) {       /* draw2d.c:24-28 */
+    auto sat = [](float f) { return f < 0 ? 0.0f : (f > 1 ? 1.0f : f); };
+    *row = (int)((float)(fb->pub.height - 1) * sat(p.y) + 0.5f);
+    *col = (int)((float)(fb->pub.width - 1) * sat(p.x) + 0.5f);
+}
+
+static void overlay_segments(Fb *fb, rz_vec4 color, const rz_vec2 *points, int count) {
+    OverlaySegments s;
+    memset(&s, 0, sizeof s);
+    int row[3], col[3], longest = 0;
+    for (int k = 0; k < count; k++) overlay_pixel(fb, points[k], &row[k], &col[k]);
+    const int segments = count == 3 ? 3 : 1;
+    for (int k = 0; k < segments; k++) {
+        const int n = count == 1 ? 0 : (k + 1) % count;
+        s.r0[k] = row[k]; s.c0[k] = col[k]; s.r1[k] = row[n]; s.c1[k] = col[n];
+        longest = std::max(longest, std::max(abs(row[k] - row[n]), abs(col[k] - col[n])));
+    }
+    s.pixel = pack_clear(color);            /* draw2d.c:17-22: float_to_uchar per channel, as a clear packs its colour */
+    s.width = fb->pub.width;
+    hipStream_t st = overlay_stream(fb);
+    rz_overlay_segments_kernel<<<dim3((unsigned)(longest / 64 + 1), (unsigned)segments), dim3(64), 0, st>>>(fb->d_color, s);
+    HIP_OK(hipGetLastError());
+}
+
+extern "C" void draw2d_draw_point(rz_framebuffer *p, rz_vec4 color, rz_vec2 point) {                   /* draw2d.c:95 */
+    overlay_segments(as_fb(p), color, &point, 1);
+}
+
+extern "C" void draw2d_draw_line(rz_framebuffer *p, rz_vec4 color, rz_vec2 point0, rz_vec2 point1) {   /* draw2d.c:104 */
+    const rz_vec2 points[2] = {point0, point1};
+    overlay_segments(as_fb(p), color, points, 2);
+}
+
+extern "C" void draw2d_draw_triangle(rz_framebuffer *p, rz_vec4 color, rz_vec2 point0, rz_vec2 point1, rz_vec2 point2) {    /* draw2d.c:114 */
+    const rz_vec2 points[3] = {point0, point1, point2};
+    overlay_segments(as_fb(p), color, points, 3);
+}
+
+static Tex *as_tex(rz_texture *p);
+static void upload_texture(Tex *t);
+
+extern "C" void draw2d_draw_texture(rz_framebuffer *p, rz_texture *texture, rz_vec2 origin) {          /* draw2d.c:128 */
+    Fb *fb = as_fb(p);
+    Tex *t = as_tex(texture);
+    if (t->device_stale) upload_texture(t);
+    graphics_flush();
+    sync_stream();                  /* the image may have been written on another lane (a shadow map shown as an overlay) */
+    hipStream_t st = overlay_stream(fb);
+    int row, col;
+    overlay_pixel(fb, origin, &row, &col);
+    const int w = std::min(fb->pub.width - col, t->pub.width), h = std::min(fb->pub.height - row, t->pub.height);
+    if (w <= 0 || h <= 0) return;
+    rz_overlay_texture_kernel<<<dim3((unsigned)((w + 63) / 64), (unsigned)h), dim3(64), 0, st>>>(
+        fb->d_color, fb->pub.width, t->d_data, t->pub.width, t->flags, row, col, w, h);
+    HIP_OK(hipGetLastError());
+    HIP_OK(hipStreamSynchronize(st));       /* the image must not be replaced under the kernel */
+}
+
 extern "C" void framebuffer_read(rz_framebuffer *p, void *color, void *depth) {
     read_framebuffer(as_fb(p), color, depth, hipMemcpyDeviceToHost);
 }

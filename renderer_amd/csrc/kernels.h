@@ -2492,6 +2492,48 @@ __global__ void rz_blit_kernel(const uint32_t *__restrict__ color, uint32_t *__r
     staged[(size_t)(h - 1 - y) * w + x] = swap ? (b | (g << 8) | (r << 16)) : (r | (g << 8) | (b << 16));
 }
 
+/* 2-D overlays (draw2d.c).  A line segment walks its longer axis pixel by pixel -- one thread per
+ * step -- and takes the other coordinate as (int)(a + (b - a) * t), t = step / distance in single
+ * precision (draw2d.c:43-73: rows when the row distance is the larger one, columns otherwise, a
+ * single pixel when both are zero).  Up to three segments of one colour per launch (a triangle's
+ * outline, draw2d.c:114-126): blockIdx.y = segment; where they meet they write the same word. */
+struct OverlaySegments { int32_t r0[3], c0[3], r1[3], c1[3]; uint32_t pixel; int32_t width; };
+__global__ void __launch_bounds__(64) rz_overlay_segments_kernel(uint32_t *__restrict__ color, const OverlaySegments s) {
+    const int k = blockIdx.y;
+    const int r0 = s.r0[k], c0 = s.c0[k], r1 = s.r1[k], c1 = s.c1[k];
+    const int dr = abs(r0 - r1), dc = abs(c0 - c1);
+    const bool along_rows = dr > dc;
+    int a0 = along_rows ? r0 : c0, a1 = along_rows ? r1 : c1;
+    int b0 = along_rows ? c0 : r0, b1 = along_rows ? c1 : r1;
+    const int dist = along_rows ? dr : dc;
+    if (a0 > a1) { int t = a0; a0 = a1; a1 = t; t = b0; b0 = b1; b1 = t; }
+    const int a = a0 + (int)(blockIdx.x * 64 + threadIdx.x);
+    if (a > a1) return;
+    int b = b0;
+    if (dist != 0) {
+        const float t = (float)(a - a0) / (float)dist;
+        b = (int)((float)b0 + (float)(b1 - b0) * t);
+    }
+    const int row = along_rows ? a : b, col = along_rows ? b : a;
+    color[(size_t)row * s.width + col] = s.pixel;
+}
+
+/* draw2d.c:75-93: rows [0, h) x columns [0, w) of the image, from its row 0 on, are added byte-wise
+ * (wrapping) to red, green and blue of the pixels from (row, col) on; alpha stays */
+__global__ void __launch_bounds__(64) rz_overlay_texture_kernel(uint32_t *__restrict__ color, int fb_width, const void *__restrict__ texels,
+                                                                int tex_width, int flags, int row, int col, int w, int h) {
+    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y;
+    if (x >= w || y >= h) return;
+    const uint32_t i = texel_index(tex_width, flags, x, y);
+    f4 t;
+    if (flags & RZ_TEX_NARROW) t = decode_word(flags, ((const float*)texels)[i]);
+    else { const float4 q = ((const float4*)texels)[i]; t = mk4(q.x, q.y, q.z, q.w); }
+    auto u8 = [](float v) { return (uint32_t)(int)(v * 255) & 0xffu; };        /* maths.c:33 */
+    uint32_t *p = color + (size_t)(row + y) * fb_width + (col + x);
+    const uint32_t d = *p;
+    *p = (d & 0xff000000u) | ((d + u8(t.x)) & 0xffu) | (((d >> 8) + u8(t.y)) & 0xffu) << 8 | (((d >> 16) + u8(t.z)) & 0xffu) << 16;
+}
+
 /* row-major float4 image -> device layout (8x8 tiles where the size allows) */
 __global__ void rz_texture_tile_kernel(const float4 *linear, float4 *texels, int w, int h, int flags, int mbits) {
     int x = blockIdx.x * 16 + (threadIdx.x & 15), y = blockIdx.y * 16 + (threadIdx.x >> 4);

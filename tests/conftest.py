@@ -38,7 +38,7 @@ def render_case(pipe, case):
         scene = pipe.open_scene(case["scene"])
     view = pipe.make_view(case.get("eye"), case.get("target"), case.get("time", 0.0), case.get("layer", -1))
     w, h = case["size"]
-    color, depth = pipe.render(scene, w, h, view)
+    color, depth = pipe.render(scene, w, h, view, case.get("overlay", ()))
     pipe.close_scene(scene)
     return color, depth
 

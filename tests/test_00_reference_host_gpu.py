@@ -1,7 +1,7 @@
 """The reference's own host code driving the GPU library (GPU box).
 
 oracle/_ref/refhost_mi355r is built in the CPU container from the reference's sources where they lie
-(oracle/Makefile, target refhost): everything except core/graphics.c and core/texture.c, i.e. its scene
+(oracle/Makefile, target refhost): everything except core/graphics.c, core/texture.c and core/draw2d.c, i.e. its scene
 factories, .scn parser, caches, loaders, the shaders' update_model / draw_model loops (one
 graphics_draw_triangle call per face) and tests/test_helper.c's frame driver, all unchanged, plus our
 headless driver, linked against renderer_amd/libmi355r.so.  The binary travels to the GPU box; the
@@ -33,7 +33,8 @@ def gpu_in_use_by_this_process():
 
 
 @pytest.mark.skipif(not os.path.exists(EXE), reason="oracle/_ref/refhost_mi355r was not built (needs the reference's sources)")
-@pytest.mark.parametrize("name", ["helmet_default", "kgirl_anim", "azura_shadow", "kgirl_blend", "helmet_inside", "buster_anim"])
+@pytest.mark.parametrize("name", ["helmet_default", "kgirl_anim", "azura_shadow", "kgirl_blend", "helmet_inside", "buster_anim",
+                                  "helmet_overlay"])
 def test_reference_host_drives_the_gpu_library(name):
     if gpu_in_use_by_this_process():
         pytest.skip("run this file first (or alone): its child processes are started before the pipeline is loaded here")

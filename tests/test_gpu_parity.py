@@ -323,6 +323,51 @@ def test_gpu_blit_equals_the_reference_blit(gpu, oracle, size):
         assert (g[..., :3] != o[..., :3]).any(axis=2).sum() <= max(2, w * h * 2e-4)   # colour bar of the frames themselves
 
 
+@pytest.mark.parametrize("size", [(1920, 1080), (333, 77), (64, 1), (1, 1)])
+def test_gpu_overlays_equal_the_reference_overlays(gpu, oracle, size):
+    """draw2d_draw_point / _line / _triangle / _texture (draw2d.c) on the device against the restated host
+    loops: random points inside and outside [0,1]^2, steep, flat, diagonal and single-pixel lines, the label
+    images, a float image a host filled by hand (values up to 1, where the byte sum wraps) and labels that
+    stick out of the frame, over a non-black clear colour and over one another; every byte identical."""
+    from renderer_amd.binding import Vec2, Vec4
+    w, h = size
+    rng = np.random.default_rng(w * 131 + h)
+    unit = lambda n: [float(np.float32(x)) for x in rng.uniform(-0.2, 1.2, n)]
+    ops = []
+    for i in range(120):
+        color = [float(np.float32(x)) for x in rng.uniform(0, 1, 4)]
+        kind = ("point", "line", "outline", "label")[i % 4]
+        if kind == "label":
+            ops.append(["label", "common/%s.tga" % ("diffuse", "specular", "roughness", "occlusion", "normal")[i // 4 % 5], *unit(2)])
+        else:
+            ops.append([kind, *color, *unit({"point": 2, "line": 4, "outline": 6}[kind])])
+    ops.append(["line", 1.0, 0.0, 0.0, 1.0, 0.0, 0.0, 1.0, 1.0])          # corner to corner
+    ops.append(["line", 0.0, 1.0, 0.0, 1.0, 0.25, 0.5, 0.25, 0.5])        # both distances zero
+    hand = np.random.default_rng(9).uniform(0, 1, (37, 53, 4)).astype(np.float32)
+    hand[::5, ::3] = 1.0
+    frames = []
+    for pipe in (gpu, oracle):
+        lib = pipe.lib
+        lib.texture_create.restype = C.c_void_p
+        lib.texture_create.argtypes = [C.c_int, C.c_int]
+        lib.texture_invalidate.argtypes = [C.c_void_p]
+        fb = pipe.framebuffer(w, h)
+        lib.framebuffer_clear_color(fb, Vec4(0.3, 0.6, 0.9, 0.5))
+        pipe.overlay(fb, ops)
+        tex = lib.texture_create(53, 37)
+        buffer = C.cast(C.cast(tex + 8, C.POINTER(C.c_void_p))[0], C.POINTER(C.c_float))     # texture_t: width, height, buffer
+        C.memmove(buffer, hand.ctypes.data, hand.nbytes)
+        lib.texture_invalidate(tex)
+        for origin in ((0.1, 0.2), (0.97, 0.4), (0.5, 0.99), (0.11, 0.21)):
+            lib.draw2d_draw_texture(fb, tex, Vec2(*origin))
+        pipe.overlay(fb, ops[:8])
+        frames.append(pipe.read(fb)[0])
+        lib.texture_release(tex)
+        pipe.release(fb)
+    assert np.array_equal(frames[0], frames[1])
+    assert (frames[0] != np.array([76, 153, 229, 127], np.uint8)).any()
+
+
 @pytest.mark.parametrize("size", [(320, 180), (67, 33), (5, 1)])
 def test_gpu_frames_without_their_alpha_bytes(gpu, size):
     """framebuffer_read_device_rgb: the colour image as RGB8 in device memory (what the multi-GPU gather

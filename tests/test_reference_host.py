@@ -1,7 +1,7 @@
 """The reference's OWN host code on top of the C ABI (CPU container only: needs /root/reference).
 
-oracle/Makefile (target refhost) compiles every source file of the reference except the two the
-library replaces (core/graphics.c, core/texture.c) -- scenes/*.c with the .scn parser, the shaders'
+oracle/Makefile (target refhost) compiles every source file of the reference except the ones the
+library replaces (core/graphics.c, core/texture.c, and core/draw2d.c for the 2-D overlays) -- scenes/*.c with the .scn parser, the shaders'
 update_model / draw_model loops (per-face program_get_attribs + graphics_draw_triangle), the caches,
 loaders and tests/test_helper.c's frame driver, unchanged, where they lie -- and links them
   (1) against renderer_amd/libmi355r.so with --no-undefined: every symbol the reference's host
@@ -44,14 +44,15 @@ def test_reference_host_links_against_the_gpu_library(refhost):
     undefined = subprocess.run(["nm", "-D", "--undefined-only", exe], check=True, capture_output=True, text=True).stdout
     for name in ("graphics_draw_triangle", "program_create", "program_get_attribs", "program_get_uniforms",
                  "framebuffer_create", "framebuffer_clear_color", "framebuffer_clear_depth", "texture_from_file",
-                 "cubemap_from_files", "texture_from_depthbuffer", "texture_create", "framebuffer_sync"):
+                 "cubemap_from_files", "texture_from_depthbuffer", "texture_create", "framebuffer_sync",
+                 "draw2d_draw_line", "draw2d_draw_texture"):
         assert f" U {name}" in undefined, name
     # and none of them is the batched addition: the reference's loops are per triangle
     assert "graphics_draw_mesh" not in undefined
 
 
 @pytest.mark.parametrize("name", ["helmet_default", "kgirl_anim", "azura_shadow", "helmet_inside", "kgirl_blend",
-                                  "craftsman_default", "buster_anim"])
+                                  "craftsman_default", "buster_anim", "helmet_overlay"])
 def test_reference_host_on_the_c_abi_reproduces_goldens(refhost, name):
     sys.path.insert(0, os.path.join(REPO, "oracle"))
     from make_goldens import run_case
