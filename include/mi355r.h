@@ -379,6 +379,13 @@ void mi355r_inspect_bins(unsigned int *counts, unsigned int *entries);
  * send ordinary scenes down that road; mi355r_passes_run_again counts the passes that took it. */
 void mi355r_set_scratch_estimate(unsigned long long fan_blocks, unsigned long long list_entries);
 unsigned long long mi355r_passes_run_again(void);
+/* graphics_draw_triangle remembers, per program, the vertex stream its last draw was made of (on the host to
+ * compare against, on the device to draw from): a later draw of the program whose triangles repeat that
+ * stream or a prefix of it -- the reference's draw_model loops submit the same faces every frame -- stores
+ * and uploads nothing per triangle.  The first triangle that differs makes the draw an ordinary recorded
+ * one; a program whose stream changed four times in a row is no longer remembered.  MI355R_REPLAY=0
+ * switches it off.  Counts the draws that were drawn from a remembered stream. */
+unsigned long long mi355r_replayed_draws(void);
 
 /* Device image formats.  texture->buffer is float RGBA as in the reference
  * (texture.h:14-17); on the device an image is kept in 4 bytes per texel when

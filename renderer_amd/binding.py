@@ -64,10 +64,10 @@ class Pipeline:
         lib.draw2d_draw_point.argtypes = [FB, Vec4, Vec2]
         lib.draw2d_draw_line.argtypes = [FB, Vec4, Vec2, Vec2]
         lib.draw2d_draw_triangle.argtypes = [FB, Vec4, Vec2, Vec2, Vec2]
-        lib.draw2d_draw_texture.argtypes = [FB, P, Vec2]
-        lib.texture_from_file.restype = P
-        lib.texture_from_file.argtypes = [C.c_char_p, C.c_int]
-        lib.texture_release.argtypes = [P]
+        # function objects of the binding's own (a test may declare the library's attribute of the same name its way)
+        self._draw_texture = C.CFUNCTYPE(None, FB, P, Vec2)(("draw2d_draw_texture", lib))
+        self._texture_from_file = C.CFUNCTYPE(P, C.c_char_p, C.c_int)(("texture_from_file", lib))
+        self._texture_release = C.CFUNCTYPE(None, P)(("texture_release", lib))
         lib.mi355r_backend.restype = C.c_char_p
         lib.rzs_set_assets_dir.argtypes = [C.c_char_p]
         lib.rzs_scene_open.restype = P
@@ -181,9 +181,9 @@ class Pipeline:
         for op in ops:
             kind, v = op[0], op[1:]
             if kind == "label":
-                tex = self.lib.texture_from_file(v[0].encode(), 0)         # USAGE_LDR_COLOR, texture.h:7
-                self.lib.draw2d_draw_texture(fb, tex, Vec2(v[1], v[2]))
-                self.lib.texture_release(tex)
+                tex = self._texture_from_file(v[0].encode(), 0)            # USAGE_LDR_COLOR, texture.h:7
+                self._draw_texture(fb, tex, Vec2(v[1], v[2]))
+                self._texture_release(tex)
                 continue
             color, pts = Vec4(*v[:4]), [Vec2(v[i], v[i + 1]) for i in range(4, len(v), 2)]
             {"point": self.lib.draw2d_draw_point, "line": self.lib.draw2d_draw_line,

@@ -132,9 +132,23 @@ struct Pending {
     size_t joints_at, joint_normals_at;     /* offsets into Context::side */
     std::vector<Tex*> gpu_textures; /* sampled textures that a GPU pass wrote */
     std::vector<Tex*> pending_textures;     /* sampled textures that a recorded copy of this flush will fill */
-    bool transient;                 /* vertices recorded by graphics_draw_triangle */
-    std::vector<rz_vertex> verts;
+    bool transient;                 /* vertices recorded by graphics_draw_triangle ... */
+    size_t verts_at = 0, verts_count = 0;   /* ... in Context::transient_verts, unless ... */
+    struct Replay *replay = nullptr;        /* ... they repeat, so far, the stream remembered for the program */
     std::vector<char> uniform_bytes;        /* for merging per-triangle calls */
+};
+
+/* A host that submits face by face (the reference's draw_model loops) sends the same vertices frame after
+ * frame.  The stream a program's draw was made of is remembered -- on the host to compare against, on the
+ * device to draw from -- and a later draw of that program whose triangles repeat it, in full or a prefix of
+ * it, is drawn from the device's copy: nothing is stored per triangle and nothing is uploaded per frame.  The
+ * first triangle that differs turns the draw back into an ordinary recorded one. */
+struct Replay {
+    std::vector<rz_vertex> host;
+    void *d_vertices = nullptr;
+    size_t faces = 0;
+    int misses = 0;                         /* streams remembered in a row that no later draw repeated */
+    unsigned long long made_epoch = ~0ull;  /* the flush that (re)made it */
 };
 
 template <typename T> struct DevBuf {
@@ -207,9 +221,14 @@ struct Context {
     size_t fan_highwater = 0, list_highwater = 0;
     size_t forced_fan_estimate = 0, forced_list_estimate = 0;
     unsigned long long passes_run_again = 0;
+    unsigned long long replayed_draws = 0;  /* draws recorded triangle by triangle that were drawn from a remembered stream */
     /* recording */
     std::vector<Pending> pending;
     std::vector<char> side;                 /* joint matrices snapshotted at record time */
+    std::vector<rz_vertex> transient_verts; /* vertices recorded triangle by triangle, draw after draw; emptied with the list */
+    std::unordered_map<rz_program*, Replay> replays;
+    bool replay_streams = true;             /* MI355R_REPLAY=0: every recorded triangle is stored and uploaded */
+    Fb *checked_fb = nullptr;               /* the framebuffer graphics_draw_triangle looked up last */
     /* resources */
     std::unordered_set<Fb*> fbs;
     std::unordered_set<Tex*> texs;
@@ -325,6 +344,8 @@ extern "C" int mi355r_init(int device) {
         g.debug_skip = env ? atoi(env) : 0;
         env = getenv("MI355R_RECORD_COPIES");
         if (env) g.record_copies = atoi(env) != 0;
+        env = getenv("MI355R_REPLAY");
+        if (env) g.replay_streams = atoi(env) != 0;
         env = getenv("MI355R_MICRO_AREA");
         if (env) g.micro_area = std::max(0, std::min(atoi(env), 128));
         env = getenv("MI355R_MICRO_MIN_LIST");
@@ -436,6 +457,7 @@ extern "C" void framebuffer_release(rz_framebuffer *p) {
     HIP_OK(hipHostFree(fb->pub.color_buffer));
     HIP_OK(hipHostFree(fb->pub.depth_buffer));
     g.fbs.erase(fb);
+    g.checked_fb = nullptr;
     delete fb;
 }
 
@@ -1128,6 +1150,11 @@ extern "C" rz_program *program_create(rz_vertex_shader *vs, rz_fragment_shader *
 
 extern "C" void program_release(rz_program *p) {                    /* graphics.c:120 */
     graphics_flush();
+    auto remembered = g.replays.find(p);
+    if (remembered != g.replays.end()) {
+        if (remembered->second.d_vertices) { sync_stream(); HIP_OK(hipFree(remembered->second.d_vertices)); }
+        g.replays.erase(remembered);
+    }
     for (int i = 0; i < 3; i++) free(p->attribs[i]);
     free(p->uniforms);
     delete p;
@@ -1461,23 +1488,71 @@ extern "C" void graphics_draw_mesh_posed(rz_framebuffer *fp, rz_program *program
     g.pending.push_back(std::move(pd));
 }
 
+/* one more triangle of a draw recorded triangle by triangle (the last one of the list) */
+static void append_transient(Pending &pd, const rz_vertex *tri) {
+    if (pd.replay) {
+        const Replay &r = *pd.replay;
+        const size_t have = (size_t)pd.rec.num_faces;
+        if (have < r.faces && memcmp(r.host.data() + 3 * have, tri, 3 * sizeof(rz_vertex)) == 0) return;
+        /* the stream departs from the remembered one: what repeated it so far is recorded after all */
+        g.transient_verts.insert(g.transient_verts.end(), r.host.begin(), r.host.begin() + 3 * have);
+        pd.verts_count = 3 * have;
+        pd.replay = nullptr;
+    }
+    g.transient_verts.insert(g.transient_verts.end(), tri, tri + 3);
+    pd.verts_count += 3;
+}
+
+static const size_t REPLAY_MIN_FACES = 32;
+static std::vector<Replay*> g_replays_to_upload;
+
+/* at the end of a flush, while the recorded vertices are still there: remember the stream of a draw that
+ * repeated none, for the next frame */
+static void remember_stream(Pending &pd) {
+    if (pd.replay) { pd.replay->misses = 0; return; }
+    if (!g.replay_streams || pd.verts_count < 3 * REPLAY_MIN_FACES) return;
+    Replay &r = g.replays[pd.program];
+    if (r.made_epoch == g.flush_epoch) return;          /* an earlier draw of this flush made it (shadow pass and main pass; several frames) */
+    const rz_vertex *verts = g.transient_verts.data() + pd.verts_at;
+    if (r.d_vertices && r.faces * 3 >= pd.verts_count && memcmp(r.host.data(), verts, pd.verts_count * sizeof(rz_vertex)) == 0) return;
+    if (r.misses >= 4) return;                          /* this program's vertices change all the time */
+    r.misses++;
+    r.made_epoch = g.flush_epoch;
+    r.host.assign(verts, verts + pd.verts_count);
+    r.faces = pd.verts_count / 3;
+    g_replays_to_upload.push_back(&r);
+}
+
+/* ... and, once the flush has been handed over, their copies on the device (passes in flight may still
+ * draw from the copy that is replaced) */
+static void upload_remembered_streams() {
+    for (Replay *r : g_replays_to_upload) {
+        if (r->d_vertices) { sync_stream(); HIP_OK(hipFree(r->d_vertices)); r->d_vertices = nullptr; }
+        HIP_OK(hipMalloc(&r->d_vertices, r->host.size() * sizeof(rz_vertex)));
+        HIP_OK(hipMemcpy(r->d_vertices, r->host.data(), r->host.size() * sizeof(rz_vertex), hipMemcpyHostToDevice));
+    }
+    g_replays_to_upload.clear();
+}
+
 /* graphics.c:537: one triangle from the program's three attribute blocks.
  * Consecutive calls with an unchanged uniform block -- and, for a skinned
  * program, unchanged joint matrices -- extend one draw. */
 extern "C" void graphics_draw_triangle(rz_framebuffer *fp, rz_program *program) {
-    Fb *fb = as_fb(fp);
+    Fb *fb = (Fb*)fp;
+    if (fb != g.checked_fb || !fb) g.checked_fb = fb = as_fb(fp);
     rz_vertex tri[3];
-    memset(tri, 0, sizeof tri);
     int top = 0;
     for (int j = 0; j < 3; j++) {
         rz_vertex &v = tri[j];
         if (program->family == RZ_FAMILY_BLINN) {
             const rz_blinn_attribs *a = (const rz_blinn_attribs*)program->attribs[j];
+            memset(&v, 0, sizeof v);
             v.position = a->position; v.texcoord = a->texcoord; v.normal = a->normal;
             v.joint = a->joint; v.weight = a->weight;
         } else if (program->family == RZ_FAMILY_PBR) {
             v = *(const rz_vertex*)program->attribs[j];
         } else {
+            memset(&v, 0, sizeof v);
             v.position = ((const rz_skybox_attribs*)program->attribs[j])->position;
         }
         top = std::max(top, std::max(std::max((int)v.joint.x, (int)v.joint.y), std::max((int)v.joint.z, (int)v.joint.w)));
@@ -1490,7 +1565,7 @@ extern "C" void graphics_draw_triangle(rz_framebuffer *fp, rz_program *program) 
             last.uniform_bytes.size() == (size_t)program->uniform_bytes &&
             memcmp(last.uniform_bytes.data(), ub, program->uniform_bytes) == 0 &&
             same_pose(program, last, top + 1)) {
-            last.verts.insert(last.verts.end(), tri, tri + 3);
+            append_transient(last, tri);
             last.rec.num_faces++;
             return;
         }
@@ -1499,9 +1574,15 @@ extern "C" void graphics_draw_triangle(rz_framebuffer *fp, rz_program *program) 
     pd.fb = fb;
     pd.program = program;
     pd.transient = true;
-    snapshot_uniforms(program, pd, top + 1);
+    snapshot_uniforms(program, pd, top + 1);            /* may flush what is recorded: the draw's vertices are appended after it */
     pd.uniform_bytes.assign(ub, ub + program->uniform_bytes);
-    pd.verts.assign(tri, tri + 3);
+    pd.verts_at = g.transient_verts.size();
+    pd.rec.num_faces = 0;
+    if (g.replay_streams) {
+        auto remembered = g.replays.find(program);
+        if (remembered != g.replays.end() && remembered->second.d_vertices) pd.replay = &remembered->second;
+    }
+    append_transient(pd, tri);
     pd.rec.num_faces = 1;
     g.pending.push_back(std::move(pd));
 }
@@ -1578,9 +1659,9 @@ static void plan_pass(PassPlan &pl, size_t &total) {
             total += (sizeof(rz_mat4) + sizeof(rz_mat3)) * pd.num_joints;
             total = (total + 15) & ~(size_t)15;
         }
-        if (pd.transient) {
+        if (pd.transient && !pd.replay) {
             pl.verts_at[i] = total;
-            total += pd.verts.size() * sizeof(rz_vertex);
+            total += pd.verts_count * sizeof(rz_vertex);
             total = (total + 15) & ~(size_t)15;
         }
     }
@@ -1606,8 +1687,11 @@ static void fill_pass(const PassPlan &pl, char *hb, char *db) {
             rec.joint_normals = (const float*)(db + pl.side_at[i] + jb);
             if (rec.flags & RZ_DRAW_SHADOW_PASS) rec.joint_normals = nullptr;
         }
-        if (pd.transient) {
-            memcpy(hb + pl.verts_at[i], pd.verts.data(), pd.verts.size() * sizeof(rz_vertex));
+        if (pd.transient && pd.replay) {
+            rec.vertices = pd.replay->d_vertices;           /* the draw repeats (a prefix of) the remembered stream */
+            g.replayed_draws++;
+        } else if (pd.transient) {
+            memcpy(hb + pl.verts_at[i], g.transient_verts.data() + pd.verts_at, pd.verts_count * sizeof(rz_vertex));
             rec.vertices = db + pl.verts_at[i];
         }
         if (pd.pose) {
@@ -2489,11 +2573,14 @@ extern "C" void graphics_flush(void) {
     }
     prof.flushes++;
     prof.passes += plans.size();
+    for (Pending &pd : g.pending) if (pd.transient) remember_stream(pd);
     g.pending.clear();
     g.side.clear();
+    g.transient_verts.clear();
     g.tex_writes.clear();
     g.flush_epoch++;
     g_in_flight.push_back(std::move(fr));
+    upload_remembered_streams();
     prof.mark(7);
 }
 
@@ -2653,6 +2740,8 @@ extern "C" void mi355r_set_scratch_estimate(unsigned long long fan_blocks, unsig
     g.forced_list_estimate = (size_t)list_entries;
     if (!fan_blocks && !list_entries) g.fan_highwater = g.list_highwater = 0;
 }
+
+extern "C" unsigned long long mi355r_replayed_draws(void) { return g.replayed_draws; }
 
 extern "C" unsigned long long mi355r_passes_run_again(void) {
     ensure_ready();

@@ -80,6 +80,37 @@ def test_gpu_per_triangle_submission_matches_reference_golden(gpu, case):
     assert_same(got, load_golden(case["name"]), got[1].size)
 
 
+@pytest.mark.parametrize("case", [c for c in golden_cases() if c["name"] in ("helmet_inside", "kgirl_blend", "azura_shadow", "buster_anim")],
+                         ids=lambda c: c["name"])
+def test_gpu_per_triangle_streams_that_repeat_are_drawn_from_the_device(gpu, case):
+    """Frame after frame the reference's per-face loops submit the same vertices: from the second frame on
+    a model's draw comes from the stream remembered on the device (mi355r_replayed_draws counts them), also
+    under another camera and time, and the frames stay the reference's."""
+    import os
+    from renderer_amd.binding import SCENES
+    gpu.lib.mi355r_replayed_draws.restype = C.c_ulonglong
+    scene = gpu.open_scene(os.path.join(SCENES, case["scene"]) if case["scene"].endswith(".scn") else case["scene"], case.get("like"))
+    view = gpu.make_view(case.get("eye"), case.get("target"), case.get("time", 0.0), case.get("layer", -1))
+    other = gpu.make_view((0.3, 0.8, -1.1), None, case.get("time", 0.0) + 0.37)
+    w, h = case["size"]
+    want = load_golden(case["name"])
+    gpu.lib.rzs_set_per_triangle(1)
+    try:
+        first = gpu.render(scene, w, h, view)
+        before = gpu.lib.mi355r_replayed_draws()
+        second = gpu.render(scene, w, h, view)
+        assert gpu.lib.mi355r_replayed_draws() > before
+        elsewhere = gpu.render(scene, w, h, other)
+        third = gpu.render(scene, w, h, view)
+    finally:
+        gpu.lib.rzs_set_per_triangle(0)
+    by_mesh = gpu.render(scene, w, h, other)
+    gpu.close_scene(scene)
+    for got in (first, second, third):
+        assert_same(got, want, w * h)
+    assert np.array_equal(elsewhere[0], by_mesh[0]) and np.array_equal(elsewhere[1], by_mesh[1])
+
+
 @pytest.mark.parametrize("name,like", [("kgirl_blend.scn", "kgirl"), ("helmet", None)])
 def test_gpu_per_triangle_submission_records_one_draw_per_model(gpu, name, like):
     """graphics_draw_triangle merges consecutive triangles of one model into one draw: the uniform
@@ -348,21 +379,21 @@ def test_gpu_overlays_equal_the_reference_overlays(gpu, oracle, size):
     frames = []
     for pipe in (gpu, oracle):
         lib = pipe.lib
-        lib.texture_create.restype = C.c_void_p
-        lib.texture_create.argtypes = [C.c_int, C.c_int]
-        lib.texture_invalidate.argtypes = [C.c_void_p]
+        P = C.c_void_p
+        texture_create = C.CFUNCTYPE(P, C.c_int, C.c_int)(("texture_create", lib))
+        texture_invalidate = C.CFUNCTYPE(None, P)(("texture_invalidate", lib))
         fb = pipe.framebuffer(w, h)
         lib.framebuffer_clear_color(fb, Vec4(0.3, 0.6, 0.9, 0.5))
         pipe.overlay(fb, ops)
-        tex = lib.texture_create(53, 37)
+        tex = texture_create(53, 37)
         buffer = C.cast(C.cast(tex + 8, C.POINTER(C.c_void_p))[0], C.POINTER(C.c_float))     # texture_t: width, height, buffer
         C.memmove(buffer, hand.ctypes.data, hand.nbytes)
-        lib.texture_invalidate(tex)
+        texture_invalidate(tex)
         for origin in ((0.1, 0.2), (0.97, 0.4), (0.5, 0.99), (0.11, 0.21)):
-            lib.draw2d_draw_texture(fb, tex, Vec2(*origin))
+            pipe._draw_texture(fb, tex, Vec2(*origin))
         pipe.overlay(fb, ops[:8])
         frames.append(pipe.read(fb)[0])
-        lib.texture_release(tex)
+        pipe._texture_release(tex)
         pipe.release(fb)
     assert np.array_equal(frames[0], frames[1])
     assert (frames[0] != np.array([76, 153, 229, 127], np.uint8)).any()

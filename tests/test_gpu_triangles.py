@@ -449,3 +449,54 @@ def test_two_sky_boxes_in_one_pass(gpu, oracle, blend):
         results.append(frames)
     for got, want in zip(*results):
         assert same(got, want)
+
+
+def test_streams_that_change_between_frames(gpu, oracle):
+    """One program, frame after frame: the same triangles (drawn from the remembered stream), a prefix of
+    them, the same with one triangle changed in the middle, more triangles than remembered, and entirely
+    different ones several times in a row -- every frame against the oracle."""
+    rng = np.random.default_rng(77)
+    base = rng.uniform(-0.9, 0.9, (200, 3, 3)).astype(np.float32)
+    changed = base.copy()
+    changed[120] = rng.uniform(-0.9, 0.9, (3, 3))
+    longer = np.concatenate([base, rng.uniform(-0.9, 0.9, (40, 3, 3)).astype(np.float32)])
+    streams = [base, base, base[:150], changed, changed, longer, longer[:10], longer]
+    streams += [rng.uniform(-0.9, 0.9, (64, 3, 3)).astype(np.float32) for _ in range(6)]
+    streams += [base, base]
+    frames = []
+    for pipe in (gpu, oracle):
+        lib = pipe.lib
+        declare(lib)
+        prog = lib.program_create(fn(lib, "blinn_vertex_shader"), fn(lib, "blinn_fragment_shader"), 64, 44, 344, 1, 0)
+        u = BlinnUniforms.from_address(lib.program_get_uniforms(prog))
+        u.light_dir[:] = [0.0, 0.0, -1.0]
+        u.camera_pos[:] = [0.0, 0.0, 2.0]
+        u.model_matrix[:] = IDENTITY4[:]
+        u.normal_matrix[:] = IDENTITY3[:]
+        u.light_vp_matrix[:] = IDENTITY4[:]
+        u.camera_vp_matrix[:] = IDENTITY4[:]
+        u.ambient_intensity = 0.7
+        u.punctual_intensity = 0.6
+        u.shininess = 12.0
+        out = []
+        for n, stream in enumerate(streams):
+            fb = pipe.framebuffer(160, 96)
+            u.basecolor[:] = [0.2 + 0.05 * (n % 10), 0.9 - 0.04 * (n % 7), 0.5, 1.0]
+            for tri in stream:
+                for j in range(3):
+                    a = BlinnAttribs.from_address(lib.program_get_attribs(prog, j))
+                    a.position[:] = [float(x) for x in tri[j]]
+                    a.texcoord[:] = [0.5, 0.5]
+                    a.normal[:] = [0.0, 0.0, 1.0]
+                    a.joint[:] = [0, 0, 0, 0]
+                    a.weight[:] = [0, 0, 0, 0]
+                lib.graphics_draw_triangle(C.cast(fb, C.c_void_p), prog)
+            out.append(pipe.read(fb))
+            pipe.release(fb)
+        lib.program_release(prog)
+        frames.append(out)
+    if gpu.is_gpu:
+        gpu.lib.mi355r_replayed_draws.restype = C.c_ulonglong
+        assert gpu.lib.mi355r_replayed_draws() > 0
+    for n, (g, o) in enumerate(zip(*frames)):
+        assert same(g, o), n
