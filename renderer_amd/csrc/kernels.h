@@ -765,13 +765,20 @@ __global__ void __launch_bounds__(64 * RZ_FILL_WAVES) rz_bin_fill_kernel(const P
          * bin find their places behind the chunk's start in its list by a prefix over the lanes
          * (ascending lane = submission order, as below) and write their entries side by side. */
         if (wave != 0) return;
+        /* lane i asks for bin i's start and whether its list is kept, all bins in one memory round trip
+         * (asked for bin after bin inside the loop they were one dependent round trip each) */
+        uint32_t my_start = 0u, my_kept = 0u;
+        if (lane < ubins) {
+            const int b = (uy0 + lane / uw) * P.bins_x + ux0 + lane % uw;
+            my_start = row[b];
+            my_kept = P.bin_range[b].y;         /* zero: the list is empty or overflowed, nothing is kept */
+        }
         for (int i = 0; i < ubins; i++) {
             const int bx = ux0 + i % uw, by = uy0 + i / uw;
-            const int b = by * P.bins_x + bx;
             const bool touch = r.entries != 0 && bx >= r.bx0 && bx <= r.bx1 && by >= r.by0 && by <= r.by1;
             const unsigned long long touching = __ballot(touch);
-            if (!touching || P.bin_range[b].y == 0) continue;       /* zero: the list is empty or overflowed, nothing is kept */
-            const uint32_t start = row[b];
+            const uint32_t start = (uint32_t)RZ_BCAST_I(my_start, i);
+            if (!touching || RZ_BCAST_I(my_kept, i) == 0) continue;
             uint32_t before;
             if (__ballot(touch && r.entries != 1u) == 0) {
                 before = __builtin_amdgcn_mbcnt_hi((uint32_t)(touching >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)touching, 0u));

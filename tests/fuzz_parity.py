@@ -3,7 +3,9 @@
 tests/fuzz_parity.py [iterations] [seed] [largest width].  Sizes are ragged on purpose (bins, tiles and sky regions cut by
 the frame's edges), cameras go inside the models and close to the sky box (clipping), times are random
 (animation), and every few views a frame is rendered twice into the same framebuffer (pending clears
-against a used buffer, the strip height that follows the last frame)."""
+against a used buffer, the strip height that follows the last frame).  FUZZ_PER_TRIANGLE=1: the GPU library is driven
+face by face (graphics_draw_triangle, the reference's draw_model loops), so that models come back under other views
+and times and their vertex streams are drawn from the copies remembered on the device."""
 import os
 import sys
 
@@ -22,6 +24,8 @@ def main():
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
     widest = int(sys.argv[3]) if len(sys.argv) > 3 else 520
     gpu, oracle = Pipeline(GPU_LIB), Pipeline(ORACLE_LIB)
+    if os.environ.get("FUZZ_PER_TRIANGLE") == "1":
+        gpu.lib.rzs_set_per_triangle(1)
     scenes = [(name, like) for _, name, like, _, _ in CONFIGS] + [("craftsman", None), ("drone", None)]
     opened = {}
     bad = 0
