@@ -611,6 +611,48 @@ __global__ void __launch_bounds__(256) rz_bin_count_kernel(const PassParams *__r
     }
 }
 
+/* Cross-lane steps of scans and reductions go through the VALU's data-parallel primitives (DPP): the
+ * operand comes from a neighbouring lane's register inside the instruction itself, where __shfl makes a
+ * trip through the LDS crossbar (ds_bpermute) and waits for it.  A lane whose source lies outside its row
+ * of 16, or whose row the mask leaves out, gets `otherwise`. */
+#define RZ_DPP_ROW_SHR(n) (0x110 + (n))     /* lane i reads lane i - n of its row */
+#define RZ_DPP_ROW_BCAST15 0x142            /* every lane of a row reads lane 15 of the row before */
+#define RZ_DPP_ROW_BCAST31 0x143            /* rows 2 and 3 read lane 31 */
+template <int CTRL, int ROW_MASK = 0xf>
+RZ_DEV int dpp_from(int otherwise, int v) { return __builtin_amdgcn_update_dpp(otherwise, v, CTRL, ROW_MASK, 0xf, false); }
+
+/* all 64 lanes must be active */
+RZ_DEV uint32_t wave_exclusive_scan(uint32_t v, uint32_t *total) {
+    int x = (int)v;
+    x += dpp_from<RZ_DPP_ROW_SHR(1)>(0, x);
+    x += dpp_from<RZ_DPP_ROW_SHR(2)>(0, x);
+    x += dpp_from<RZ_DPP_ROW_SHR(4)>(0, x);
+    x += dpp_from<RZ_DPP_ROW_SHR(8)>(0, x);                 /* inclusive within each row of 16 */
+    x += dpp_from<RZ_DPP_ROW_BCAST15, 0xa>(0, x);           /* rows 1 and 3 add the row before them */
+    x += dpp_from<RZ_DPP_ROW_BCAST31, 0xc>(0, x);           /* rows 2 and 3 add the first half */
+    *total = (uint32_t)__builtin_amdgcn_readlane(x, 63);
+    return (uint32_t)x - v;
+}
+
+/* the rows' results end up in their last lanes and are combined on the scalar side */
+RZ_DEV int wave_min_i(int v) {
+    v = min(v, dpp_from<RZ_DPP_ROW_SHR(1)>(v, v));
+    v = min(v, dpp_from<RZ_DPP_ROW_SHR(2)>(v, v));
+    v = min(v, dpp_from<RZ_DPP_ROW_SHR(4)>(v, v));
+    v = min(v, dpp_from<RZ_DPP_ROW_SHR(8)>(v, v));
+    return min(min(__builtin_amdgcn_readlane(v, 15), __builtin_amdgcn_readlane(v, 31)),
+               min(__builtin_amdgcn_readlane(v, 47), __builtin_amdgcn_readlane(v, 63)));
+}
+
+RZ_DEV int wave_max_i(int v) {
+    v = max(v, dpp_from<RZ_DPP_ROW_SHR(1)>(v, v));
+    v = max(v, dpp_from<RZ_DPP_ROW_SHR(2)>(v, v));
+    v = max(v, dpp_from<RZ_DPP_ROW_SHR(4)>(v, v));
+    v = max(v, dpp_from<RZ_DPP_ROW_SHR(8)>(v, v));
+    return max(max(__builtin_amdgcn_readlane(v, 15), __builtin_amdgcn_readlane(v, 31)),
+               max(__builtin_amdgcn_readlane(v, 47), __builtin_amdgcn_readlane(v, 63)));
+}
+
 /* 1024 threads = 64 bins x 16 segments of the chunk range */
 #define RZ_SCAN_SEGMENTS 16
 __global__ void __launch_bounds__(64 * RZ_SCAN_SEGMENTS) rz_bin_scan_kernel(const PassParams *__restrict__ passes) {
@@ -655,7 +697,7 @@ __global__ void __launch_bounds__(64 * RZ_SCAN_SEGMENTS) rz_bin_scan_kernel(cons
     }
     if (segment == 0) {             /* the pass's longest list, for the host's choice of strip height next time */
         uint32_t longest = bin < bins ? total : 0u;
-        for (int off = 32; off; off >>= 1) longest = max(longest, (uint32_t)__shfl_xor((int)longest, off));
+        longest = (uint32_t)wave_max_i((int)longest);           /* entry counts stay far below 2^31 */
         if ((threadIdx.x & 63) == 0 && longest) atomicMax(&P.control[4], longest);
     }
     __syncthreads();
@@ -672,27 +714,6 @@ __global__ void __launch_bounds__(64 * RZ_SCAN_SEGMENTS) rz_bin_scan_kernel(cons
             run += v[u];
         }
     }
-}
-
-RZ_DEV uint32_t wave_exclusive_scan(uint32_t v, uint32_t *total) {
-    const int lane = threadIdx.x & 63;
-    uint32_t inc = v;
-    for (int off = 1; off < 64; off <<= 1) {
-        uint32_t up = __shfl_up(inc, off);
-        if (lane >= off) inc += up;
-    }
-    *total = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
-    return inc - v;
-}
-
-RZ_DEV int wave_min_i(int v) {
-    for (int off = 32; off > 0; off >>= 1) v = min(v, __shfl_xor(v, off));
-    return v;
-}
-
-RZ_DEV int wave_max_i(int v) {
-    for (int off = 32; off > 0; off >>= 1) v = max(v, __shfl_xor(v, off));
-    return v;
 }
 
 #define RZ_FILL_FAN_SLOTS 64
@@ -1362,8 +1383,7 @@ __global__ void __launch_bounds__(256) rz_raster_list_kernel(const PassParams *_
     const int lane = threadIdx.x & 63;
     const uint32_t my_count = min(queue_counts[(RZ_ORDERED_LIST * RZ_QUEUE_WAYS + lane) * RZ_QUEUE_PAD], queue_capacity);
     uint32_t longest = my_count;
-    for (int off = 32; off > 0; off >>= 1) longest = max(longest, (uint32_t)__shfl_xor((int)longest, off));
-    longest = (uint32_t)__builtin_amdgcn_readfirstlane((int)longest);
+    longest = (uint32_t)wave_max_i((int)longest);
     for (uint32_t k = blockIdx.x; k < longest * RZ_QUEUE_WAYS; k += gridDim.x) {
         const uint32_t part = k & (RZ_QUEUE_WAYS - 1u), index = k / RZ_QUEUE_WAYS;
         if (index >= (uint32_t)__builtin_amdgcn_readlane((int)my_count, (int)part)) continue;
@@ -2410,8 +2430,7 @@ __global__ void __launch_bounds__(256) rz_shade_list_kernel(const PassParams *__
     /* lane q holds the length of part q of this family's list */
     const uint32_t my_count = min(queue_counts[(FAMILY * RZ_QUEUE_WAYS + lane) * RZ_QUEUE_PAD], queue_capacity);
     uint32_t longest = my_count;
-    for (int off = 32; off > 0; off >>= 1) longest = max(longest, (uint32_t)__shfl_xor((int)longest, off));
-    longest = (uint32_t)__builtin_amdgcn_readfirstlane((int)longest);
+    longest = (uint32_t)wave_max_i((int)longest);
     constexpr uint32_t per_turn = BLOCKS ? 2u : 1u;
     /* (wave-uniform, and said so: everything read through `k` -- the item, the pass's parameters, the
      * draw record -- must come through scalar loads) */
