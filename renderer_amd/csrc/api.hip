@@ -1963,7 +1963,7 @@ static void launch_batch(const Batch &b, const std::vector<PassPlan> &plans, cha
     stamp();
     rz_bin_count_kernel<<<tgrid, dim3(256), 0, st>>>(passes);
     rz_bin_scan_kernel<<<dim3((unsigned)((max_bins + 63) / 64), n), dim3(64 * RZ_SCAN_SEGMENTS), 0, st>>>(passes);
-    rz_bin_fill_kernel<<<dim3((unsigned)((max_T + 63) / 64), n), dim3(64 * RZ_FILL_WAVES), 0, st>>>(passes);
+    rz_bin_fill_kernel<<<dim3((unsigned)((max_T + 63) / 64 * n)), dim3(64 * RZ_FILL_WAVES), 0, st>>>(passes, n);
     stamp();
     bool narrow = true;
     for (size_t i : b.members) narrow = narrow && plans[i].narrow_texels;

@@ -733,10 +733,15 @@ RZ_DEV uint2 entry_box(float4 q3) {
  * are the per-bin start offsets.  Every entry carries a copy of the
  * triangle's record. */
 #define RZ_FILL_WAVES 4
-__global__ void __launch_bounds__(64 * RZ_FILL_WAVES) rz_bin_fill_kernel(const PassParams *__restrict__ passes) {
-    const PassParams &P = passes[blockIdx.y];
-    const uint32_t chunk = blockIdx.x;
-    if (chunk * 64u >= (uint32_t)P.num_tris) return;            /* uniform over the workgroup */
+__global__ void __launch_bounds__(64 * RZ_FILL_WAVES) rz_bin_fill_kernel(const PassParams *__restrict__ passes, uint32_t num_passes) {
+    /* Workgroups start in index order: the pass is the fastest part of the index and a pass's chunks are taken
+     * from its last one down.  The chunks that run longest are those of triangles over many bins, i.e. the sky
+     * box, which a frame draws last (test_helper.c:497-503): they start first in every pass instead of making
+     * up the launch's tail. */
+    const PassParams &P = passes[blockIdx.x % num_passes];
+    const uint32_t chunks = ((uint32_t)P.num_tris + 63u) / 64u, turn = blockIdx.x / num_passes;
+    if (turn >= chunks) return;                                 /* uniform over the workgroup */
+    const uint32_t chunk = chunks - 1u - turn;
     if (P.control[2] != 0u) return;                             /* out of scratch, or left out: the pass is run again later */
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t t = chunk * 64u + lane;
