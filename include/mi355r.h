@@ -312,6 +312,12 @@ void framebuffer_read_device(rz_framebuffer *framebuffer, void *color_rgba8_dev,
  * pixel is whatever the last clear put there: a receiver that knows the clear colour loses nothing,
  * and a gather of frames over GPU links moves a quarter less. */
 void framebuffer_read_device_rgb(rz_framebuffer *framebuffer, void *color_rgb8_dev);
+/* The same for `count` framebuffers at once, frame i at color_rgb8_dev + i * stride_bytes (stride and
+ * pointer multiples of 4, stride at least width * height * 3): the copies follow the rendering on each
+ * framebuffer's own stream and the host waits once for all of them -- what a step's frames cost on
+ * their way into the buffer a gather sends. */
+void framebuffers_read_device_rgb(rz_framebuffer *const *framebuffers, int count, void *color_rgb8_dev,
+                                  size_t stride_bytes);
 
 /* Explicit family registration for hosts whose shader functions are not
  * visible as dynamic symbols. */

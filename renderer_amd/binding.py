@@ -96,6 +96,7 @@ class Pipeline:
             lib.mi355r_init.restype = C.c_int
             lib.framebuffer_read_device.argtypes = [FB, P, P]
             lib.framebuffer_read_device_rgb.argtypes = [FB, P]
+            lib.framebuffers_read_device_rgb.argtypes = [C.POINTER(FB), C.c_int, P, C.c_size_t]
             lib.mi355r_get_counters.argtypes = [C.POINTER(C.c_ulonglong)]
             lib.mi355r_enable_counters.argtypes = [C.c_int]
             lib.mi355r_stream.restype = P

@@ -2163,6 +2163,40 @@ static void settle_framebuffer(Fb *fb) {
             if (fr.plans[i].fb == fb && fr.control(i)[2] != 0) { settle_in_flight(false); return; }
 }
 
+/* framebuffer_read_device_rgb for many framebuffers at once (the frames of a step, about to be gathered): their copies are
+ * launched behind the rendering on each framebuffer's own lane and the host waits once, for all lanes,
+ * instead of once or twice per frame.  Should one of their passes turn out not to have run (out of
+ * scratch), the flush is settled and the copies are made again. */
+extern "C" void framebuffers_read_device_rgb(rz_framebuffer *const *fps, int count, void *rgb, size_t stride_bytes) {
+    if (count <= 0) return;
+    if (!rgb || ((uintptr_t)rgb & 3u) || (stride_bytes & 3u))
+        fatal("framebuffers_read_device_rgb: destination and stride must be 4-byte aligned (%p, %zu)", rgb, stride_bytes);
+    std::vector<Fb*> fbs((size_t)count);
+    for (int i = 0; i < count; i++) {
+        fbs[i] = as_fb(fps[i]);
+        if ((size_t)fbs[i]->pub.width * fbs[i]->pub.height * 3 > stride_bytes) fatal("framebuffers_read_device_rgb: frame %d is larger than the stride", i);
+    }
+    graphics_flush();
+    for (int attempt = 0; attempt < 2; attempt++) {
+        for (int i = 0; i < count; i++) {
+            Fb *fb = fbs[i];
+            apply_pending_clear(fb);
+            const size_t n = (size_t)fb->pub.width * fb->pub.height;
+            hipStream_t st = g.lanes[fb->lane < 0 ? 0 : fb->lane].stream;
+            rz_strip_alpha_kernel<<<dim3((unsigned)((n / 4 + 1 + 255) / 256)), dim3(256), 0, st>>>(
+                fb->d_color, (uint32_t*)((char*)rgb + (size_t)i * stride_bytes), n);
+            HIP_OK(hipGetLastError());
+        }
+        for (int l = 0; l < g.num_lanes; l++) HIP_OK(hipStreamSynchronize(g.lanes[l].stream));
+        bool left_out = false;
+        for (const FlushRecord &fr : g_in_flight)
+            for (size_t k = 0; k < fr.plans.size() && !left_out; k++)
+                if (fr.control(k)[2] != 0 && std::find(fbs.begin(), fbs.end(), fr.plans[k].fb) != fbs.end()) left_out = true;
+        if (!left_out) return;
+        settle_in_flight(false);
+    }
+}
+
 /* ---- texture_sync without allocations ---------------------------------------
  * texture_sync above stages the row-major float4 image in a buffer it allocates and frees per call.
  * Callers that cannot allocate device memory (code under HIP graph capture, a viewer's loop that shows

@@ -54,6 +54,11 @@ def frames_to_tensor(pipe, framebuffers, count, out):
     framebuffer_read_device_rgb), host tensors through framebuffer_read."""
     frame_bytes = out[0].numel()
     channels = out.shape[-1]
+    if out.is_cuda and channels == 3 and count > 0:
+        # all of them behind the rendering on their own streams, one wait for the lot
+        handles = (type(framebuffers[0]) * count)(*framebuffers[:count])
+        pipe.lib.framebuffers_read_device_rgb(handles, count, C.c_void_p(out.data_ptr()), frame_bytes)
+        return out
     for i in range(count):
         dst = C.c_void_p(out.data_ptr() + i * frame_bytes)
         if out.is_cuda and channels == 3:

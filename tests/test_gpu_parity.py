@@ -426,6 +426,61 @@ def test_gpu_frames_without_their_alpha_bytes(gpu, size):
     gpu.close_scene(scene)
 
 
+def test_gpu_many_frames_without_their_alpha_bytes_at_once(gpu):
+    """framebuffers_read_device_rgb: the frames of a step copied out together (one wait for all lanes) equal
+    the frames copied out one by one, each at its stride, nothing in between touched; also right after the
+    draws were recorded, and with a framebuffer that was only cleared."""
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    hip.hipMemset.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    hip.hipFree.argtypes = [C.c_void_p]
+    from renderer_amd.binding import Vec4
+    w, h, count = 322, 181, 9
+    stride = (w * h * 3 + 3) // 4 * 4 + 64
+    scene = gpu.open_scene("helmet")
+    fbs = [gpu.framebuffer(w, h) for _ in range(count)]
+    gpu.lib.framebuffer_clear_color(fbs[-1], Vec4(0.2, 0.4, 0.6, 1.0))
+    for i, fb in enumerate(fbs[:-1]):
+        gpu.draw(scene, fb, gpu.orbit_view(i, 16))
+    dev = C.c_void_p()
+    assert hip.hipMalloc(C.byref(dev), stride * count) == 0 and hip.hipMemset(dev, 9, stride * count) == 0
+    handles = (type(fbs[0]) * count)(*fbs)
+    gpu.lib.framebuffers_read_device_rgb(handles, count, dev, stride)     # the draws are still only recorded
+    got = np.zeros(stride * count, np.uint8)
+    assert hip.hipMemcpy(got.ctypes.data_as(C.c_void_p), dev, stride * count, 2) == 0
+    hip.hipFree(dev)
+    got = got.reshape(count, stride)
+    for i, fb in enumerate(fbs):
+        color, _ = gpu.read(fb)
+        assert np.array_equal(got[i, :w * h * 3].reshape(h, w, 3), color[..., :3]), i
+        assert np.all(got[i, w * h * 3:] == 9)
+        gpu.release(fb)
+    assert np.all(got[-1, :3] == np.array([51, 102, 153], np.uint8))
+    gpu.close_scene(scene)
+
+
+def test_gpu_frames_into_the_gather_buffer(gpu):
+    """orbit.frames_to_tensor with a device tensor, as bench.py --gpus N fills the buffer its gather sends:
+    RGB8 (all frames in one call) and RGBA8 (frame by frame) against the frames read back one by one."""
+    import torch
+    from renderer_amd import orbit
+    w, h, count = 200, 120, 6
+    scene = gpu.open_scene("helmet")
+    fbs = [gpu.framebuffer(w, h) for _ in range(count)]
+    orbit.render_views(gpu, scene, fbs, [gpu.orbit_view(i, 16) for i in range(count)])
+    rgb = orbit.frames_to_tensor(gpu, fbs, count, torch.zeros((count + 1, h, w, 3), dtype=torch.uint8, device="cuda"))
+    rgba = orbit.frames_to_tensor(gpu, fbs, count, torch.zeros((count, h, w, 4), dtype=torch.uint8, device="cuda"))
+    torch.cuda.synchronize()
+    rgb, rgba = rgb.cpu().numpy(), rgba.cpu().numpy()
+    for i, fb in enumerate(fbs):
+        color, _ = gpu.read(fb)
+        assert np.array_equal(rgb[i], color[..., :3]) and np.array_equal(rgba[i], color)
+        gpu.release(fb)
+    assert not rgb[count].any()
+    gpu.close_scene(scene)
+
+
 @pytest.mark.gpu
 def test_gpu_random_views_match_oracle():
     """tests/fuzz_parity.py for a few dozen views: ragged sizes, cameras inside the models and near the sky
