@@ -5,6 +5,8 @@
  * software renderer that make up its hot path,
  *     renderer/core/graphics.c   (framebuffer, program, graphics_draw_triangle)
  *     renderer/core/texture.c    (texture / cubemap objects, samplers, depth->texture)
+ * and for the one that draws 2-D overlays straight into a colour buffer,
+ *     renderer/core/draw2d.c     (points, lines, outlines, label images)
  * and exports their public functions under their original names with
  * identical signatures and struct layouts (x86-64 SysV), so the reference's
  * scene files, shader "high-level api" and frame driver link against it
