@@ -31,7 +31,7 @@ SCENE = "helmet"
 ORBIT = 128                 # views on the orbit circle
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E
 GATHER_CHANNELS = 3         # N > 1: frames travel as RGB8 (a draw never writes the alpha byte, graphics.c:466-468)
-KERNEL_SYMBOL = {"vertex": "rz_vertex_kernel", "setup": "rz_setup_kernel", "bin": "rz_bin_fill_kernel",
+KERNEL_SYMBOL = {"vertex": "rz_vertex_kernel", "setup": "rz_clip_kernel", "bin": "rz_bin_fill_kernel",
                  "raster": "rz_strip_kernel<4, false>", "shade_skybox": "rz_sky_kernel<2>",
                  "shade_blinn": "rz_shade_list_kernel<0, true, true>", "shade_pbr": "rz_shade_list_kernel<1, true, true>"}
 

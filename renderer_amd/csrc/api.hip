@@ -1929,7 +1929,7 @@ static void launch_batch(const Batch &b, const std::vector<PassPlan> &plans, cha
         HIP_OK(hipEventRecord(e, st));
         g.timing_events.push_back(e);
     };
-    const dim3 vgrid((unsigned)((max_T * 3 + 255) / 256), n), tgrid((unsigned)((max_T + 255) / 256), n);
+    const dim3 vgrid((unsigned)((max_T + RZ_VS_TRIS - 1) / RZ_VS_TRIS), n), tgrid((unsigned)((max_T + 255) / 256), n);
     const dim3 tiles((unsigned)max_tiles_x, (unsigned)max_tiles_y, n);
     /* tile_order (kernels.h): whole bins, i.e. an even number of tile columns and a multiple of a bin's tile rows */
     const unsigned bin_columns = (unsigned)(max_tiles_x + 1) / 2, bin_rows = (unsigned)(max_tiles_y * RZ_TILE_H + RZ_BIN - 1) / RZ_BIN;
@@ -1956,9 +1956,9 @@ static void launch_batch(const Batch &b, const std::vector<PassPlan> &plans, cha
             fatal("scratch of lane %d is smaller than the batch it is about to run", b.lane);
     }
     stamp();
-    rz_vertex_kernel<<<vgrid, dim3(256), 0, st>>>(passes);
+    rz_begin_kernel<<<dim3(64, n), dim3(256), 0, st>>>(passes);
+    rz_vertex_kernel<<<vgrid, dim3(256), 0, st>>>(passes);      /* with the triangles' set-up */
     stamp();
-    rz_setup_kernel<<<tgrid, dim3(256), 0, st>>>(passes);
     rz_clip_kernel<<<dim3(256, n), dim3(64), 0, st>>>(passes);
     stamp();
     rz_bin_count_kernel<<<tgrid, dim3(256), 0, st>>>(passes);

@@ -61,21 +61,48 @@ RZ_DEV void mat_mul(const float *a, const float *b, float *c) {
     }
 }
 
-__global__ void __launch_bounds__(256) rz_vertex_kernel(const PassParams *__restrict__ passes) {
+/* first kernel of a batch: what the passes' kernels count in or add into starts at zero */
+__global__ void __launch_bounds__(256) rz_begin_kernel(const PassParams *__restrict__ passes) {
     const PassParams &P = passes[blockIdx.y];
-    uint32_t gv = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t gv = blockIdx.x * 256u + threadIdx.x;
     /* the pass's device-written scalars start at zero -- unless another pass of the flush ran out of
      * scratch and this one may depend on it: then it is marked to be left out and run again later */
     if (gv < 8u) P.control[gv] = (gv == 2u && P.level > 0 && *P.flush_flag != 0u) ? (uint32_t)RZ_ERR_SKIPPED : 0u;
     if (blockIdx.y == 0 && gv < 3u * RZ_QUEUE_WAYS) P.queue_counts[gv * RZ_QUEUE_PAD] = 0;    /* ... and the batch's work-list lengths */
-    /* the grid is sized for the largest pass of the batch: all of its threads share the clearing */
     for (uint32_t t = gv; t < (uint32_t)(P.tiles_x * P.tiles_y); t += gridDim.x * 256u) P.tile_listed[t] = 0;
     {   /* ... and the pass's (chunk, bin) matrix, which rz_bin_count_kernel adds into */
         const uint32_t cells = (((uint32_t)P.num_tris + 63u) / 64u) * (uint32_t)(P.bins_x * P.bins_y);
         for (uint32_t t = gv; t < cells; t += gridDim.x * 256u) P.bin_counts[t] = 0;
     }
-    if (gv >= 3u * (uint32_t)P.num_tris) return;
-    int d = find_draw(P.first_tri, P.num_draws, gv / 3u);
+}
+
+RZ_DEV bool make_tri(const f4 c[3], int width, int height, bool double_sided, uint32_t draw,
+                     TriRec &rec, int &x0, int &x1, int &y0, int &y1);
+RZ_DEV bool fully_visible(f4 v);
+RZ_DEV uint2 pack_bin_box(uint32_t bx, uint32_t by, uint32_t entries);
+RZ_DEV void store_tri(TriRec *dst, const TriRec &r);
+
+/* Vertex shaders and triangle set-up in one kernel.  A workgroup takes 85 triangles: thread 3k + i shades
+ * corner i of triangle k (thread 255 idles) and leaves its clip-space position in LDS; the triangle's
+ * first thread then does the set-up from the three positions -- trivial accept (graphics.c:275-277),
+ * cull, record and pixel box, or the queue of the clipper -- and tells the other two what became of it.
+ * Varyings are stored for triangles that live (half of a closed mesh's are culled: nothing ever reads
+ * theirs), clip-space positions only for triangles the clipper will read them of. */
+#define RZ_VS_TRIS 85
+__global__ void __launch_bounds__(256) rz_vertex_kernel(const PassParams *__restrict__ passes) {
+    const PassParams &P = passes[blockIdx.y];
+    __shared__ float4 s_clip[256];
+    __shared__ int s_fate[RZ_VS_TRIS + 1];          /* 0 culled, 1 alive, 2 for the clipper */
+    const uint32_t tri = blockIdx.x * (uint32_t)RZ_VS_TRIS + threadIdx.x / 3u, corner = threadIdx.x % 3u;
+    if (blockIdx.x * (uint32_t)RZ_VS_TRIS >= (uint32_t)P.num_tris) return;      /* uniform over the workgroup */
+    const bool mine = threadIdx.x < 3u * RZ_VS_TRIS && tri < (uint32_t)P.num_tris;
+    const uint32_t gv = 3u * tri + corner;
+    int d = 0;
+    f4 clip = mk4(0, 0, 0, 0);
+    float vary[RZ_VARY_STRIDE];     /* put together in registers, stored as whole groups of four below */
+    for (int k = 0; k < RZ_VARY_STRIDE; k++) vary[k] = 0;
+    if (mine) {
+    d = find_draw(P.first_tri, P.num_draws, tri);
     const DrawRec &D = P.draws[d];
     uint32_t local = gv - 3u * P.first_tri[d];
     const float4 RZ_GLOBAL *src = (const float4 RZ_GLOBAL*)(D.vertices.as<const char>() + (size_t)local * 80u);
@@ -84,10 +111,7 @@ __global__ void __launch_bounds__(256) rz_vertex_kernel(const PassParams *__rest
         float4 q = src[i];
         a[4 * i] = q.x; a[4 * i + 1] = q.y; a[4 * i + 2] = q.z; a[4 * i + 3] = q.w;
     }
-    float vary[RZ_VARY_STRIDE];     /* put together in registers, stored as whole groups of four below */
-    for (int k = 0; k < RZ_VARY_STRIDE; k++) vary[k] = 0;
     f4 pos = mk4(a[0], a[1], a[2], 1.0f);
-    f4 clip;
 
     if (D.family == 2) {                                        /* skybox_shader.c:8-19 */
         clip = m4v4(D.camera_vp, pos);
@@ -146,9 +170,49 @@ __global__ void __launch_bounds__(256) rz_vertex_kernel(const PassParams *__rest
             }
         }
     }
-    P.clip.as<float4>()[gv] = make_float4(clip.x, clip.y, clip.z, clip.w);
+    }
+    s_clip[threadIdx.x] = make_float4(clip.x, clip.y, clip.z, clip.w);
+    __syncthreads();
+    if (mine && corner == 0u) {
+        const DrawRec &D = P.draws[d];
+        const bool double_sided = (D.flags & RZ_DRAW_DOUBLE_SIDED) != 0;
+        /* what the rasteriser needs to know about the draw without loading it */
+        const uint32_t class_bits = ((D.flags & RZ_DRAW_BLEND) ? 1u << 22 : 0u) | (D.alpha_cutoff > 0 ? 1u << 23 : 0u) |
+                                    ((uint32_t)D.family << 24);
+        f4 c[3];
+        for (int i = 0; i < 3; i++) {
+            const float4 q = s_clip[threadIdx.x + i];
+            c[i] = mk4(q.x, q.y, q.z, q.w);
+        }
+        const uint2 empty = make_uint2(RZ_BBOX_EMPTY_X, RZ_BBOX_EMPTY_X);
+        int fate = 0;
+        if (fully_visible(c[0]) && fully_visible(c[1]) && fully_visible(c[2])) {        /* graphics.c:290-300 */
+            TriRec rec;
+            int x0, x1, y0, y1;
+            if (make_tri(c, P.width, P.height, double_sided, (uint32_t)d, rec, x0, x1, y0, y1)) {
+                rec.meta |= class_bits;
+                store_tri(&P.tri[tri], rec);
+                P.bbox[tri] = pack_bin_box(rec.bx, rec.by, 1u);
+                if (P.counters) atomicAdd(&P.counters[1], 1ull);
+                fate = 1;
+            } else {
+                P.bbox[tri] = empty;
+            }
+        } else {
+            /* needs the clipper: queued for rz_clip_kernel, which fills tri/bbox */
+            P.bbox[tri] = empty;
+            P.clip_list[atomicAdd(&P.control[3], 1u)] = tri;
+            fate = 2;
+        }
+        s_fate[threadIdx.x / 3u] = fate;
+    }
+    __syncthreads();
+    if (!mine) return;
+    const int fate = s_fate[threadIdx.x / 3u];
+    if (fate == 0) return;
+    if (fate == 2) P.clip.as<float4>()[gv] = make_float4(clip.x, clip.y, clip.z, clip.w);
     float4 RZ_GLOBAL *out = (float4 RZ_GLOBAL*)(P.vary + (size_t)gv * RZ_VARY_STRIDE);
-    const int groups = (D.num_varyings + 3) / 4;                /* 1 skybox, 3 blinn, 6 pbr */
+    const int groups = (P.draws[d].num_varyings + 3) / 4;       /* 1 skybox, 3 blinn, 6 pbr */
     for (int i = 0; i < RZ_VARY_STRIDE / 4; i++)
         if (i < groups) out[i] = make_float4(vary[4 * i], vary[4 * i + 1], vary[4 * i + 2], vary[4 * i + 3]);
 }
@@ -397,40 +461,6 @@ RZ_DEV void store_tri(TriRec *dst, const TriRec &r) {
     o[1] = make_float4(r.acx, r.acy, r.factor, r.z[0]);
     o[2] = make_float4(r.z[1], r.z[2], r.rw[0], r.rw[1]);
     o[3] = make_float4(r.rw[2], __uint_as_float(r.meta), __uint_as_float(r.bx), __uint_as_float(r.by));
-}
-
-__global__ void __launch_bounds__(256) rz_setup_kernel(const PassParams *__restrict__ passes) {
-    const PassParams &P = passes[blockIdx.y];
-    uint32_t t = blockIdx.x * 256u + threadIdx.x;
-    if (t >= (uint32_t)P.num_tris) return;
-    int d = find_draw(P.first_tri, P.num_draws, t);
-    const DrawRec &D = P.draws[d];
-    bool double_sided = (D.flags & RZ_DRAW_DOUBLE_SIDED) != 0;
-    /* what the rasteriser needs to know about the draw without loading it */
-    const uint32_t class_bits = ((D.flags & RZ_DRAW_BLEND) ? 1u << 22 : 0u) | (D.alpha_cutoff > 0 ? 1u << 23 : 0u) |
-                                ((uint32_t)D.family << 24);
-    f4 c[3];
-    for (int i = 0; i < 3; i++) {
-        float4 q = P.clip.as<const float4>()[3u * t + i];
-        c[i] = mk4(q.x, q.y, q.z, q.w);
-    }
-    uint2 empty = make_uint2(RZ_BBOX_EMPTY_X, RZ_BBOX_EMPTY_X);
-    if (fully_visible(c[0]) && fully_visible(c[1]) && fully_visible(c[2])) {        /* graphics.c:290-300 */
-        TriRec rec;
-        int x0, x1, y0, y1;
-        if (make_tri(c, P.width, P.height, double_sided, (uint32_t)d, rec, x0, x1, y0, y1)) {
-            rec.meta |= class_bits;
-            store_tri(&P.tri[t], rec);
-            P.bbox[t] = pack_bin_box(rec.bx, rec.by, 1u);
-            if (P.counters) atomicAdd(&P.counters[1], 1ull);
-        } else {
-            P.bbox[t] = empty;
-        }
-    } else {
-        /* needs the clipper: queued for rz_clip_kernel, which fills tri/bbox */
-        P.bbox[t] = empty;
-        P.clip_list[atomicAdd(&P.control[3], 1u)] = t;
-    }
 }
 
 /* K2b  clipping, one WAVE per queued triangle.  Lane c carries one float
