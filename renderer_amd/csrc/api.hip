@@ -1143,7 +1143,9 @@ extern "C" rz_program *program_create(rz_vertex_shader *vs, rz_fragment_shader *
     p->uniform_bytes = sizeof_uniforms;
     p->double_sided = double_sided;
     p->blend = enable_blend;
-    for (int i = 0; i < 3; i++) p->attribs[i] = calloc(1, sizeof_attribs);
+    p->attribs[0] = calloc(3, sizeof_attribs);          /* one allocation: a pbr program's three blocks are then a piece of vertex stream as they are */
+    p->attribs[1] = (char*)p->attribs[0] + sizeof_attribs;
+    p->attribs[2] = (char*)p->attribs[0] + 2 * (size_t)sizeof_attribs;
     p->uniforms = calloc(1, sizeof_uniforms);
     return p;
 }
@@ -1155,7 +1157,7 @@ extern "C" void program_release(rz_program *p) {                    /* graphics.
         if (remembered->second.d_vertices) { sync_stream(); HIP_OK(hipFree(remembered->second.d_vertices)); }
         g.replays.erase(remembered);
     }
-    for (int i = 0; i < 3; i++) free(p->attribs[i]);
+    free(p->attribs[0]);
     free(p->uniforms);
     delete p;
 }
@@ -1540,22 +1542,41 @@ static void upload_remembered_streams() {
 extern "C" void graphics_draw_triangle(rz_framebuffer *fp, rz_program *program) {
     Fb *fb = (Fb*)fp;
     if (fb != g.checked_fb || !fb) g.checked_fb = fb = as_fb(fp);
-    rz_vertex tri[3];
-    int top = 0;
-    for (int j = 0; j < 3; j++) {
-        rz_vertex &v = tri[j];
-        if (program->family == RZ_FAMILY_BLINN) {
-            const rz_blinn_attribs *a = (const rz_blinn_attribs*)program->attribs[j];
-            memset(&v, 0, sizeof v);
-            v.position = a->position; v.texcoord = a->texcoord; v.normal = a->normal;
-            v.joint = a->joint; v.weight = a->weight;
-        } else if (program->family == RZ_FAMILY_PBR) {
-            v = *(const rz_vertex*)program->attribs[j];
-        } else {
-            memset(&v, 0, sizeof v);
-            v.position = ((const rz_skybox_attribs*)program->attribs[j])->position;
+    rz_vertex built[3];
+    const rz_vertex *tri = built;
+    if (program->family == RZ_FAMILY_PBR && program->attribs[1] == (char*)program->attribs[0] + sizeof(rz_vertex) &&
+        program->attribs[2] == (char*)program->attribs[0] + 2 * sizeof(rz_vertex)) {
+        tri = (const rz_vertex*)program->attribs[0];    /* the three blocks are one allocation and already have the stream's layout */
+    } else {
+        for (int j = 0; j < 3; j++) {
+            rz_vertex &v = built[j];
+            if (program->family == RZ_FAMILY_BLINN) {
+                const rz_blinn_attribs *a = (const rz_blinn_attribs*)program->attribs[j];
+                memset(&v, 0, sizeof v);
+                v.position = a->position; v.texcoord = a->texcoord; v.normal = a->normal;
+                v.joint = a->joint; v.weight = a->weight;
+            } else if (program->family == RZ_FAMILY_PBR) {
+                v = *(const rz_vertex*)program->attribs[j];
+            } else {
+                memset(&v, 0, sizeof v);
+                v.position = ((const rz_skybox_attribs*)program->attribs[j])->position;
+            }
         }
-        top = std::max(top, std::max(std::max((int)v.joint.x, (int)v.joint.y), std::max((int)v.joint.z, (int)v.joint.w)));
+    }
+    /* joints a skinned program's triangle refers to (1 + the largest index): only such a program's draw keeps a pose */
+    int joints_needed = 1;
+    {
+        const rz_mat4 *joints;
+        const rz_mat3 *joint_normals;
+        pose_of(program, &joints, &joint_normals);
+        if (joints) {
+            int top = 0;
+            for (int j = 0; j < 3; j++) {
+                const rz_vec4 &q = tri[j].joint;
+                top = std::max(top, std::max(std::max((int)q.x, (int)q.y), std::max((int)q.z, (int)q.w)));
+            }
+            joints_needed = top + 1;
+        }
     }
     const char *ub = (const char*)program->uniforms;
     if (!g.pending.empty()) {
@@ -1564,7 +1585,7 @@ extern "C" void graphics_draw_triangle(rz_framebuffer *fp, rz_program *program) 
         if (!copy_between && last.transient && last.fb == fb && last.program == program &&
             last.uniform_bytes.size() == (size_t)program->uniform_bytes &&
             memcmp(last.uniform_bytes.data(), ub, program->uniform_bytes) == 0 &&
-            same_pose(program, last, top + 1)) {
+            same_pose(program, last, joints_needed)) {
             append_transient(last, tri);
             last.rec.num_faces++;
             return;
@@ -1574,7 +1595,7 @@ extern "C" void graphics_draw_triangle(rz_framebuffer *fp, rz_program *program) 
     pd.fb = fb;
     pd.program = program;
     pd.transient = true;
-    snapshot_uniforms(program, pd, top + 1);            /* may flush what is recorded: the draw's vertices are appended after it */
+    snapshot_uniforms(program, pd, joints_needed);      /* may flush what is recorded: the draw's vertices are appended after it */
     pd.uniform_bytes.assign(ub, ub + program->uniform_bytes);
     pd.verts_at = g.transient_verts.size();
     pd.rec.num_faces = 0;
