@@ -96,8 +96,9 @@ def measured_counters(symbol, frames_per_launch, key):
 
 
 def calibrate_split(gpu, orbit, scene, B, world, rank, device, dist, torch):
-    """Frames per peer and step for the gather-aware split, from rank 0's render rate and the rate at
-    which the peers' frames arrive when all of them send at once (both measured here, on B frames)."""
+    """Frames per peer and step for the gather-aware split, from the rate at which rank 0 renders frames and
+    copies them out and the rate at which the peers' frames arrive when all of them send at once (both
+    measured here, on B frames)."""
     fbs = [gpu.framebuffer(WIDTH, HEIGHT) for _ in range(B)]
     views = [gpu.orbit_view(i % ORBIT, ORBIT) for i in range(B)]
     trial = orbit.FrameGather(B, HEIGHT, WIDTH, device, rank, world, depth=1, channels=GATHER_CHANNELS)
@@ -109,11 +110,15 @@ def calibrate_split(gpu, orbit, scene, B, world, rank, device, dist, torch):
     orbit.render_views(gpu, scene, fbs, views)
     trial.submit(gpu, fbs, B)                   # first use of the scene, the links and the buffers
     fence()
+    # rank 0's own frames as the timed loop produces them: recorded, rendered, then copied into the buffer it keeps them in
+    own = torch.empty((B, HEIGHT, WIDTH, GATHER_CHANNELS), dtype=torch.uint8, device=device)
     t0 = time.perf_counter()
     for _ in range(2):
         orbit.render_views(gpu, scene, fbs, views)
+        orbit.frames_to_tensor(gpu, fbs, B, own)
     torch.cuda.synchronize()
     render_s = (time.perf_counter() - t0) / 2
+    del own
     fence()
     t0 = time.perf_counter()
     trial.submit(gpu, fbs, B)
