@@ -1833,7 +1833,7 @@ static void prepare_batch(const Batch &b, const FlushRecord &fr, bool reserve_on
     reserve(L.bin_counts, matrix, st);
     /* tiles are dealt to the parts of a list by their index: a part holds at most its even share */
     /* (32x8 tiles, or the two 16x8 blocks of each that rz_strip_kernel lists) */
-    const size_t queue_capacity = (2 * tiles + RZ_QUEUE_WAYS - 1) / RZ_QUEUE_WAYS;
+    const size_t queue_capacity = (2 * tiles + RZ_QUEUE_WAYS - 1) / RZ_QUEUE_WAYS + b.members.size();    /* every pass's share rounded up */
     reserve(L.tile_listed, tiles, st);
     reserve(L.queue, 3 * RZ_QUEUE_WAYS * queue_capacity, st);           /* blinn, pbr, RZ_ORDERED_LIST */
     reserve(L.queue_counts, 3 * RZ_QUEUE_WAYS * RZ_QUEUE_PAD, st);
@@ -1959,7 +1959,7 @@ static void launch_batch(const Batch &b, const std::vector<PassPlan> &plans, cha
     size_t batch_tiles = 0;
     for (size_t i : b.members)
         batch_tiles += (size_t)((plans[i].fb->pub.width + RZ_TILE_W - 1) / RZ_TILE_W) * ((plans[i].fb->pub.height + RZ_TILE_H - 1) / RZ_TILE_H);
-    const uint32_t queue_capacity = (uint32_t)((2 * batch_tiles + RZ_QUEUE_WAYS - 1) / RZ_QUEUE_WAYS);
+    const uint32_t queue_capacity = (uint32_t)((2 * batch_tiles + RZ_QUEUE_WAYS - 1) / RZ_QUEUE_WAYS + b.members.size());
     const dim3 shade_grid((unsigned)std::min<size_t>(max_tiles_x * max_tiles_y * n, (size_t)g.shade_workgroups));
     {
         /* what the kernels below index without a check of their own: wrong sizes here must stop the host, not fault the GPU */

@@ -2141,11 +2141,14 @@ __global__ void __launch_bounds__(128) rz_strip_kernel(const PassParams *__restr
         if (__any(listed)) {
             /* the block holds blinn or pbr fragments: its references are written -- all of them, the
              * family's shade kernel looks at every pixel of a listed block -- and the block goes on the
-             * work list of each family it holds (parts chosen by the block's index in the batch, so
-             * that no part can get more than its even share) */
+             * work list of each family it holds (parts chosen by the block's index in its pass: a part
+             * gets at most its even share of every pass, rounded up) */
             for (int q = 0; q < PPL; q++) if (valid[q]) P.ref[pixel[q]] = ref_of[q];
             const uint32_t block_x = (uint32_t)bx0 / (8u * PPL), block_y = (uint32_t)by0 / 8u;
-            const uint32_t index = 2u * P.tile_off + block_y * 2u * (uint32_t)P.tiles_x + block_x;
+            /* the block's index in its own pass: a block of the screen is on the same part, and with it on the same
+             * XCD's share of the shade kernel's workgroups (workgroup b runs on XCD b mod 8 and takes parts 2b and
+             * 2b + 1 mod 64), in every pass of the batch -- the views of a batch fetch much the same texels for it */
+            const uint32_t index = block_y * 2u * (uint32_t)P.tiles_x + block_x;
             for (uint32_t f = 0; f < 2; f++) {
                 bool mine_f = false;
                 for (int q = 0; q < PPL; q++) mine_f |= ((ref_of[q] >> 28) & 3u) == f;
