@@ -320,6 +320,13 @@ void framebuffer_read_device_rgb(rz_framebuffer *framebuffer, void *color_rgb8_d
  * their way into the buffer a gather sends. */
 void framebuffers_read_device_rgb(rz_framebuffer *const *framebuffers, int count, void *color_rgb8_dev,
                                   size_t stride_bytes);
+/* The same in two halves.  _begin submits what is recorded, launches the copies behind the rendering and
+ * returns without waiting; _end waits for those copies only, not for what was submitted after _begin.  In
+ * between the caller may record and submit more -- also into the same framebuffers: later passes come after
+ * the copies -- but must leave the destination alone.  One set of frames at a time. */
+void framebuffers_read_device_rgb_begin(rz_framebuffer *const *framebuffers, int count, void *color_rgb8_dev,
+                                        size_t stride_bytes);
+void framebuffers_read_device_rgb_end(void);
 
 /* Explicit family registration for hosts whose shader functions are not
  * visible as dynamic symbols. */

@@ -97,6 +97,8 @@ class Pipeline:
             lib.framebuffer_read_device.argtypes = [FB, P, P]
             lib.framebuffer_read_device_rgb.argtypes = [FB, P]
             lib.framebuffers_read_device_rgb.argtypes = [C.POINTER(FB), C.c_int, P, C.c_size_t]
+            lib.framebuffers_read_device_rgb_begin.argtypes = [C.POINTER(FB), C.c_int, P, C.c_size_t]
+            lib.framebuffers_read_device_rgb_end.argtypes = []
             lib.mi355r_get_counters.argtypes = [C.POINTER(C.c_ulonglong)]
             lib.mi355r_enable_counters.argtypes = [C.c_int]
             lib.mi355r_stream.restype = P

@@ -448,8 +448,11 @@ extern "C" rz_framebuffer *framebuffer_create(int width, int height) {
     return &fb->pub;
 }
 
+extern "C" void framebuffers_read_device_rgb_end(void);
+
 extern "C" void framebuffer_release(rz_framebuffer *p) {
     Fb *fb = as_fb(p);
+    framebuffers_read_device_rgb_end();
     graphics_flush();
     sync_stream();
     HIP_OK(hipFree(fb->d_color));
@@ -2147,6 +2150,18 @@ static void run_again(FlushRecord &fr) {
 
 /* Looks at the control blocks of the flushes in flight -- waiting for their lanes unless the caller
  * knows them idle -- and runs again what did not run. */
+/* framebuffers_read_device_rgb_begin .. _end: the copies of a set of frames that the host has not waited for yet */
+struct FramesRead {
+    bool active = false;
+    std::vector<Fb*> fbs;
+    char *rgb = nullptr;
+    size_t stride = 0;
+    hipEvent_t done[MAX_LANES];
+    bool used[MAX_LANES] = {false};
+};
+static FramesRead g_frames_read;
+static void launch_frames_read();
+
 static bool settle_in_flight(bool lanes_idle) {
     bool ran_again = false;
     while (!g_in_flight.empty()) {
@@ -2171,6 +2186,8 @@ static bool settle_in_flight(bool lanes_idle) {
             ran_again = true;
         }
     }
+    /* frames that were copied out behind passes which had not run: copied again behind the passes' second run */
+    if (ran_again && g_frames_read.active) launch_frames_read();
     return ran_again;
 }
 
@@ -2216,6 +2233,68 @@ extern "C" void framebuffers_read_device_rgb(rz_framebuffer *const *fps, int cou
         if (!left_out) return;
         settle_in_flight(false);
     }
+}
+
+/* The same in two halves, for a caller that has something to do while the frames are rendered and copied (a
+ * render loop that records its next step): _begin submits what is recorded and launches the copies behind the
+ * rendering, each on its framebuffer's lane, and returns; _end waits for those copies -- not for what was
+ * submitted after them.  Later passes into the same framebuffers come after the copies in stream order.  Passes
+ * that turn out not to have run are run again when the flush is settled (at the latest before the next flush's
+ * first launch), and the copies are launched again behind them (settle_in_flight).  One set at a time. */
+static void launch_frames_read() {
+    FramesRead &r = g_frames_read;
+    for (int l = 0; l < MAX_LANES; l++) if (r.used[l]) { HIP_OK(hipEventDestroy(r.done[l])); r.used[l] = false; }
+    for (size_t i = 0; i < r.fbs.size(); i++) {
+        Fb *fb = r.fbs[i];
+        apply_pending_clear(fb);
+        const size_t n = (size_t)fb->pub.width * fb->pub.height;
+        const int lane = fb->lane < 0 ? 0 : fb->lane;
+        rz_strip_alpha_kernel<<<dim3((unsigned)((n / 4 + 1 + 255) / 256)), dim3(256), 0, g.lanes[lane].stream>>>(
+            fb->d_color, (uint32_t*)(r.rgb + i * r.stride), n);
+        HIP_OK(hipGetLastError());
+        r.used[lane] = true;
+    }
+    for (int l = 0; l < MAX_LANES; l++)
+        if (r.used[l]) {
+            HIP_OK(hipEventCreateWithFlags(&r.done[l], hipEventDisableTiming));
+            HIP_OK(hipEventRecord(r.done[l], g.lanes[l].stream));
+        }
+}
+
+extern "C" void framebuffers_read_device_rgb_begin(rz_framebuffer *const *fps, int count, void *rgb, size_t stride_bytes) {
+    FramesRead &r = g_frames_read;
+    if (r.active) fatal("framebuffers_read_device_rgb_begin: the set before has not been waited for (framebuffers_read_device_rgb_end)");
+    if (count <= 0) return;
+    if (!rgb || ((uintptr_t)rgb & 3u) || (stride_bytes & 3u))
+        fatal("framebuffers_read_device_rgb_begin: destination and stride must be 4-byte aligned (%p, %zu)", rgb, stride_bytes);
+    r.fbs.assign((size_t)count, nullptr);
+    for (int i = 0; i < count; i++) {
+        r.fbs[i] = as_fb(fps[i]);
+        if ((size_t)r.fbs[i]->pub.width * r.fbs[i]->pub.height * 3 > stride_bytes) fatal("framebuffers_read_device_rgb_begin: frame %d is larger than the stride", i);
+    }
+    r.rgb = (char*)rgb;
+    r.stride = stride_bytes;
+    graphics_flush();
+    r.active = true;
+    launch_frames_read();
+}
+
+extern "C" void framebuffers_read_device_rgb_end(void) {
+    FramesRead &r = g_frames_read;
+    if (!r.active) return;
+    for (int attempt = 0; attempt < 2; attempt++) {
+        for (int l = 0; l < MAX_LANES; l++) if (r.used[l]) HIP_OK(hipEventSynchronize(r.done[l]));
+        /* their flush may still be the one in flight (nothing was submitted since): look at its control blocks now */
+        bool left_out = false;
+        for (const FlushRecord &fr : g_in_flight)
+            for (size_t k = 0; k < fr.plans.size() && !left_out; k++)
+                if (fr.control(k)[2] != 0 && std::find(r.fbs.begin(), r.fbs.end(), fr.plans[k].fb) != r.fbs.end()) left_out = true;
+        if (!left_out) break;
+        settle_in_flight(false);            /* runs them again and launches the copies again */
+    }
+    for (int l = 0; l < MAX_LANES; l++) if (r.used[l]) { HIP_OK(hipEventDestroy(r.done[l])); r.used[l] = false; }
+    r.active = false;
+    r.fbs.clear();
 }
 
 /* ---- texture_sync without allocations ---------------------------------------

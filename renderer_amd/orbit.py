@@ -106,9 +106,14 @@ class FrameGather:
     """The gather as a pipeline of `depth` slots: a step's frames go into the next slot and their
     gather starts at once (async_op); the slot is only waited for when it comes round again, so
     the transfer of one step overlaps the rendering of the next.  Rank 0 ends up with
-    `received(slot)` = list over ranks of that step's frames.  world == 1: nothing is moved."""
+    `received(slot)` = list over ranks of that step's frames.  world == 1: nothing is moved.
 
-    def __init__(self, frames, height, width, device, rank, world, depth=2, root_frames=None, channels=4):
+    `lagged` (the default for RGB8 frames in device memory): the copy of a step's frames into the slot is only
+    launched by `submit` (framebuffers_read_device_rgb_begin: behind the rendering, no wait), and waited for
+    -- and the slot's gather started -- by the NEXT `submit` or by `drain`.  The host then records the next
+    step while the GPU still renders and copies this one, instead of waiting for the copies first."""
+
+    def __init__(self, frames, height, width, device, rank, world, depth=2, root_frames=None, channels=4, lagged=None):
         """frames: slot size of the collective (the largest block a rank sends).  root_frames: the
         gather-aware split (shard_views_rooted) -- rank 0's block has that many frames and does not
         go through the collective: rank 0 copies it into a buffer of its own per slot (`own(slot)`),
@@ -117,6 +122,8 @@ class FrameGather:
         self.rank, self.world, self.depth, self.count = rank, world, depth, 0
         self.rooted = root_frames is not None
         self.on_device = torch.device(device).type == "cuda"
+        self.lagged = (self.on_device and channels == 3) if lagged is None else lagged
+        self.pending = None             # (pipe, slot): copies launched, gather not started yet
         self.slots = self.inbox = self.work = self.kept = None
         if world > 1:
             shape = (frames, height, width, channels)
@@ -135,20 +142,43 @@ class FrameGather:
                 torch.cuda.current_stream().synchronize()   # wait() only orders streams; the slot is reused by other streams
             self.work[slot] = None
 
-    def submit(self, pipe, framebuffers, count):
-        """Copies `count` finished frames into the next slot and starts gathering it."""
+    def _start(self, slot):
         import torch.distributed as dist
+        self.work[slot] = dist.gather(self.slots[slot], self.inbox[slot], dst=0, async_op=True)
+
+    def _start_pending(self):
+        """The step whose copies `submit` launched last: wait for them, then start its gather."""
+        if self.pending is not None:
+            pipe, slot = self.pending
+            self.pending = None
+            pipe.lib.framebuffers_read_device_rgb_end()
+            self._start(slot)
+
+    def submit(self, pipe, framebuffers, count):
+        """Copies `count` finished frames into the next slot and starts gathering it (lagged: launches the
+        copies, and starts gathering the step before)."""
         if self.world == 1:
             return
         slot = self.count % self.depth
         self._finish(slot)
-        # (frames_to_tensor returns when the copies are complete)
-        frames_to_tensor(pipe, framebuffers, count, self.kept[slot] if self.rooted and self.rank == 0 else self.slots[slot])
-        self.work[slot] = dist.gather(self.slots[slot], self.inbox[slot], dst=0, async_op=True)
+        target = self.kept[slot] if self.rooted and self.rank == 0 else self.slots[slot]
+        if self.lagged:
+            self._start_pending()
+            if count > 0:
+                handles = (type(framebuffers[0]) * count)(*framebuffers[:count])
+                pipe.lib.framebuffers_read_device_rgb_begin(handles, count, C.c_void_p(target.data_ptr()), target[0].numel())
+            else:
+                pipe.lib.graphics_flush()
+            self.pending = (pipe, slot)
+        else:
+            # (frames_to_tensor returns when the copies are complete)
+            frames_to_tensor(pipe, framebuffers, count, target)
+            self._start(slot)
         self.count += 1
 
     def drain(self):
         if self.world > 1:
+            self._start_pending()
             for slot in range(self.depth):
                 self._finish(slot)
 

@@ -242,3 +242,67 @@ def test_thousands_of_small_flushes_without_a_full_synchronisation(gpu, oracle):
     for view, got in last.values():
         assert_same(got, oracle.render(scene, size[0], size[1], oracle.orbit_view(view, 16)), size[0] * size[1])
     oracle.close_scene(scene)
+
+
+@pytest.mark.parametrize("tiny", [False, True], ids=["ordinary", "scratch-too-small"])
+def test_frames_copied_out_in_two_halves(gpu, tiny):
+    """framebuffers_read_device_rgb_begin / _end: the copies of a step's frames are launched behind the rendering
+    and waited for later; in between the next step is recorded and submitted into the SAME framebuffers.  What
+    arrives is the first step's frames, the framebuffers end up with the second's.  With scratch estimates that
+    are always too small the first step's passes do not run when submitted: they run again when the flush is
+    settled (before the next one's first launch), and the copies are launched again behind them."""
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    hip.hipMemset.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    hip.hipFree.argtypes = [C.c_void_p]
+    w, h, count = 320, 180, 6
+    stride = w * h * 3
+    scene = gpu.open_scene("helmet")
+    fbs = [gpu.framebuffer(w, h) for _ in range(count)]
+    handles = (type(fbs[0]) * count)(*fbs)
+    first = [gpu.orbit_view(i, 16) for i in range(count)]
+    second = [gpu.orbit_view(i + 8, 16) for i in range(count)]
+    want = []
+    for views in (first, second):
+        for fb, v in zip(fbs, views):
+            gpu.draw(scene, fb, v)
+        want.append([gpu.read(fb)[0][..., :3].copy() for fb in fbs])
+    assert any(not np.array_equal(a, b) for a, b in zip(*want))
+    dev = C.c_void_p()
+    assert hip.hipMalloc(C.byref(dev), stride * count) == 0 and hip.hipMemset(dev, 5, stride * count) == 0
+    if tiny:
+        gpu.lib.mi355r_set_scratch_estimate(2, 48)
+    try:
+        before = gpu.lib.mi355r_passes_run_again()
+        for rounds in range(2):                         # twice: the second set begins while nothing else is in flight
+            for fb, v in zip(fbs, first):
+                gpu.draw(scene, fb, v)
+            gpu.lib.framebuffers_read_device_rgb_begin(handles, count, dev, stride)
+            for fb, v in zip(fbs, second):
+                gpu.draw(scene, fb, v)
+            gpu.lib.graphics_flush()
+            gpu.lib.framebuffers_read_device_rgb_end()
+            got = np.zeros(stride * count, np.uint8)
+            assert hip.hipMemcpy(got.ctypes.data_as(C.c_void_p), dev, stride * count, 2) == 0
+            got = got.reshape(count, h, w, 3)
+            for i, fb in enumerate(fbs):
+                assert np.array_equal(got[i], want[0][i]), (rounds, i)
+                assert np.array_equal(gpu.read(fb)[0][..., :3], want[1][i]), (rounds, i)
+            assert hip.hipMemset(dev, 5, stride * count) == 0
+        # begin and end with nothing submitted in between
+        for fb, v in zip(fbs, first):
+            gpu.draw(scene, fb, v)
+        gpu.lib.framebuffers_read_device_rgb_begin(handles, count, dev, stride)
+        gpu.lib.framebuffers_read_device_rgb_end()
+        got = np.zeros(stride * count, np.uint8)
+        assert hip.hipMemcpy(got.ctypes.data_as(C.c_void_p), dev, stride * count, 2) == 0
+        assert all(np.array_equal(got.reshape(count, h, w, 3)[i], want[0][i]) for i in range(count))
+        if tiny:
+            assert gpu.lib.mi355r_passes_run_again() > before
+    finally:
+        gpu.lib.mi355r_set_scratch_estimate(0, 0)
+        hip.hipFree(dev)
+        for fb in fbs:
+            gpu.release(fb)
+        gpu.close_scene(scene)

@@ -58,16 +58,19 @@ def test_gather_aware_split_arithmetic():
                 assert abs(root * 1.0 - p * ratio) <= max(1.0, ratio) * world
 
 
-@pytest.mark.parametrize("world,total,scene,peer,channels", [(2, 5, "helmet", None, 4), (2, 4, "helmet", None, 3), (2, 6, "buster", None, 4),
-                                                             (2, 6, "helmet", 2, 4), (3, 7, "helmet", 1, 3), (4, 11, "helmet", 2, 3),
-                                                             (4, 9, "buster", None, 3)],
+@pytest.mark.parametrize("world,total,scene,peer,channels,mode", [(2, 5, "helmet", None, 4, "-"), (2, 4, "helmet", None, 3, "-"), (2, 6, "buster", None, 4, "-"),
+                                                                  (2, 6, "helmet", 2, 4, "-"), (3, 7, "helmet", 1, 3, "-"), (4, 11, "helmet", 2, 3, "-"),
+                                                                  (4, 9, "buster", None, 3, "-"), (2, 6, "helmet", 2, 3, "lagged"),
+                                                                  (4, 11, "helmet", 2, 3, "lagged"), (3, 7, "helmet", None, 3, "lagged")],
                          ids=["helmet-5", "helmet-4-rgb", "buster-animated-6", "helmet-6-rooted-2", "helmet-7-of-3-rooted-1-rgb",
-                              "helmet-11-of-4-rooted-2-rgb", "buster-9-of-4-rgb"])
-def test_gloo_orbit_gather(oracle, world, total, scene, peer, channels):
+                              "helmet-11-of-4-rooted-2-rgb", "buster-9-of-4-rgb", "helmet-6-rooted-2-rgb-lagged",
+                              "helmet-11-of-4-rooted-2-rgb-lagged", "helmet-7-of-3-rgb-lagged"])
+def test_gloo_orbit_gather(oracle, world, total, scene, peer, channels, mode):
     """helmet: the benchmark's scene; buster: the animated scene of the batch-render configuration
     (every view has its own frame time, so every rank evaluates its own poses).  rooted: the
     gather-aware split bench.py uses for N > 1 (peers render `peer` views each, rank 0 the rest and
-    keeps its own outside the collective)."""
+    keeps its own outside the collective).  lagged: the copy-out in two halves as bench.py uses it with frames in device
+    memory (a step's copies are launched by its submit and waited for, and its gather started, by the next)."""
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
@@ -76,7 +79,7 @@ def test_gloo_orbit_gather(oracle, world, total, scene, peer, channels):
     for rank in range(world):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="1")
-        procs.append(subprocess.Popen([sys.executable, os.path.join(REPO, "tests", "orbit_worker.py"), str(total), "96", "54", scene, str(peer) if peer is not None else "-", str(channels)],
+        procs.append(subprocess.Popen([sys.executable, os.path.join(REPO, "tests", "orbit_worker.py"), str(total), "96", "54", scene, str(peer) if peer is not None else "-", str(channels), mode],
                                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     outs = []
     for p in procs:
