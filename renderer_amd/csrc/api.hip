@@ -1761,6 +1761,7 @@ struct FlushRecord {
     /* poses evaluated on the device for this flush: jobs (PoseJob[]) and attach jobs (AttachJob[]) in the region */
     size_t pose_jobs_at = 0, pose_jobs = 0, attach_jobs_at = 0, attach_jobs = 0;
     bool used[MAX_LANES] = {false};
+    unsigned long long epoch = 0;                           /* Context::flush_epoch when it was submitted */
     const uint32_t *control(size_t plan) const { return (const uint32_t*)(g.ring_host + at + CONTROL_BYTES * plans[plan].slot); }
     uint32_t *control_dev(size_t plan) const { return (uint32_t*)(g.ring_dev + at + CONTROL_BYTES * plans[plan].slot); }
 };
@@ -2158,12 +2159,13 @@ struct FramesRead {
     size_t stride = 0;
     hipEvent_t done[MAX_LANES];
     bool used[MAX_LANES] = {false};
+    unsigned long long before_epoch = 0;        /* flushes submitted before the copies: those with a smaller epoch */
 };
 static FramesRead g_frames_read;
 static void launch_frames_read();
 
 static bool settle_in_flight(bool lanes_idle) {
-    bool ran_again = false;
+    bool ran_again = false, ran_again_before_read = false;
     while (!g_in_flight.empty()) {
         FlushRecord fr = std::move(g_in_flight.back());
         g_in_flight.pop_back();
@@ -2184,10 +2186,12 @@ static bool settle_in_flight(bool lanes_idle) {
             }
             run_again(fr);
             ran_again = true;
+            if (g_frames_read.active && fr.epoch < g_frames_read.before_epoch) ran_again_before_read = true;
         }
     }
-    /* frames that were copied out behind passes which had not run: copied again behind the passes' second run */
-    if (ran_again && g_frames_read.active) launch_frames_read();
+    /* frames that were copied out behind passes which had not run: copied again behind the passes' second run
+     * (a flush is settled before the next one's first launch, so nothing later has touched the framebuffers yet) */
+    if (ran_again_before_read) launch_frames_read();
     return ran_again;
 }
 
@@ -2275,6 +2279,7 @@ extern "C" void framebuffers_read_device_rgb_begin(rz_framebuffer *const *fps, i
     r.rgb = (char*)rgb;
     r.stride = stride_bytes;
     graphics_flush();
+    r.before_epoch = g.flush_epoch;
     r.active = true;
     launch_frames_read();
 }
@@ -2287,7 +2292,7 @@ extern "C" void framebuffers_read_device_rgb_end(void) {
         /* their flush may still be the one in flight (nothing was submitted since): look at its control blocks now */
         bool left_out = false;
         for (const FlushRecord &fr : g_in_flight)
-            for (size_t k = 0; k < fr.plans.size() && !left_out; k++)
+            for (size_t k = 0; fr.epoch < r.before_epoch && k < fr.plans.size() && !left_out; k++)
                 if (fr.control(k)[2] != 0 && std::find(r.fbs.begin(), r.fbs.end(), fr.plans[k].fb) != r.fbs.end()) left_out = true;
         if (!left_out) break;
         settle_in_flight(false);            /* runs them again and launches the copies again */
@@ -2449,6 +2454,7 @@ extern "C" void graphics_flush(void) {
     prof.start();
     if (g.events.size() > 4096) sync_stream();          /* bound the number of live events; no event of this flush exists yet */
     FlushRecord fr;
+    fr.epoch = g.flush_epoch;
     std::vector<PassPlan> &plans = fr.plans;
     size_t n = g.pending.size(), first = 0;
     while (first < n) {
