@@ -308,6 +308,22 @@ def main():
                 if config[0].startswith(("C2", "C3")):
                     r = time_config(gpu, config, steps=2, warmup=1, frames=32, per_triangle=True)
                     others[config[0].split()[0] + "_per_triangle"] = r
+            # ... and the reference's OWN host (its scene factories, draw_model loops and frame driver, compiled from its
+            # sources in the build container, linked against the library: oracle/Makefile, target refhost) as a child
+            # process, when that binary travelled with the tree: frames per second of its frame loop at 1920x1080
+            host = os.path.join(REPO, "oracle", "_ref", "refhost_mi355r")
+            if os.path.exists(host):
+                import subprocess
+                for label, scene_name in (("C2_reference_host", "pbr:helmet"), ("C3_reference_host", "blinn:kgirl")):
+                    try:
+                        out = subprocess.run([host, "--scene", scene_name, "--assets", os.path.join(REPO, "assets"), "--size", str(WIDTH), str(HEIGHT),
+                                              "--bench", "100"], capture_output=True, text=True, timeout=120, check=True).stdout
+                        r = json.loads(out.strip().splitlines()[-1])
+                        others[label] = {"workload": f"{scene_name} {WIDTH}x{HEIGHT}, one frame after the other into one framebuffer", "fps": 1e3 / r["median_ms"],
+                                         "ms_per_step": r["median_ms"], "frames_per_step": 1, "steps": r["frames"],
+                                         "submission": "the reference's own host: per face (graphics_draw_triangle), median frame time of its loop"}
+                    except Exception as e:      # the figure is an extra: the bench line does not depend on it
+                        others[label] = {"error": str(e)[:200]}
             result["other_configs"] = others
         if world == 1 and not args.no_cpu:
             result["cpu_baseline"] = cpu_baseline(48)
