@@ -22,6 +22,14 @@
 #include <type_traits>
 #include "shade.h"
 
+/* Timing experiments leave parts of the rasterisers out (PassParams::debug_skip, MI355R_DEBUG_SKIP).  The
+ * switch exists only in builds made for that (-DRZ_MEASURE): the library's kernels do not test it. */
+#ifdef RZ_MEASURE
+#define RZ_SKIP(P) ((P).debug_skip)
+#else
+#define RZ_SKIP(P) 0
+#endif
+
 /* largest d with first_tri[d] <= t */
 RZ_DEV int find_draw(const uint32_t *first_tri, int num_draws, uint32_t t) {
     int lo = 0, hi = num_draws - 1;
@@ -1193,7 +1201,7 @@ RZ_DEV void raster_tile(const PassParams &P, const uint32_t pass_index, const ui
     const DrawRec *draw_table = (const DrawRec*)(upload_base + P.draws_off);
     const uint2 *bin_range_table = bin_range_base + P.bin_off;
     /* A workgroup owns a 32x8-pixel tile, wave w its w-th 8x8 block, lane = pixel. */
-    if (P.debug_skip == 3) return;
+    if (RZ_SKIP(P) == 3) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int tx0 = (int)tile_x * RZ_TILE_W, ty0 = (int)tile_y * RZ_TILE_H;
     const int bx0 = tx0 + wave * 8, by0 = ty0;
@@ -1251,7 +1259,7 @@ RZ_DEV void raster_tile(const PassParams &P, const uint32_t pass_index, const ui
                     r = e->rec;
                     have = true;
                 } else {
-                    if (base >= count || P.debug_skip == 4) { exhausted = true; break; }
+                    if (base >= count || RZ_SKIP(P) == 4) { exhausted = true; break; }
                     const float4 c0 = n0, c1 = n1;
                     const float2 cbox = nbox;
                     const bool present = base + lane < count;
@@ -1269,7 +1277,7 @@ RZ_DEV void raster_tile(const PassParams &P, const uint32_t pass_index, const ui
                     continue;
                 }
             }
-            if (P.debug_skip >= 2) { have = false; continue; }
+            if (RZ_SKIP(P) >= 2) { have = false; continue; }
             /* the triangle in r against this block */
             int x0 = (int)(r.bx & 0xffffu), x1 = (int)(r.bx >> 16);
             int y0 = (int)(r.by & 0xffffu), y1 = (int)(r.by >> 16);
@@ -1319,7 +1327,7 @@ RZ_DEV void raster_tile(const PassParams &P, const uint32_t pass_index, const ui
 
         /* ---- phase B: resolve the stacks, bottom level first */
         for (int level = 0; level < 2; level++) {
-            bool want = depth_of_stack > level && P.debug_skip == 0;
+            bool want = depth_of_stack > level && RZ_SKIP(P) == 0;
             if (!__any(want)) break;
             TriRec m;
             const float *m0 = vary_table, *m1 = vary_table, *m2 = vary_table;
@@ -1442,7 +1450,7 @@ __global__ void __launch_bounds__(256 / PPL) rz_visibility_kernel(const PassPara
     const TileOrder o = tile_order(num_passes, RZ_BIN / RZ_TILE_H);
     const PassParams P = passes[o.pass];
     if ((int)o.column >= P.tiles_x || (int)o.row >= P.tiles_y) return;
-    if (P.debug_skip == 3) return;
+    if (RZ_SKIP(P) == 3) return;
     if (P.control[2] != 0u) return;                             /* out of scratch, or left out: the pass is run again later */
     const BinEntry *list_table = list_base + P.list_off;
     const float *vary_table = vary_base + (size_t)P.tri_off * 3 * RZ_VARY_STRIDE;
@@ -1575,7 +1583,7 @@ __global__ void __launch_bounds__(256 / PPL) rz_visibility_kernel(const PassPara
     /* block corners at pixel centres, for the conservative triangle/block test */
     const float cx0 = (float)bx0 + 0.5f, cx1 = (float)bx1 + 0.5f, cy0 = (float)by0 + 0.5f, cy1 = (float)by0 + 7.5f;
 
-    for (uint32_t base = 0; base < count && P.debug_skip != 4;) {
+    for (uint32_t base = 0; base < count && RZ_SKIP(P) != 4;) {
         const uint2 cbox = nbox;
         float4 c0 = n0, c1 = n1;
         const bool present = base + lane < count;
@@ -1625,7 +1633,7 @@ __global__ void __launch_bounds__(256 / PPL) rz_visibility_kernel(const PassPara
             todo &= todo - 1;
             const uint32_t ref = e->tri;
             const TriRec r = e->rec;
-            if (P.debug_skip >= 2) continue;
+            if (RZ_SKIP(P) >= 2) continue;
             const int x0 = (int)(r.bx & 0xffffu), x1 = (int)(r.bx >> 16);
             const int y0 = (int)(r.by & 0xffffu), y1 = (int)(r.by >> 16);
             const bool row_in = py >= y0 && py <= y1;
@@ -1765,7 +1773,7 @@ struct SkyBin {
     uint32_t pad[5];
 };
 RZ_DEV bool sky_only_bin(const PassParams &P, const BinEntry *list, uint32_t count) {
-    if (count == 0u || count > RZ_SKY_ONLY_MAX || P.counters || P.debug_skip) return false;
+    if (count == 0u || count > RZ_SKY_ONLY_MAX || P.counters || RZ_SKIP(P)) return false;
     const uint32_t first = list[0].rec.meta, last = list[count - 1u].rec.meta;
     return RZ_META_FAMILY(first) == 2u && RZ_META_FAMILY(last) == 2u && RZ_META_DRAW(first) == RZ_META_DRAW(last);
 }
@@ -2182,7 +2190,7 @@ RZ_DEV void shade_pixel(const PassParams &P, const TriRec *__restrict__ tri_base
     const bool valid = px < P.width && py < P.height;
     const uint32_t pixel = (uint32_t)py * (uint32_t)P.width + (uint32_t)px;
     uint32_t myref = valid ? ref_table[pixel] : RZ_REF_NONE;
-    if (P.debug_skip) myref = RZ_REF_NONE;
+    if (RZ_SKIP(P)) myref = RZ_REF_NONE;
     /* the rasteriser tagged the reference with the fragment's family (RZ_REF_NONE reads as family 3) */
     const bool want = ((myref >> 28) & 3u) == (uint32_t)FAMILY;
     if (!__any(want)) return;
@@ -2398,7 +2406,7 @@ __global__ void __launch_bounds__(256 / PPL) rz_sky_kernel(const PassParams *__r
         }
     }
     for (int q = 0; q < PPL; q++)
-        myref[q] = (px < P.width && py[q] < P.height && !P.debug_skip) ? ref_table[pixel[q]] : RZ_REF_NONE;
+        myref[q] = (px < P.width && py[q] < P.height && !RZ_SKIP(P)) ? ref_table[pixel[q]] : RZ_REF_NONE;
     for (int q = 0; q < PPL; q++) {
         want[q] = ((myref[q] >> 28) & 3u) == 2u;        /* RZ_REF_NONE reads as family 3 */
         any_want |= want[q];

@@ -202,7 +202,7 @@ struct PassParams {
      * used, [2] error bits, [3] triangles queued for clipping */
     rz_gptr<uint32_t> control;
     rz_gptr<unsigned long long> counters;   /* nullptr unless counting is enabled */
-    int32_t debug_skip;             /* measurement only (MI355R_DEBUG_SKIP): 1 no shading, 2 no coverage tests either,
+    int32_t debug_skip;             /* measurement only (MI355R_DEBUG_SKIP, read by builds with -DRZ_MEASURE; otherwise ignored): 1 no shading, 2 no coverage tests either,
                                      * 3 no rasteriser at all, 4 the rasteriser without its walk over the bin lists */
     int32_t micro_area;             /* triangles whose box covers at most this many pixels of a wave's block
                                      * are rasterised one per lane; 0 = none */
