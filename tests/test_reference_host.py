@@ -61,3 +61,30 @@ def test_reference_host_on_the_c_abi_reproduces_goldens(refhost, name):
     want_color, want_depth = load_golden(name)
     assert np.array_equal(depth, want_depth)
     assert np.array_equal(color, want_color)
+
+
+@pytest.mark.parametrize("seed,size", [(1, (97, 61)), (2, (160, 90)), (3, (33, 200))])
+def test_random_overlays_equal_the_unmodified_reference(oracle, seed, size):
+    """draw2d.c of the UNMODIFIED reference (oracle/_ref/refdump) against the restatement in oracle/pipeline.c on
+    random points, lines, outlines and labels over a rendered frame (60 per case, ragged frame sizes, points
+    outside [0,1]^2): pins the overlay restatement beyond the one golden frame."""
+    sys.path.insert(0, os.path.join(REPO, "oracle"))
+    from make_goldens import run_case, REFDUMP
+    if not os.path.exists(REFDUMP):
+        subprocess.run(["make", "-C", os.path.join(REPO, "oracle"), "ref"], check=True, capture_output=True)
+    rng = np.random.default_rng(seed)
+    f32 = lambda xs: [float(np.float32(x)) for x in xs]
+    ops = []
+    for i in range(60):
+        kind = ("point", "line", "outline", "label")[int(rng.integers(4))]
+        if kind == "label":
+            ops.append(["label", "common/%s.tga" % ("diffuse", "specular", "roughness", "occlusion", "normal")[int(rng.integers(5))],
+                        *f32(rng.uniform(-0.1, 1.1, 2))])
+        else:
+            ops.append([kind, *f32(rng.uniform(0, 1, 4)), *f32(rng.uniform(-0.2, 1.2, {"point": 2, "line": 4, "outline": 6}[kind]))])
+    case = {"name": "overlays", "scene": "helmet", "ref": "pbr:helmet", "size": list(size), "overlay": ops}
+    want_color, want_depth = run_case(case, os.path.join(REPO, "assets"))
+    from conftest import render_case
+    color, depth = render_case(oracle, case)
+    assert np.array_equal(depth, want_depth)
+    assert np.array_equal(color, want_color)
