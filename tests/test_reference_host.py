@@ -88,3 +88,29 @@ def test_random_overlays_equal_the_unmodified_reference(oracle, seed, size):
     color, depth = render_case(oracle, case)
     assert np.array_equal(depth, want_depth)
     assert np.array_equal(color, want_color)
+
+
+@pytest.mark.parametrize("seed", [11, 12, 13, 14, 15, 16, 17, 18])
+def test_random_views_equal_the_unmodified_reference(oracle, seed):
+    """The restatement against the unmodified reference (oracle/_ref/refdump) beyond the golden cameras: a random
+    scene, frame size, eye (also inside the model and next to the sky box), target and animation time per
+    case; colour and depth bit for bit."""
+    sys.path.insert(0, os.path.join(REPO, "oracle"))
+    from make_goldens import run_case
+    from conftest import render_case
+    rng = np.random.default_rng(seed)
+    scenes = [("helmet", "pbr:helmet"), ("kgirl", "blinn:kgirl"), ("buster", "pbr:buster"), ("azura", "blinn:azura"),
+              ("craftsman", "blinn:craftsman"), ("drone", "pbr:drone"), ("dieselpunk", "pbr:dieselpunk"), ("phoenix", "blinn:phoenix")]
+    scene, ref = scenes[seed % len(scenes)]
+    direction = rng.normal(size=3)
+    direction /= np.linalg.norm(direction)
+    radius = float(rng.choice([0.08, 0.4, 1.2, 2.5]))
+    case = {"name": "random", "scene": scene, "ref": ref,
+            "size": [int(rng.integers(40, 150)), int(rng.integers(30, 100))],
+            "eye": [float(np.float32(x)) for x in direction * radius],
+            "target": [float(np.float32(x)) for x in rng.uniform(-0.2, 0.2, 3)],
+            "time": float(np.float32(rng.uniform(0, 3)))}
+    want_color, want_depth = run_case(case, os.path.join(REPO, "assets"))
+    color, depth = render_case(oracle, case)
+    assert np.array_equal(depth, want_depth), case
+    assert np.array_equal(color, want_color), case
