@@ -142,6 +142,26 @@ static int cmp_double(const void *a, const void *b) {
     return x < y ? -1 : (x > y ? 1 : 0);
 }
 
+/* --poses file.ani joints count out: the reference's own pose evaluation (core/skeleton.h:13-15) at the times
+ * i * 0.137f, i < count; per time `joints` 4x4 joint matrices, then `joints` 3x3 normal matrices, as floats */
+static int dump_poses(const char *assets, const char *ani, int joints, int count, const char *out) {
+    skeleton_t *skeleton;
+    FILE *f;
+    int i;
+    if (chdir(assets) != 0) { perror("chdir assets"); return 2; }
+    skeleton = skeleton_load(ani);
+    f = fopen(out, "wb");
+    if (!f) { perror(out); return 2; }
+    for (i = 0; i < count; i++) {
+        skeleton_update_joints(skeleton, (float)i * 0.137f);
+        fwrite(skeleton_get_joint_matrices(skeleton), sizeof(mat4_t), (size_t)joints, f);
+        fwrite(skeleton_get_normal_matrices(skeleton), sizeof(mat3_t), (size_t)joints, f);
+    }
+    fclose(f);
+    skeleton_release(skeleton);
+    return 0;
+}
+
 int main(int argc, char **argv) {
     const char *assets = "/root/reference/assets";
     const char *scene_name = NULL, *scn_file = NULL, *out = NULL;
@@ -155,6 +175,9 @@ int main(int argc, char **argv) {
     context_t context;
     perframe_t perframe;
 
+    for (i = 1; i + 1 < argc; i++) if (!strcmp(argv[i], "--assets")) assets = argv[i + 1];
+    for (i = 1; i + 4 < argc; i++)
+        if (!strcmp(argv[i], "--poses")) return dump_poses(assets, argv[i + 1], atoi(argv[i + 2]), atoi(argv[i + 3]), argv[i + 4]);
     for (i = 1; i < argc; i++) {
         if (!strcmp(argv[i], "--scene") && i + 1 < argc) scene_name = argv[++i];
         else if (!strcmp(argv[i], "--scn") && i + 1 < argc) scn_file = argv[++i];

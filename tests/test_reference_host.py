@@ -114,3 +114,27 @@ def test_random_views_equal_the_unmodified_reference(oracle, seed):
     color, depth = render_case(oracle, case)
     assert np.array_equal(depth, want_depth), case
     assert np.array_equal(color, want_color), case
+
+
+@pytest.mark.parametrize("ani", ["kgirl/kgirl.ani", "buster/buster.ani", "drone/drone.ani", "drone/fire.ani", "phoenix/phoenix.ani"])
+def test_poses_equal_the_unmodified_reference(oracle, ani, tmp_path):
+    """skeleton_update_joints of the UNMODIFIED reference (core/skeleton.c:231-341, through oracle/_ref/refdump
+    --poses) against the restated evaluation (oracle/pose.c) and the scene layer's (host/assets.c): joint and
+    normal matrices of every joint at 220 times (i * 0.137, past the animations' ends where time wraps), bit
+    for bit -- the matrices themselves, not frames rendered with them."""
+    sys.path.insert(0, os.path.join(REPO, "oracle"))
+    from make_goldens import REFDUMP
+    subprocess.run(["make", "-C", os.path.join(REPO, "oracle"), "ref"], check=True, capture_output=True)
+    count = 220
+    times = (np.arange(count, dtype=np.float32) * np.float32(0.137)).astype(np.float32)
+    restated = oracle.poses(ani, times)
+    host = oracle.poses(ani, times, on_host=True)
+    J = restated[0].shape[1]
+    out = str(tmp_path / "poses.bin")
+    subprocess.run([REFDUMP, "--assets", os.path.join(REPO, "assets"), "--poses", ani, str(J), str(count), out], check=True, timeout=120)
+    raw = np.fromfile(out, np.float32).reshape(count, J * 25)
+    want_joints = raw[:, :J * 16].reshape(count, J, 4, 4)
+    want_normals = raw[:, J * 16:].reshape(count, J, 3, 3)
+    for got in (restated, host):
+        assert np.array_equal(got[0].view(np.uint32), want_joints.view(np.uint32))
+        assert np.array_equal(got[1].view(np.uint32), want_normals.view(np.uint32))
