@@ -162,6 +162,24 @@ static int dump_poses(const char *assets, const char *ani, int joints, int count
     return 0;
 }
 
+/* --texture file usage out: the reference's own image loading and usage conversion (core/texture.c:32-128,
+ * core/image.c) -- width, height, then the float RGBA texels of texture->buffer */
+static int dump_texture(const char *assets, const char *file, int usage, const char *out) {
+    texture_t *texture;
+    FILE *f;
+    int size[2];
+    if (chdir(assets) != 0) { perror("chdir assets"); return 2; }
+    texture = texture_from_file(file, (usage_t)usage);
+    f = fopen(out, "wb");
+    if (!f) { perror(out); return 2; }
+    size[0] = texture->width; size[1] = texture->height;
+    fwrite(size, sizeof(int), 2, f);
+    fwrite(texture->buffer, sizeof(vec4_t), (size_t)texture->width * texture->height, f);
+    fclose(f);
+    texture_release(texture);
+    return 0;
+}
+
 int main(int argc, char **argv) {
     const char *assets = "/root/reference/assets";
     const char *scene_name = NULL, *scn_file = NULL, *out = NULL;
@@ -176,6 +194,8 @@ int main(int argc, char **argv) {
     perframe_t perframe;
 
     for (i = 1; i + 1 < argc; i++) if (!strcmp(argv[i], "--assets")) assets = argv[i + 1];
+    for (i = 1; i + 3 < argc; i++)
+        if (!strcmp(argv[i], "--texture")) return dump_texture(assets, argv[i + 1], atoi(argv[i + 2]), argv[i + 3]);
     for (i = 1; i + 4 < argc; i++)
         if (!strcmp(argv[i], "--poses")) return dump_poses(assets, argv[i + 1], atoi(argv[i + 2]), atoi(argv[i + 3]), argv[i + 4]);
     for (i = 1; i < argc; i++) {

@@ -138,3 +138,33 @@ def test_poses_equal_the_unmodified_reference(oracle, ani, tmp_path):
     for got in (restated, host):
         assert np.array_equal(got[0].view(np.uint32), want_joints.view(np.uint32))
         assert np.array_equal(got[1].view(np.uint32), want_normals.view(np.uint32))
+
+
+@pytest.mark.parametrize("file,usage", [
+    ("helmet/helmet_basecolor.tga", 2), ("helmet/helmet_metalness.tga", 1), ("helmet/helmet_normal.tga", 1), ("helmet/helmet_emission.tga", 2),
+    ("workshop/m1_px.hdr", 0), ("workshop/i_ny.hdr", 2), ("workshop/m3_pz.hdr", 2), ("common/brdf_lut.hdr", 3),
+    ("common/diffuse.tga", 0), ("azura/body_diffuse.tga", 0), ("kgirl/kgirl_diffuse.tga", 0), ("drone/drone_specular.tga", 2)])
+def test_loaded_textures_equal_the_unmodified_reference(oracle, file, usage, tmp_path):
+    """texture_from_file of the UNMODIFIED reference (image decoding, bottom-up rows, and the conversion its usage asks
+    for: byte / 255, pow(v, 2.2) on colour maps, ACES + pow(v, 1 / 2.2) on tone-mapped sky faces; texture.c:32-128)
+    against this repository's loader: every float of texture->buffer, bit for bit.  usage: 0 LDR_COLOR, 1 LDR_DATA,
+    2 HDR_COLOR, 3 HDR_DATA (texture.h:7-12)."""
+    import ctypes as C
+    sys.path.insert(0, os.path.join(REPO, "oracle"))
+    from make_goldens import REFDUMP
+    if not os.path.exists(os.path.join(REPO, "assets", file)):
+        pytest.skip("the tree does not carry " + file)
+    subprocess.run(["make", "-C", os.path.join(REPO, "oracle"), "ref"], check=True, capture_output=True)
+    out = str(tmp_path / "texture.bin")
+    subprocess.run([REFDUMP, "--assets", os.path.join(REPO, "assets"), "--texture", file, str(usage), out], check=True, timeout=120)
+    w, h = np.fromfile(out, np.int32, 2)
+    want = np.fromfile(out, np.float32, offset=8).reshape(h, w, 4)
+    load = C.CFUNCTYPE(C.c_void_p, C.c_char_p, C.c_int)(("texture_from_file", oracle.lib))
+    release = C.CFUNCTYPE(None, C.c_void_p)(("texture_release", oracle.lib))
+    tex = load(file.encode(), usage)
+    tw, th = C.cast(tex, C.POINTER(C.c_int))[0], C.cast(tex, C.POINTER(C.c_int))[1]
+    assert (tw, th) == (w, h)
+    buffer = C.cast(C.cast(tex + 8, C.POINTER(C.c_void_p))[0], C.POINTER(C.c_float))
+    got = np.ctypeslib.as_array(buffer, shape=(h, w, 4)).copy()
+    release(tex)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
