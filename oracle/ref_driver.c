@@ -180,6 +180,24 @@ static int dump_texture(const char *assets, const char *file, int usage, const c
     return 0;
 }
 
+/* --mesh file out: the reference's own OBJ loading (core/mesh.c: de-indexed vertex stream with tangents, joints and
+ * weights) -- the number of faces, then 3 x faces vertex_t of 80 bytes */
+static int dump_mesh(const char *assets, const char *file, const char *out) {
+    mesh_t *mesh;
+    FILE *f;
+    int faces;
+    if (chdir(assets) != 0) { perror("chdir assets"); return 2; }
+    mesh = mesh_load(file);
+    f = fopen(out, "wb");
+    if (!f) { perror(out); return 2; }
+    faces = mesh_get_num_faces(mesh);
+    fwrite(&faces, sizeof(int), 1, f);
+    fwrite(mesh_get_vertices(mesh), sizeof(vertex_t), (size_t)faces * 3, f);
+    fclose(f);
+    mesh_release(mesh);
+    return 0;
+}
+
 int main(int argc, char **argv) {
     const char *assets = "/root/reference/assets";
     const char *scene_name = NULL, *scn_file = NULL, *out = NULL;
@@ -194,6 +212,8 @@ int main(int argc, char **argv) {
     perframe_t perframe;
 
     for (i = 1; i + 1 < argc; i++) if (!strcmp(argv[i], "--assets")) assets = argv[i + 1];
+    for (i = 1; i + 2 < argc; i++)
+        if (!strcmp(argv[i], "--mesh")) return dump_mesh(assets, argv[i + 1], argv[i + 2]);
     for (i = 1; i + 3 < argc; i++)
         if (!strcmp(argv[i], "--texture")) return dump_texture(assets, argv[i + 1], atoi(argv[i + 2]), argv[i + 3]);
     for (i = 1; i + 4 < argc; i++)

@@ -168,3 +168,30 @@ def test_loaded_textures_equal_the_unmodified_reference(oracle, file, usage, tmp
     got = np.ctypeslib.as_array(buffer, shape=(h, w, 4)).copy()
     release(tex)
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+@pytest.mark.parametrize("file", ["helmet/helmet.obj", "kgirl/body.obj", "kgirl/hair.obj", "azura/hair.obj", "buster/buster10.obj",
+                                  "dieselpunk/mech.obj", "common/sphere.obj", "common/box.obj", "drone/drone.obj"])
+def test_loaded_meshes_equal_the_unmodified_reference(oracle, file, tmp_path):
+    """mesh_load of the UNMODIFIED reference (core/mesh.c: OBJ faces de-indexed into the 80-byte vertex stream, with
+    tangents, joints and weights) against this repository's loader: face count and every byte of the stream."""
+    import ctypes as C
+    sys.path.insert(0, os.path.join(REPO, "oracle"))
+    from make_goldens import REFDUMP
+    if not os.path.exists(os.path.join(REPO, "assets", file)):
+        pytest.skip("the tree does not carry " + file)
+    subprocess.run(["make", "-C", os.path.join(REPO, "oracle"), "ref"], check=True, capture_output=True)
+    out = str(tmp_path / "mesh.bin")
+    subprocess.run([REFDUMP, "--assets", os.path.join(REPO, "assets"), "--mesh", file, out], check=True, timeout=120)
+    faces = int(np.fromfile(out, np.int32, 1)[0])
+    want = np.fromfile(out, np.uint32, offset=4).reshape(faces * 3, 20)
+
+    class Mesh(C.Structure):
+        _fields_ = [("num_faces", C.c_int), ("vertices", C.POINTER(C.c_uint32)), ("center", C.c_float * 3)]
+    load = C.CFUNCTYPE(C.POINTER(Mesh), C.c_char_p)(("rzh_mesh_load", oracle.lib))
+    free = C.CFUNCTYPE(None, C.POINTER(Mesh))(("rzh_mesh_free", oracle.lib))
+    mesh = load(file.encode())
+    assert mesh.contents.num_faces == faces
+    got = np.ctypeslib.as_array(mesh.contents.vertices, shape=(faces * 3, 20)).copy()
+    free(mesh)
+    assert np.array_equal(got, want)
