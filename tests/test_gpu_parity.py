@@ -111,6 +111,34 @@ def test_gpu_per_triangle_streams_that_repeat_are_drawn_from_the_device(gpu, cas
     assert np.array_equal(elsewhere[0], by_mesh[0]) and np.array_equal(elsewhere[1], by_mesh[1])
 
 
+@pytest.mark.parametrize("name,like", [("kgirl_blend.scn", "kgirl"), ("helmet", None), ("azura_shadow.scn", "azura")])
+def test_gpu_per_triangle_frames_recorded_together(gpu, name, like):
+    """Several frames submitted face by face into one flush, three flushes in a row (the first remembers the
+    models' vertex streams, the others draw from them: many draws of one program per flush, shadow pass and
+    main pass, different views and times) against the same frames submitted mesh by mesh."""
+    import os
+    from renderer_amd import orbit
+    from renderer_amd.binding import SCENES
+    scene = gpu.open_scene(os.path.join(SCENES, name) if name.endswith(".scn") else name, like)
+    w, h, count = 256, 144, 6
+    fbs = [gpu.framebuffer(w, h) for _ in range(count)]
+    for flush in range(3):
+        views = [gpu.orbit_view(7 * flush + i, 40) for i in range(count)]
+        orbit.render_views(gpu, scene, fbs, views)
+        want = [gpu.read(fb) for fb in fbs]
+        gpu.lib.rzs_set_per_triangle(1)
+        try:
+            orbit.render_views(gpu, scene, fbs, views)
+        finally:
+            gpu.lib.rzs_set_per_triangle(0)
+        for i, fb in enumerate(fbs):
+            got = gpu.read(fb)
+            assert np.array_equal(got[0], want[i][0]) and np.array_equal(got[1], want[i][1]), (flush, i)
+    for fb in fbs:
+        gpu.release(fb)
+    gpu.close_scene(scene)
+
+
 @pytest.mark.parametrize("name,like", [("kgirl_blend.scn", "kgirl"), ("helmet", None)])
 def test_gpu_per_triangle_submission_records_one_draw_per_model(gpu, name, like):
     """graphics_draw_triangle merges consecutive triangles of one model into one draw: the uniform
