@@ -289,16 +289,21 @@ void draw2d_draw_texture(rz_framebuffer *framebuffer, rz_texture *texture, rz_ve
 /* Same for a texture written by texture_from_{color,depth}buffer. */
 void texture_sync(rz_texture *texture);
 /* texture_sync for callers that cannot allocate device memory.  No counterpart in the reference (whose
- * textures live in host memory only); it is for callers that must not call hipMalloc: code under HIP
- * graph capture, tight per-frame loops (a viewer that shows the shadow map every frame), harnesses that
- * forbid allocation.  Same result as texture_sync -- texture->buffer valid on the host -- but the
- * row-major staging image lives in a fixed 16 MiB array inside the library's device image instead of
- * a buffer allocated and freed per call; the call allocates and frees nothing and creates no event.
+ * textures live in host memory only); it is for callers that must not call hipMalloc: tight per-frame
+ * loops (a viewer that shows the shadow map every frame), harnesses that forbid allocation.  Same result
+ * as texture_sync -- texture->buffer valid on the host -- but the row-major staging image lives in a
+ * fixed 16 MiB array inside the library's device image instead of a buffer allocated and freed per
+ * call; the call allocates and frees nothing and creates no event.  It does SYNCHRONISE: it waits for
+ * the stream that wrote the texture, before and after its own kernel and copy, so it is not a call to
+ * make while a stream is being captured into a graph.
  * Limits: at most 1024 x 1024 = 1 048 576 texels; the copy into the texture must have been submitted
- * (graphics_flush) -- a recorded copy is not submitted here, because submitting sizes scratch.  One
- * staging array per GPU, shared by all calls on it: calls that overlap on one GPU race.
+ * (graphics_flush) -- a recorded copy is not submitted here, because submitting sizes scratch; the
+ * host image must be page-locked, which texture_from_colorbuffer / texture_from_depthbuffer see to
+ * (a pageable destination would make the runtime stage the copy in memory of its own).  One staging
+ * array per GPU, shared by all calls on it: calls that overlap on one GPU race.
  * Returns RZ_NOALLOC_OK, or a negative code after a message on stderr (nothing is written then). */
-enum { RZ_NOALLOC_OK = 0, RZ_NOALLOC_TOO_LARGE = -1, RZ_NOALLOC_NOT_SUBMITTED = -2, RZ_NOALLOC_NO_HOST_IMAGE = -3 };
+enum { RZ_NOALLOC_OK = 0, RZ_NOALLOC_TOO_LARGE = -1, RZ_NOALLOC_NOT_SUBMITTED = -2, RZ_NOALLOC_NO_HOST_IMAGE = -3,
+       RZ_NOALLOC_NOT_PINNED = -4 };
 int texture_sync_noalloc(rz_texture *texture);
 /* Tells the library that texture->buffer was modified by the host. */
 void texture_invalidate(rz_texture *texture);
@@ -394,6 +399,9 @@ void mi355r_inspect_bins(unsigned int *counts, unsigned int *entries);
  * send ordinary scenes down that road; mi355r_passes_run_again counts the passes that took it. */
 void mi355r_set_scratch_estimate(unsigned long long fan_blocks, unsigned long long list_entries);
 unsigned long long mi355r_passes_run_again(void);
+/* Measurement: the name of the rasterising kernel the last batch of passes was launched with (the strip
+ * height is chosen per batch), as a profiler spells it, e.g. "rz_strip_kernel<4, false>". */
+const char *mi355r_last_raster_kernel(void);
 /* graphics_draw_triangle remembers, per program, the vertex stream its last draw was made of (on the host to
  * compare against, on the device to draw from): a later draw of the program whose triangles repeat that
  * stream or a prefix of it -- the reference's draw_model loops submit the same faces every frame -- stores

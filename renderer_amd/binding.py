@@ -108,6 +108,7 @@ class Pipeline:
             lib.mi355r_get_timing.restype = C.c_ulonglong
             lib.mi355r_set_scratch_estimate.argtypes = [C.c_ulonglong, C.c_ulonglong]
             lib.mi355r_passes_run_again.restype = C.c_ulonglong
+            lib.mi355r_last_raster_kernel.restype = C.c_char_p
         else:
             lib.oracle_get_stats.argtypes = [C.POINTER(C.c_ulonglong)]
         lib.rzs_set_assets_dir(assets.encode())

@@ -18,11 +18,13 @@ CONFIGS = [
 ]
 
 
-def time_config(gpu, config, steps=3, warmup=1, frames=None, per_triangle=False, sync=None):
+def time_config(gpu, config, steps=3, warmup=1, frames=None, per_triangle=False, sync=None, measure=False):
     """Frames/s of one configuration: `frames` orbit views (animation time index / 30 s) recorded and
     flushed per step, every view into its own framebuffer, scene resident on the device.
     per_triangle: through the reference's own per-face loop (program_get_attribs +
-    graphics_draw_triangle) instead of graphics_draw_mesh."""
+    graphics_draw_triangle) instead of graphics_draw_mesh.
+    measure: also one untimed step with the device-side workload counters on and two steps with HIP events
+    around every launch (`measured`: counters, summed kernel milliseconds, frames, passes, launch sequences)."""
     label, name, like, (w, h), default_frames = config
     frames = frames or default_frames
     if sync is None:
@@ -44,9 +46,24 @@ def time_config(gpu, config, steps=3, warmup=1, frames=None, per_triangle=False,
     finally:
         gpu.lib.rzs_set_per_triangle(0)
     info = gpu.scene_info(scene)
+    measured = None
+    if measure:
+        gpu.lib.mi355r_reset_counters()
+        gpu.lib.mi355r_enable_counters(1)
+        orbit.render_views(gpu, scene, fbs, views)
+        counters = gpu.counters()
+        gpu.lib.mi355r_enable_counters(0)
+        gpu.lib.mi355r_enable_timing(1)
+        for _ in range(2):
+            orbit.render_views(gpu, scene, fbs, views)
+        passes, sequences, ms = gpu.kernel_times()
+        gpu.lib.mi355r_enable_timing(0)
+        measured = {"counters": counters, "kernel_ms": ms, "frames": 2 * frames, "passes": passes, "sequences": sequences,
+                    "shadow_side": info["shadow_w"], "raster_symbol": gpu.lib.mi355r_last_raster_kernel().decode()}
     for fb in fbs:
         gpu.release(fb)
     gpu.close_scene(scene)
     return {"workload": label, "frames_per_step": frames, "steps": steps, "ms_per_step": dt / steps * 1e3,
             "fps": steps * frames / dt, "triangles_per_frame": info["faces"] + (12 if info["skybox"] else 0),
-            "width": w, "height": h, "submission": "per triangle (graphics_draw_triangle)" if per_triangle else "per mesh (graphics_draw_mesh)"}
+            "width": w, "height": h, "submission": "per triangle (graphics_draw_triangle)" if per_triangle else "per mesh (graphics_draw_mesh)",
+            **({"measured": measured} if measure else {})}

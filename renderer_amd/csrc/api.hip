@@ -80,6 +80,7 @@ struct Tex {
     bool device_stale;              /* host buffer is newer */
     bool host_stale;                /* device image is newer */
     bool host_pinned = false;       /* pub.buffer is page-locked (textures the GPU writes: their read-back is a plain DMA) */
+    bool host_from_runtime = false; /* ... because it was allocated with hipHostMalloc (freed with hipHostFree) */
     /* a texture written on the GPU (texture_from_*buffer) orders the passes
      * around it: readers wait for the write, the next write for the readers */
     int write_lane;
@@ -257,6 +258,7 @@ struct Context {
     bool counting = false;
     unsigned long long *d_counters = nullptr;
     unsigned long long host_counters[8] = {0};
+    char last_raster_kernel[64] = "";       /* the rasterising kernel of the last batch launched (measurement: which symbol to look up) */
     /* the pass mi355r_inspect_* looks at: the last one submitted */
     PassParams last_pass;
     bool have_last_pass = false;
@@ -694,8 +696,11 @@ extern "C" void texture_release(rz_texture *p) {                    /* texture.c
     sync_stream();
     drop_derived_handles();
     if (t->d_data) HIP_OK(hipFree(t->d_data));
-    if (t->host_pinned) (void)hipHostUnregister(t->pub.buffer);
-    free(t->pub.buffer);
+    if (t->host_from_runtime) HIP_OK(hipHostFree(t->pub.buffer));
+    else {
+        if (t->host_pinned) (void)hipHostUnregister(t->pub.buffer);
+        free(t->pub.buffer);
+    }
     g.texs.erase(t);
     delete t;
 }
@@ -937,11 +942,25 @@ static void launch_texture_write(Tex *t, Fb *fb, bool depth);
 static void texture_from_buffer(Tex *t, Fb *fb, bool depth, const char *who) {
     if (t->pub.width != fb->pub.width || t->pub.height != fb->pub.height) fatal("%s: size mismatch", who);
     if (!t->host_pinned) {
-        /* its host image will be filled from the device (texture_sync): page-locked, that copy needs no staging */
-        if (hipHostRegister(t->pub.buffer, (size_t)t->pub.width * t->pub.height * sizeof(rz_vec4), hipHostRegisterDefault) == hipSuccess)
+        /* its host image will be filled from the device (texture_sync): page-locked, that copy needs no staging.  Where
+         * the process may not lock pages it allocated itself (an ordinary user's limit), the image moves into memory
+         * the runtime hands out page-locked; its contents are about to be replaced anyway */
+        const size_t bytes = (size_t)t->pub.width * t->pub.height * sizeof(rz_vec4);
+        if (t->pub.buffer && hipHostRegister(t->pub.buffer, bytes, hipHostRegisterDefault) == hipSuccess) {
             t->host_pinned = true;
-        else
+        } else {
             (void)hipGetLastError();
+            rz_vec4 *locked = nullptr;
+            if (hipHostMalloc((void**)&locked, bytes, hipHostMallocDefault) == hipSuccess) {
+                if (t->pub.buffer) memcpy(locked, t->pub.buffer, bytes);
+                else memset(locked, 0, bytes);          /* an image that came in packed: nobody has asked for its floats yet */
+                free(t->pub.buffer);
+                t->pub.buffer = locked;
+                t->host_pinned = t->host_from_runtime = true;
+            } else {
+                (void)hipGetLastError();
+            }
+        }
     }
     const bool in_use = t->pending_write || (!g.pending.empty() && t->used_epoch == g.flush_epoch);
     if (!has_pending_for(fb) || in_use || !g.record_copies) {
@@ -2004,6 +2023,7 @@ static void launch_batch(const Batch &b, const std::vector<PassPlan> &plans, cha
         if (only == 1) kernel = narrow ? rz_raster_kernel<false, 1, true> : rz_raster_kernel<false, 1, false>;
         kernel<<<ordered_tiles, dim3(256), 0, st>>>(
             passes, L.tri.ptr, L.fan_tri.ptr, L.bin_list.ptr, L.vary.ptr, L.fan_vary.ptr, db, L.bin_range.ptr, n);
+        snprintf(g.last_raster_kernel, sizeof g.last_raster_kernel, "rz_raster_kernel<false, %d, %s>", only, narrow && only >= 0 ? "true" : "false");
         stamp(); stamp(); stamp(); stamp();
     } else {
         if (b.has_blend) {
@@ -2039,6 +2059,7 @@ static void launch_batch(const Batch &b, const std::vector<PassPlan> &plans, cha
             sky_bins = g.sky_bins && !g.strip_sky && g.sky_pixels_per_lane == 2 && (b.families & (1 << RZ_FAMILY_SKYBOX));
             if (sky_bins) rz_sky_regions_kernel<<<dim3((unsigned)max_bins, n), dim3(64), 0, st>>>(passes, L.bin_list.ptr, L.bin_range.ptr, L.sky_bins.ptr);
             if (g.verbose) fprintf(stderr, "mi355r: batch of %u passes, longest bin list last time %u entries, strips of %d\n", n, longest, strip);
+            snprintf(g.last_raster_kernel, sizeof g.last_raster_kernel, "rz_strip_kernel<%d, %s>", strip, g.strip_sky ? "true" : "false");
             kernel<<<dim3(bin_columns * 2 * n, bin_rows * strips_per_bin), dim3(128), 0, st>>>(
                 passes, L.bin_list.ptr, L.bin_boxes.ptr, L.vary.ptr, L.fan_vary.ptr, db, L.bin_range.ptr, n, sky_bins ? L.sky_bins.ptr : nullptr);
         }
@@ -2112,7 +2133,9 @@ static void run_again(FlushRecord &fr) {
         Lane &L = g.lanes[r.lane];
         /* A pass that ran out of clipper blocks did not bin the triangles it had no block for, so the
          * list entries it reported are too few: its second run has enough blocks, reports the true
-         * number of entries and may need a third. */
+         * number of entries and may need a third.  Only the passes that still fail are launched again:
+         * a blended pass carries no clear, so rendering it twice would blend it twice. */
+        const std::vector<size_t> ran = r.members;
         for (int attempt = 0;; attempt++) {
             prepare_batch(r, fr, true, PREPARE_AGAIN);
             prepare_batch(r, fr, false, PREPARE_AGAIN);
@@ -2122,21 +2145,25 @@ static void run_again(FlushRecord &fr) {
                 HIP_OK(hipMemcpyAsync(hb + CONTROL_BYTES * fr.plans[i].slot, db + CONTROL_BYTES * fr.plans[i].slot, CONTROL_BYTES,
                                       hipMemcpyDeviceToHost, L.stream));
             HIP_OK(hipStreamSynchronize(L.stream));
-            bool failed = false;
+            std::vector<size_t> still;
+            int families = 0;
             for (size_t i : r.members) {
                 const uint32_t *c = fr.control(i);
-                failed = failed || c[2] != 0;
+                if (c[2] == 0) continue;
+                still.push_back(i);
+                families |= fr.plans[i].families;
                 if (c[2] & RZ_ERR_BIN_OVERFLOW) g.list_highwater = std::max<size_t>(g.list_highwater, c[1]);
             }
-            if (!failed) break;
+            if (still.empty()) break;
             if (attempt == 2)
-                for (size_t i : r.members)
-                    if (fr.control(i)[2] != 0)
-                        fatal("a pass run again with the scratch it asked for (%u clipper blocks, %u list entries) failed again: error bits %u",
-                              fr.control(i)[0], fr.control(i)[1], fr.control(i)[2]);
+                for (size_t i : still)
+                    fatal("a pass run again with the scratch it asked for (%u clipper blocks, %u list entries) failed again: error bits %u",
+                          fr.control(i)[0], fr.control(i)[1], fr.control(i)[2]);
+            r.members = still;
+            r.families = families;
         }
         for (const FlushRecord::Copy &c : fr.copies) {
-            if (std::find(r.members.begin(), r.members.end(), c.producer) == r.members.end()) continue;
+            if (std::find(ran.begin(), ran.end(), c.producer) == ran.end()) continue;
             CopyJobs jobs;
             memset(&jobs, 0, sizeof jobs);
             jobs.job[0] = copy_job(c.tex, c.fb, c.depth, nullptr);
@@ -2162,7 +2189,7 @@ struct FramesRead {
     unsigned long long before_epoch = 0;        /* flushes submitted before the copies: those with a smaller epoch */
 };
 static FramesRead g_frames_read;
-static void launch_frames_read();
+static void launch_frames_read(bool again);
 
 static bool settle_in_flight(bool lanes_idle) {
     bool ran_again = false, ran_again_before_read = false;
@@ -2189,9 +2216,10 @@ static bool settle_in_flight(bool lanes_idle) {
             if (g_frames_read.active && fr.epoch < g_frames_read.before_epoch) ran_again_before_read = true;
         }
     }
-    /* frames that were copied out behind passes which had not run: copied again behind the passes' second run
-     * (a flush is settled before the next one's first launch, so nothing later has touched the framebuffers yet) */
-    if (ran_again_before_read) launch_frames_read();
+    /* frames that were copied out behind passes which had not run: copied again behind the passes' second run.
+     * A flush is settled before the next one's first launch, so no later pass has touched the framebuffers yet;
+     * clears the host has asked for since are only flags until a pass consumes them, and stay flags here */
+    if (ran_again_before_read) launch_frames_read(true);
     return ran_again;
 }
 
@@ -2245,12 +2273,16 @@ extern "C" void framebuffers_read_device_rgb(rz_framebuffer *const *fps, int cou
  * submitted after them.  Later passes into the same framebuffers come after the copies in stream order.  Passes
  * that turn out not to have run are run again when the flush is settled (at the latest before the next flush's
  * first launch), and the copies are launched again behind them (settle_in_flight).  One set at a time. */
-static void launch_frames_read() {
+/* again: the copies are launched a second time, behind passes that have just run again.  A clear that is pending
+ * now was asked for AFTER _begin -- it belongs to the caller's next step (a render loop clears and records its next
+ * frames while these copies are outstanding) -- and must not reach the frame that is being copied out. */
+static void launch_frames_read(bool again) {
     FramesRead &r = g_frames_read;
+    /* (a clear on its own settles the flush in flight first, which may launch the copies: before the events below) */
+    if (!again) for (Fb *fb : r.fbs) apply_pending_clear(fb);
     for (int l = 0; l < MAX_LANES; l++) if (r.used[l]) { HIP_OK(hipEventDestroy(r.done[l])); r.used[l] = false; }
     for (size_t i = 0; i < r.fbs.size(); i++) {
         Fb *fb = r.fbs[i];
-        apply_pending_clear(fb);
         const size_t n = (size_t)fb->pub.width * fb->pub.height;
         const int lane = fb->lane < 0 ? 0 : fb->lane;
         rz_strip_alpha_kernel<<<dim3((unsigned)((n / 4 + 1 + 255) / 256)), dim3(256), 0, g.lanes[lane].stream>>>(
@@ -2281,7 +2313,7 @@ extern "C" void framebuffers_read_device_rgb_begin(rz_framebuffer *const *fps, i
     graphics_flush();
     r.before_epoch = g.flush_epoch;
     r.active = true;
-    launch_frames_read();
+    launch_frames_read(false);
 }
 
 extern "C" void framebuffers_read_device_rgb_end(void) {
@@ -2304,15 +2336,15 @@ extern "C" void framebuffers_read_device_rgb_end(void) {
 
 /* ---- texture_sync without allocations ---------------------------------------
  * texture_sync above stages the row-major float4 image in a buffer it allocates and frees per call.
- * Callers that cannot allocate device memory (code under HIP graph capture, a viewer's loop that shows
- * the shadow map every frame, harnesses that forbid hipMalloc) get the same result through a staging
+ * Callers that cannot allocate device memory (a viewer's loop that shows the shadow map every frame,
+ * harnesses that forbid hipMalloc) get the same result through a staging
  * area that is part of the library's image on the device: a file-scope __device__ array of
  * RZ_SYNC_SCRATCH_TEXELS float4 texels.  Every GPU the library runs on holds its own copy of that
  * array, at its own address, until the process ends; the address is looked up once per device
  * (scratch_on_device) and only that pointer is ever handed to kernels and copies.  Every call on a
  * GPU uses the same array: calls that overlap on one GPU would race (the library is single-threaded,
  * like the reference).  Nothing in it has to start at zero: the kernel writes every texel the copy
- * then reads. */
+ * then reads.  The call waits for the texture's stream (twice): not for use under stream capture. */
 #define RZ_SYNC_SCRATCH_TEXELS (1024u * 1024u)      /* 16 MiB: a 1024x1024 image, twice the default shadow map's side */
 static __device__ __align__(256) float4 rz_sync_scratch[RZ_SYNC_SCRATCH_TEXELS];
 
@@ -2353,6 +2385,11 @@ extern "C" int texture_sync_noalloc(rz_texture *p) {
         /* an image that came in packed (texture_create_packed) and whose floats nobody has asked for yet: texture_sync makes the host image */
         fprintf(stderr, "mi355r: texture_sync_noalloc: the texture has no host image yet; call texture_sync once\n");
         return RZ_NOALLOC_NO_HOST_IMAGE;
+    }
+    if (!t->host_pinned) {
+        /* the copy to a pageable host image goes through staging memory of the runtime's own */
+        fprintf(stderr, "mi355r: texture_sync_noalloc: the texture's host image is not page-locked; call texture_sync\n");
+        return RZ_NOALLOC_NOT_PINNED;
     }
     float4 *staging = scratch_on_device(g.device);
     hipStream_t st = g.lanes[t->write_lane < 0 ? 0 : t->write_lane].stream;     /* behind the copy that wrote the image */
@@ -2886,6 +2923,8 @@ extern "C" void mi355r_set_scratch_estimate(unsigned long long fan_blocks, unsig
 }
 
 extern "C" unsigned long long mi355r_replayed_draws(void) { return g.replayed_draws; }
+
+extern "C" const char *mi355r_last_raster_kernel(void) { return g.last_raster_kernel; }
 
 extern "C" unsigned long long mi355r_passes_run_again(void) {
     ensure_ready();

@@ -106,26 +106,29 @@ class FrameGather:
     """The gather as a pipeline of `depth` slots: a step's frames go into the next slot and their
     gather starts at once (async_op); the slot is only waited for when it comes round again, so
     the transfer of one step overlaps the rendering of the next.  Rank 0 ends up with
-    `received(slot)` = list over ranks of that step's frames.  world == 1: nothing is moved.
+    `received(slot)` = list over ranks of that step's frames.  world == 1: nothing is moved, unless
+    `force` is set -- then the one rank gathers to itself through the same slots, copies and collective
+    calls (how the N > 1 code path is exercised on a single GPU).
 
     `lagged` (the default for RGB8 frames in device memory): the copy of a step's frames into the slot is only
     launched by `submit` (framebuffers_read_device_rgb_begin: behind the rendering, no wait), and waited for
     -- and the slot's gather started -- by the NEXT `submit` or by `drain`.  The host then records the next
     step while the GPU still renders and copies this one, instead of waiting for the copies first."""
 
-    def __init__(self, frames, height, width, device, rank, world, depth=2, root_frames=None, channels=4, lagged=None):
+    def __init__(self, frames, height, width, device, rank, world, depth=2, root_frames=None, channels=4, lagged=None, force=False):
         """frames: slot size of the collective (the largest block a rank sends).  root_frames: the
         gather-aware split (shard_views_rooted) -- rank 0's block has that many frames and does not
         go through the collective: rank 0 copies it into a buffer of its own per slot (`own(slot)`),
         and takes part in the gather with an unused slot."""
         import torch
         self.rank, self.world, self.depth, self.count = rank, world, depth, 0
+        self.active = world > 1 or force
         self.rooted = root_frames is not None
         self.on_device = torch.device(device).type == "cuda"
         self.lagged = (self.on_device and channels == 3) if lagged is None else lagged
         self.pending = None             # (pipe, slot): copies launched, gather not started yet
         self.slots = self.inbox = self.work = self.kept = None
-        if world > 1:
+        if self.active:
             shape = (frames, height, width, channels)
             self.slots = [torch.empty(shape, dtype=torch.uint8, device=device) for _ in range(depth)]
             self.inbox = [[torch.empty(shape, dtype=torch.uint8, device=device) for _ in range(world)] if rank == 0 else None
@@ -157,13 +160,15 @@ class FrameGather:
     def submit(self, pipe, framebuffers, count):
         """Copies `count` finished frames into the next slot and starts gathering it (lagged: launches the
         copies, and starts gathering the step before)."""
-        if self.world == 1:
+        if not self.active:
             return
         slot = self.count % self.depth
+        # the step before's gather is started first and only then is this slot waited for: with depth 1 they are
+        # the same slot, and its gather must have finished before this step's copies overwrite it
+        self._start_pending()
         self._finish(slot)
         target = self.kept[slot] if self.rooted and self.rank == 0 else self.slots[slot]
         if self.lagged:
-            self._start_pending()
             if count > 0:
                 handles = (type(framebuffers[0]) * count)(*framebuffers[:count])
                 pipe.lib.framebuffers_read_device_rgb_begin(handles, count, C.c_void_p(target.data_ptr()), target[0].numel())
@@ -177,7 +182,7 @@ class FrameGather:
         self.count += 1
 
     def drain(self):
-        if self.world > 1:
+        if self.active:
             self._start_pending()
             for slot in range(self.depth):
                 self._finish(slot)

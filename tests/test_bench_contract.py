@@ -27,7 +27,10 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     assert out["value"] > 500                                   # frames/s at 1920x1080, the target's order of magnitude at least
     assert abs(out["value"] * out["ms_per_step"] / 1e3 - 32) < 1e-6 * 32        # value = frames of a step / its time
     roof = out["roofline"]
-    assert roof["bound"] in ("hbm", "mfma") and roof["unit"] == "GB/s" and roof["peak"] == 8000.0
+    # `bound` names the roof the committed hardware counters put the kernel under (HBM traffic, vector issue, texture data path)
+    assert roof["bound"] in ("hbm", "mfma", "valu", "td") and roof["unit"] == "GB/s" and roof["peak"] == 8000.0
     assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-9 and 0 < roof["frac"] < 1
+    assert roof["algorithmic_frac"] == roof["frac"] and roof["kernel"]
+    assert out["value_with_copy_out"] > 500 and "value_includes" in out["config"]
     cpu = out["cpu_baseline"]
     assert cpu["kind"] in ("port", "reference") and cpu["cores"] == 1 and cpu["value"] > 0 and cpu["sample"]

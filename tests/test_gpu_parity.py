@@ -176,20 +176,47 @@ def test_gpu_ragged_framebuffer_sizes(gpu, oracle, size):
     assert_same(frames[0], frames[1], size[0] * size[1])
 
 
-@pytest.mark.parametrize("name,like,size,eye", [
-    ("helmet", None, (1920, 1080), None),                                   # the benchmark configuration
-    ("dieselpunk_shadow.scn", "dieselpunk", (3840, 2160), (-0.9, 0.6, 1.0)),  # 4K + 2048^2 shadow map
-    ("kgirl_blend.scn", "kgirl", (1920, 1080), (0.5, 0.2, -1.3)),           # skinning + ordered blend
+@pytest.mark.parametrize("name,like,size,eye,time", [
+    ("helmet", None, (1920, 1080), None, 0.6),                                   # the benchmark configuration (C2)
+    ("dieselpunk_shadow.scn", "dieselpunk", (3840, 2160), (-0.9, 0.6, 1.0), 0.6),  # C4: 4K + 2048^2 shadow map
+    ("kgirl_blend.scn", "kgirl", (1920, 1080), (0.5, 0.2, -1.3), 0.6),           # C3: skinning + ordered blend
+    ("azura_shadow.scn", "azura", (800, 600), None, 0.0),                        # C1 at its quoted size: dense mesh, shadow pass
+    ("buster", None, (1920, 1080), None, 0.4),                                   # C5 at its quoted size, two animation times
+    ("buster", None, (1920, 1080), (1.1, 0.45, -1.0), 2.9),
 ])
-def test_gpu_full_size_frames_match_oracle(gpu, oracle, name, like, size, eye):
+def test_gpu_full_size_frames_match_oracle(gpu, oracle, name, like, size, eye, time):
     import os
     from renderer_amd.binding import SCENES
     frames = []
     for pipe in (gpu, oracle):
         scene = pipe.open_scene(os.path.join(SCENES, name) if name.endswith(".scn") else name, like)
-        frames.append(pipe.render(scene, size[0], size[1], pipe.make_view(eye, None, 0.6)))
+        frames.append(pipe.render(scene, size[0], size[1], pipe.make_view(eye, None, time)))
         pipe.close_scene(scene)
     assert_same(frames[0], frames[1], size[0] * size[1])
+
+
+def test_gpu_full_size_animated_frames_of_one_flush_match_oracle(gpu, oracle):
+    """C3 as the orbit bench submits it, at its quoted size: eight 1080p frames of the skinned, shadowed, blended
+    scene with eight different animation times recorded into ONE flush (eight poses evaluated by one launch, shadow
+    passes, recorded copies, main and blended passes batched level by level), each against the oracle."""
+    import os
+    from renderer_amd.binding import SCENES
+    path, size, n = os.path.join(SCENES, "kgirl_blend.scn"), (1920, 1080), 8
+    scene = gpu.open_scene(path, "kgirl")
+    views = [gpu.orbit_view(i * 29, 240) for i in range(n)]         # frame_time = index / 30 s
+    assert len({v.frame_time for v in views}) == n
+    fbs = [gpu.framebuffer(*size) for _ in range(n)]
+    for fb, v in zip(fbs, views):
+        gpu.draw(scene, fb, v)
+    gpu.lib.graphics_flush()
+    got = [gpu.read(fb) for fb in fbs]
+    for fb in fbs:
+        gpu.release(fb)
+    gpu.close_scene(scene)
+    scene = oracle.open_scene(path, "kgirl")
+    for i in range(n):
+        assert_same(got[i], oracle.render(scene, size[0], size[1], oracle.orbit_view(i * 29, 240)), size[0] * size[1])
+    oracle.close_scene(scene)
 
 
 def test_gpu_batched_frames_equal_single_frames(gpu):

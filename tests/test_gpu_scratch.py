@@ -309,3 +309,132 @@ def test_frames_copied_out_in_two_halves(gpu, tiny):
         for fb in fbs:
             gpu.release(fb)
         gpu.close_scene(scene)
+
+
+def test_clears_asked_for_while_copies_are_outstanding(gpu):
+    """A render loop clears its framebuffers for the next step while the copies of this step are outstanding
+    (framebuffers_read_device_rgb_begin .. _end).  Clears are flags until a pass consumes them.  When the step's
+    passes have to run again (scratch too small) and the flush is settled by a full synchronisation BEFORE the
+    next step is submitted, the copies are launched again behind the second run: they must carry this step's
+    frames, not the colour the framebuffers are about to be cleared to -- and the clears must still happen."""
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    hip.hipMemset.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    hip.hipFree.argtypes = [C.c_void_p]
+    w, h, count = 320, 180, 4
+    stride = w * h * 3
+    scene = gpu.open_scene("helmet")
+    fbs = [gpu.framebuffer(w, h) for _ in range(count)]
+    handles = (type(fbs[0]) * count)(*fbs)
+    views = [gpu.orbit_view(i, 16) for i in range(count)]
+    for fb, v in zip(fbs, views):
+        gpu.draw(scene, fb, v)
+    want = [gpu.read(fb)[0][..., :3].copy() for fb in fbs]
+    dev = C.c_void_p()
+    assert hip.hipMalloc(C.byref(dev), stride * count) == 0 and hip.hipMemset(dev, 5, stride * count) == 0
+    gpu.lib.mi355r_set_scratch_estimate(2, 48)
+    try:
+        for fb, v in zip(fbs, views):
+            gpu.draw(scene, fb, v)
+        gpu.lib.framebuffers_read_device_rgb_begin(handles, count, dev, stride)
+        for fb in fbs:                                  # the next step's clears: flags only
+            gpu.lib.framebuffer_clear_color(fb, Vec4(1.0, 0.0, 0.0, 1.0))
+        before = gpu.lib.mi355r_passes_run_again()      # a full synchronisation: settles the flush, runs its passes again
+        assert before > 0
+        gpu.lib.framebuffers_read_device_rgb_end()
+        got = np.zeros(stride * count, np.uint8)
+        assert hip.hipMemcpy(got.ctypes.data_as(C.c_void_p), dev, stride * count, 2) == 0
+        got = got.reshape(count, h, w, 3)
+        for i in range(count):
+            assert np.array_equal(got[i], want[i]), i
+        # the clears are still pending and happen when the framebuffer is looked at
+        colour, _ = gpu.read(fbs[0])
+        assert np.all(colour[..., :3] == [255, 0, 0])
+    finally:
+        gpu.lib.mi355r_set_scratch_estimate(0, 0)
+        hip.hipFree(dev)
+        for fb in fbs:
+            gpu.release(fb)
+        gpu.close_scene(scene)
+
+
+def _blended_frames(pipe, size, sets):
+    """Several framebuffers, each with its own list of (triangle, colour) blended draws, all recorded
+    before any is read: their passes share one flush and, being of one kind and level, one batch."""
+    lib = pipe.lib
+    declare(lib)
+    prog = lib.program_create(fn(lib, "blinn_vertex_shader"), fn(lib, "blinn_fragment_shader"), 64, 44, 344, 1, 1)
+    u = BlinnUniforms.from_address(lib.program_get_uniforms(prog))
+    u.light_dir[:] = [0.0, 0.0, -1.0]
+    u.camera_pos[:] = [0.0, 0.0, 2.0]
+    u.model_matrix[:] = IDENTITY4[:]
+    u.normal_matrix[:] = IDENTITY3[:]
+    u.light_vp_matrix[:] = IDENTITY4[:]
+    u.camera_vp_matrix[:] = IDENTITY4[:]
+    u.ambient_intensity = 0.7
+    u.punctual_intensity = 0.6
+    u.shininess = 12.0
+    fbs = []
+    for triangles, colours in sets:
+        fb = pipe.framebuffer(*size)
+        fbs.append(fb)
+        lib.framebuffer_clear_color(fb, Vec4(0.25, 0.25, 0.25, 1.0))
+        lib.framebuffer_clear_depth(fb, 1.0)
+    # a first, opaque-free flush consumes the clears: the blended passes below carry none
+    lib.graphics_flush()
+    for fb in fbs:
+        pipe.read(fb)
+    for fb, (triangles, colours) in zip(fbs, sets):
+        for tri, colour in zip(triangles, colours):
+            u.basecolor[:] = [float(c) for c in colour]
+            for j in range(3):
+                a = BlinnAttribs_of(lib, prog, j)
+                a.position[:] = [float(tri[j][0]), float(tri[j][1]), float(tri[j][2])]
+                a.texcoord[:] = [0.5, 0.5]
+                a.normal[:] = [0.0, 0.0, 1.0]
+                a.joint[:] = [0, 0, 0, 0]
+                a.weight[:] = [0, 0, 0, 0]
+            lib.graphics_draw_triangle(C.cast(fb, C.c_void_p), prog)
+    lib.graphics_flush()
+    out = [pipe.read(fb) for fb in fbs]
+    for fb in fbs:
+        pipe.release(fb)
+    lib.program_release(prog)
+    return out
+
+
+def BlinnAttribs_of(lib, prog, j):
+    from test_gpu_triangles import BlinnAttribs
+    return BlinnAttribs.from_address(lib.program_get_attribs(prog, j))
+
+
+def test_two_blended_passes_of_one_batch_where_one_needs_a_third_run(gpu, oracle):
+    """Forced estimates of 2 clipper blocks and 48 list entries.  Framebuffer A gets blended triangles that fit the
+    clipper but not the lists: its pass fails once and succeeds when run again.  Framebuffer B gets sixty blended
+    triangles that all need the clipper: its first run counts list entries only for the two triangles it had blocks
+    for, so its second run fails on the lists and it needs a third.  Both passes sit in one batch; the third run must
+    not render A's pass once more -- a blended pass carries no clear, it would be blended twice."""
+    rng = np.random.default_rng(31)
+    size = (512, 512)
+    # A: two view-filling triangles (64 bins each) and a few small ones, all inside the view volume
+    a_tris = [np.array([[-1.0, -1.0, 0.0], [1.0, -1.0, 0.0], [1.0, 1.0, 0.0]], np.float32),
+              np.array([[-1.0, -1.0, 0.1], [1.0, 1.0, 0.1], [-1.0, 1.0, 0.1]], np.float32)]
+    a_tris += list(random_triangles(6, 6, 0.3) * np.float32(0.5))
+    a_cols = np.concatenate([rng.uniform(0, 1, (len(a_tris), 3)), rng.uniform(0.3, 0.7, (len(a_tris), 1))], axis=1)
+    # B: every triangle has a corner outside the view volume
+    b_tris = random_triangles(7, 60, 0.8)
+    b_tris[:, 2, 0] = 1.5
+    b_tris[..., 2] *= 0.5
+    b_cols = np.concatenate([rng.uniform(0, 1, (60, 3)), rng.uniform(0.3, 0.7, (60, 1))], axis=1)
+    sets = [(a_tris, a_cols), (b_tris, b_cols)]
+    want = _blended_frames(oracle, size, sets)
+    gpu.lib.mi355r_set_scratch_estimate(2, 48)
+    try:
+        before = gpu.lib.mi355r_passes_run_again()
+        got = _blended_frames(gpu, size, sets)
+        assert gpu.lib.mi355r_passes_run_again() >= before + 2
+    finally:
+        gpu.lib.mi355r_set_scratch_estimate(0, 0)
+    for g, w_ in zip(got, want):
+        assert same(g, w_)

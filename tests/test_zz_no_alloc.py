@@ -2,7 +2,7 @@
 image lives in a fixed array inside the library's device image -- must leave the same bytes in
 texture->buffer as the entry point that allocates and frees a staging buffer per call.  Two calls in a
 row, the second with a smaller texture (the staging array still holds the first call's texels), through
-the C ABI; then the limits: a texture beyond the staging array's size and a copy that is still
+the C ABI, with the device's free memory the same before and after; then the limits: a texture beyond the staging array's size and a copy that is still
 recorded are refused with an error code and leave the host image alone."""
 import ctypes as C
 
@@ -28,6 +28,14 @@ def _api(lib):
     lib.texture_from_depthbuffer.argtypes = [T, C.c_void_p]
 
 
+def _free_device_memory():
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemGetInfo.argtypes = [C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+    free, total = C.c_size_t(), C.c_size_t()
+    assert hip.hipMemGetInfo(C.byref(free), C.byref(total)) == 0
+    return free.value
+
+
 def _texels(t):
     return np.ctypeslib.as_array(t.contents.buffer, (t.contents.height, t.contents.width, 4))
 
@@ -46,7 +54,9 @@ def test_texture_sync_without_allocations_equals_texture_sync(gpu):
         copy(b, fb)
         _texels(b)[...] = -1.0                                      # every texel has to be written by the call
         lib.texture_sync(a)
+        free_before = _free_device_memory()
         assert lib.texture_sync_noalloc(b) == 0
+        assert _free_device_memory() == free_before             # nothing was allocated (and kept), nothing freed
         got, want = _texels(b).copy(), _texels(a).copy()
         assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (w, h, depth)
         if depth:

@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Throughput of the other BASELINE configurations (not the contract bench): orbit batches of each
-scene through the GPU library, frames/s and per-kernel time.  usage: tools/bench_configs.py [frames]"""
+scene through the GPU library, frames/s and per-kernel time.
+usage: tools/bench_configs.py [frames] [label prefix, e.g. C4] [plain]
+plain: the rendering loop only (what a profiler run wants: no read-back leg, no event-timed leg)."""
 import json
 import os
 import sys
@@ -18,6 +20,7 @@ def main():
     import torch
     frames = int(sys.argv[1]) if len(sys.argv) > 1 else 16
     only = sys.argv[2] if len(sys.argv) > 2 else None
+    plain = len(sys.argv) > 3 and sys.argv[3] == "plain"
     gpu = Pipeline(GPU_LIB)
     for label, name, like, (w, h), _ in CONFIGS:
         if only and not label.startswith(only):
@@ -34,6 +37,12 @@ def main():
             orbit.render_views(gpu, scene, fbs, views)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+        if plain:
+            print(json.dumps({"config": label, "fps": round(steps * frames / dt, 1)}))
+            for fb in fbs:
+                gpu.release(fb)
+            gpu.close_scene(scene)
+            continue
         # the same with every frame copied to host memory (colour + depth over PCIe)
         t0 = time.perf_counter()
         for _ in range(steps):

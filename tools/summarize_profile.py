@@ -66,32 +66,46 @@ for k, (calls, avg, pct) in sorted(stats.items(), key=lambda kv: -kv[1][2]):
             note = f"  KiB -> {mean * 1024 / 1e6:.2f} MB/launch"
         print(f"    {c:28s} {mean:16.1f}{note}")
 
-# machine-readable HBM traffic per launch for bench.py's roofline.traffic
+# machine-readable figures per kernel for bench.py's roofline objects
 import json
 frames = int(sys.argv[2]) if len(sys.argv) > 2 else None
-traffic = {"frames_per_launch": frames, "unit": "bytes per launch",
-           "note": "hbm_bytes_per_launch = 2 x FETCH_SIZE + WRITE_SIZE (KiB -> bytes); the factor 2 is the gfx950 "
-                   "correction for wide coalesced reads and an upper bound for 16-byte gathers",
+HBM_PEAK = 8000e9       # bytes/s
+COMPUTE_UNITS = 256
+CLOCK_MHZ = 2400.0
+traffic = {"frames_per_launch": frames, "unit": "bytes per launch; fractions over the kernel's steady average duration in this profile",
+           "note": "traffic_frac = (FETCH_SIZE + WRITE_SIZE, KiB -> bytes) / duration / 8 TB/s; traffic_frac_x2 doubles FETCH_SIZE, the gfx950 "
+                   "correction for wide coalesced reads (an upper bound for 4- and 16-byte gathers); valu_issue_frac = wave-level VALU "
+                   "instructions x 4 cycles over the cycles of the 1024 SIMDs at 2.4 GHz; td_busy_frac = TD_TD_BUSY_sum over the "
+                   "cycles of the 256 compute units' texture data paths",
            "kernels": {}}
 for k in stats:
     c = pmc.get(k, {})
     if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
         fetch = sum(c["FETCH_SIZE"]) / len(c["FETCH_SIZE"]) * 1024
         write = sum(c["WRITE_SIZE"]) / len(c["WRITE_SIZE"]) * 1024
+        us = steady(durations.get(k, []))
         entry = {"fetch_size_bytes_raw": fetch, "write_size_bytes": write,
                  "hbm_bytes_per_launch": 2 * fetch + write,
-                 "median_us": median(durations.get(k, []))}
-        # VALU issue utilisation: wave-level VALU instructions x 4 cycles (a wave64 op on a 16-lane SIMD)
-        # over the cycles the 1024 SIMDs had during the launch, at the 2.4 GHz peak engine clock
-        if "SQ_INSTS_VALU" in c and entry["median_us"] == entry["median_us"]:
-            valu = sum(c["SQ_INSTS_VALU"]) / len(c["SQ_INSTS_VALU"])
-            salu = sum(c["SQ_INSTS_SALU"]) / len(c["SQ_INSTS_SALU"]) if "SQ_INSTS_SALU" in c else 0.0
-            entry["valu_insts_per_launch"] = valu
-            entry["salu_insts_per_launch"] = salu
-            entry["valu_issue_frac"] = valu * 4 / (1024 * entry["median_us"] * 2400.0)
-            # scalar issue: a compute unit's scalar unit takes one instruction per cycle from its four SIMDs in turn,
-            # i.e. one per SIMD every 4 cycles, like the vector unit; scalar memory instructions go through it too
-            smem = sum(c["SQ_INSTS_SMEM"]) / len(c["SQ_INSTS_SMEM"]) if "SQ_INSTS_SMEM" in c else 0.0
-            entry["salu_issue_frac"] = (salu + smem) * 4 / (1024 * entry["median_us"] * 2400.0)
+                 "median_us": median(durations.get(k, [])), "steady_avg_us": us, "launches": len(durations.get(k, []))}
+        if us == us and us > 0:
+            entry["traffic_frac"] = (fetch + write) / (us * 1e-6) / HBM_PEAK
+            entry["traffic_frac_x2"] = (2 * fetch + write) / (us * 1e-6) / HBM_PEAK
+            # VALU issue utilisation: wave-level VALU instructions x 4 cycles (a wave64 op on a 16-lane SIMD)
+            # over the cycles the 1024 SIMDs had during the launch, at the 2.4 GHz peak engine clock
+            if "SQ_INSTS_VALU" in c:
+                valu = sum(c["SQ_INSTS_VALU"]) / len(c["SQ_INSTS_VALU"])
+                salu = sum(c["SQ_INSTS_SALU"]) / len(c["SQ_INSTS_SALU"]) if "SQ_INSTS_SALU" in c else 0.0
+                entry["valu_insts_per_launch"] = valu
+                entry["salu_insts_per_launch"] = salu
+                entry["valu_issue_frac"] = valu * 4 / (4 * COMPUTE_UNITS * us * CLOCK_MHZ)
+                # scalar issue: a compute unit's scalar unit takes one instruction per cycle from its four SIMDs in turn,
+                # i.e. one per SIMD every 4 cycles, like the vector unit; scalar memory instructions go through it too
+                smem = sum(c["SQ_INSTS_SMEM"]) / len(c["SQ_INSTS_SMEM"]) if "SQ_INSTS_SMEM" in c else 0.0
+                entry["salu_issue_frac"] = (salu + smem) * 4 / (4 * COMPUTE_UNITS * us * CLOCK_MHZ)
+            if "TD_TD_BUSY_sum" in c:
+                busy = sum(c["TD_TD_BUSY_sum"]) / len(c["TD_TD_BUSY_sum"])
+                entry["td_busy_frac"] = busy / (COMPUTE_UNITS * us * CLOCK_MHZ)
+            if "SQ_INSTS_VMEM_RD" in c:
+                entry["vmem_rd_insts_per_launch"] = sum(c["SQ_INSTS_VMEM_RD"]) / len(c["SQ_INSTS_VMEM_RD"])
         traffic["kernels"][k] = entry
 json.dump(traffic, open(os.path.join(out, "traffic.json"), "w"), indent=1)
