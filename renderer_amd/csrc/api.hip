@@ -76,7 +76,7 @@ struct Tex {
     rz_texture pub;                 /* must stay first */
     void *d_data;
     size_t d_bytes;
-    int flags, mbits;               /* RZ_TEX_* of the device image */
+    int flags;                      /* RZ_TEX_* of the device image */
     bool device_stale;              /* host buffer is newer */
     bool host_stale;                /* device image is newer */
     bool host_pinned = false;       /* pub.buffer is page-locked (textures the GPU writes: their read-back is a plain DMA) */
@@ -170,6 +170,7 @@ struct Lane {
     DevBuf<uint2> bin_range;
     DevBuf<SkyBin> sky_bins;            /* per bin of the batch: rz_sky_regions_kernel's record */
     DevBuf<uint32_t> bin_counts, queue, queue_counts, tile_listed;
+    DevBuf<uint2> crowd_list;           /* per batch: the squares of its crowded bins (rz_crowd_kernel), at most 16 per bin */
     DevBuf<BinEntry> bin_list;
     DevBuf<uint2> bin_boxes;
 };
@@ -188,23 +189,18 @@ struct Context {
     size_t max_batch = 32;                  /* passes per launch sequence */
     bool sky_bytes = true;                  /* MI355R_SKY_BYTES=0: skybox fragments fetch the face's texel and convert it themselves */
     bool pack_textures = true;              /* MI355R_PACK=0: keep every image as float4 */
-    bool narrow_raster = false;             /* MI355R_NARROW_RASTER=1: one pixel per lane in the visibility pass */
-    int pixels_per_lane = 2;                /* MI355R_PPL=4: a wave takes the whole 32x8 tile */
-    int micro_min_list = 256;               /* MI355R_MICRO_MIN_LIST: ... only in bins with at least this many list entries */
-    int sky_pixels_per_lane = 2;            /* MI355R_SKY_PPL=1: the one-pixel-per-lane skybox kernel */
-    bool strip_sky = false;                 /* MI355R_STRIP_SKY=1: rz_strip_kernel shades skybox fragments in place (measured: slower) */
+    int micro_min_list = 256;               /* MI355R_MICRO_MIN_LIST: small triangles are rasterised one per lane only in bins with at least this many list entries */
     bool sky_bins = true;                   /* MI355R_SKY_BINS=0: bins that hold only skybox triangles go through rz_strip_kernel like any other */
     unsigned strip_long = 2048;             /* MI355R_STRIP_LONG: a batch whose framebuffers had a bin list of this many entries in their last frame takes one block per wave,
                                              * of half as many two; 0, or MI355R_STRIP set = always `strip` */
-    int strip = 4;                          /* MI355R_STRIP: 16x8 blocks a wave of rz_strip_kernel takes (8, 4, 2, 1); 0 = rz_visibility_kernel + rz_sky_kernel */
+    int strip = 4;                          /* MI355R_STRIP: 16x8 blocks a wave of rz_strip_kernel takes (8, 4, 2, 1) */
     /* passes with blended draws: 0 = whole through the ordered kernel, 1 = visibility first and the ordered kernel only for
      * the tiles that need it, 2 = the latter for large framebuffers (MI355R_SPLIT_BLEND=0 / 1; measured: 4K frames gain 8 %,
      * 1080p frames lose as much to the three extra launches) */
     int split_blend = 2;
-    /* older code paths and measurement switches, read once when the library starts (MI355R_MONOLITHIC, _GENERIC_BLEND,
-     * _VERBOSE, _DEBUG_SKIP) */
-    bool monolithic = false, generic_blend = false, verbose = false;
-    int debug_skip = 0;
+    bool verbose = false;                   /* MI355R_VERBOSE */
+    unsigned crowd_min = 0;                 /* MI355R_CROWD_MIN: bins with at least this many list entries go to rz_crowd_kernel; 0 = none */
+    int crowd_small = 64;                   /* MI355R_CROWD_SMALL: largest box (pixels) one lane of rz_crowd_kernel rasterises on its own */
     bool record_copies = true;              /* MI355R_RECORD_COPIES=0: texture_from_*buffer always flushes first */
     int micro_area = 32;                    /* MI355R_MICRO_AREA: largest box (pixels of a block) rasterised one triangle per lane; 0 = off */
     int shade_workgroups = 4096;            /* 256-thread workgroups per shade launch (compute units x 16) */
@@ -320,16 +316,8 @@ extern "C" int mi355r_init(int device) {
         g.num_lanes = env ? atoi(env) : 4;
         if (g.num_lanes < 1) g.num_lanes = 1;
         if (g.num_lanes > MAX_LANES) g.num_lanes = MAX_LANES;
-        env = getenv("MI355R_NARROW_RASTER");
-        if (env) g.narrow_raster = atoi(env) != 0;
-        env = getenv("MI355R_PPL");
-        if (env) g.pixels_per_lane = atoi(env);
-        env = getenv("MI355R_SKY_PPL");
-        if (env) g.sky_pixels_per_lane = atoi(env) == 1 ? 1 : 2;
         env = getenv("MI355R_STRIP");
-        if (env) { const int v = atoi(env); g.strip = (v == 8 || v == 4 || v == 2 || v == 1) ? v : 0; g.strip_long = 0; }
-        env = getenv("MI355R_STRIP_SKY");
-        if (env) g.strip_sky = atoi(env) != 0;
+        if (env) { const int v = atoi(env); if (v == 8 || v == 4 || v == 2 || v == 1) { g.strip = v; g.strip_long = 0; } }
         env = getenv("MI355R_SKY_BYTES");
         if (env) g.sky_bytes = atoi(env) != 0;
         env = getenv("MI355R_SKY_BINS");
@@ -338,12 +326,11 @@ extern "C" int mi355r_init(int device) {
         if (env) g.strip_long = (unsigned)atoi(env);
         env = getenv("MI355R_SPLIT_BLEND");
         if (env) g.split_blend = atoi(env) != 0 ? 1 : 0;
-        g.monolithic = getenv("MI355R_MONOLITHIC") != nullptr;
-        if (g.monolithic) g.split_blend = 0;                        /* every pass through the ordered kernel */
-        g.generic_blend = getenv("MI355R_GENERIC_BLEND") != nullptr;
         g.verbose = getenv("MI355R_VERBOSE") != nullptr;
-        env = getenv("MI355R_DEBUG_SKIP");
-        g.debug_skip = env ? atoi(env) : 0;
+        env = getenv("MI355R_CROWD_MIN");
+        if (env) g.crowd_min = (unsigned)std::max(0, atoi(env));
+        env = getenv("MI355R_CROWD_SMALL");
+        if (env) g.crowd_small = std::max(0, std::min(atoi(env), 64));
         env = getenv("MI355R_RECORD_COPIES");
         if (env) g.record_copies = atoi(env) != 0;
         env = getenv("MI355R_REPLAY");
@@ -660,13 +647,10 @@ static int log2_exact(int v) {
     return b;
 }
 
-static void choose_layout(int w, int h, int *flags, int *mbits) {
-    *mbits = 0;
-    static const int layout = getenv("MI355R_TEX_LAYOUT") ? atoi(getenv("MI355R_TEX_LAYOUT")) : 0;
+/* images whose sides are multiples of 8 are stored in 8x8-texel tiles (texel_index, shade.h) */
+static void choose_layout(int w, int h, int *flags) {
     *flags &= ~RZ_TEX_LAYOUT;
-    if (layout == 1 && w % 16 == 0 && h % 16 == 0) *flags |= RZ_TEX_TILE16;
-    else if (layout == 2 && w % 8 == 0 && h % 8 == 0) *flags |= RZ_TEX_MORTON;
-    else if (w % 8 == 0 && h % 8 == 0 && w < (1 << 24) && h < (1 << 24)) *flags |= RZ_TEX_TILED;   /* texel_index multiplies tile counts with 24 bits */
+    if (w % 8 == 0 && h % 8 == 0 && w < (1 << 24) && h < (1 << 24)) *flags |= RZ_TEX_TILED;   /* texel_index multiplies tile counts with 24 bits */
 }
 
 static void drop_derived_handles();
@@ -681,7 +665,6 @@ extern "C" rz_texture *texture_create(int width, int height) {      /* texture.c
     t->d_data = nullptr;
     t->d_bytes = 0;
     t->flags = 0;
-    t->mbits = 0;
     t->device_stale = true;
     t->host_stale = false;
     t->write_lane = -1;
@@ -715,8 +698,8 @@ extern "C" void texture_invalidate(rz_texture *p) {
 static void device_image(Tex *t, int flags_wanted, size_t texel_bytes) {
     /* whole 16-byte units: the samplers read the aligned 16 bytes around a 4-byte texel */
     size_t bytes = ((size_t)t->pub.width * t->pub.height * texel_bytes + 15) & ~(size_t)15;
-    int flags = flags_wanted, mbits = 0;
-    choose_layout(t->pub.width, t->pub.height, &flags, &mbits);
+    int flags = flags_wanted;
+    choose_layout(t->pub.width, t->pub.height, &flags);
     if (t->d_bytes != bytes) {
         /* the device address changes: cube / IBL handle tables that embed it are rebuilt */
         if (t->d_data) { graphics_flush(); sync_stream(); drop_derived_handles(); HIP_OK(hipFree(t->d_data)); }
@@ -725,7 +708,6 @@ static void device_image(Tex *t, int flags_wanted, size_t texel_bytes) {
     }
     t->image_version++;             /* every caller is about to write the image */
     t->flags = flags;
-    t->mbits = mbits;
 }
 
 /* ---- lossless 4-byte device formats (rz_device.h) --------------------------
@@ -837,7 +819,7 @@ static void upload_texture(Tex *t) {
     HIP_OK(hipMalloc((void**)&staging, bytes));
     HIP_OK(hipMemcpyAsync(staging, t->pub.buffer, bytes, hipMemcpyHostToDevice, g.stream));
     rz_texture_tile_kernel<<<dim3((w + 15) / 16, (h + 15) / 16), dim3(256), 0, g.stream>>>(
-        staging, (float4*)t->d_data, w, h, t->flags, t->mbits);
+        staging, (float4*)t->d_data, w, h, t->flags);
     HIP_OK(hipGetLastError());
     HIP_OK(hipStreamSynchronize(g.stream));
     HIP_OK(hipFree(staging));
@@ -875,7 +857,6 @@ extern "C" rz_texture *texture_create_packed(int width, int height, int format, 
     t->d_data = nullptr;
     t->d_bytes = 0;
     t->flags = 0;
-    t->mbits = 0;
     t->write_lane = -1;
     t->write_event = nullptr;
     g.texs.insert(t);
@@ -905,7 +886,7 @@ extern "C" void texture_sync(rz_texture *p) {
     float4 *staging;
     HIP_OK(hipMalloc((void**)&staging, bytes));
     rz_texture_untile_kernel<<<dim3((w + 15) / 16, (h + 15) / 16), dim3(256), 0, g.stream>>>(
-        t->d_data, staging, w, h, t->flags, t->mbits);
+        t->d_data, staging, w, h, t->flags);
     HIP_OK(hipGetLastError());
     HIP_OK(hipMemcpyAsync(t->pub.buffer, staging, bytes, hipMemcpyDeviceToHost, g.stream));
     sync_stream();
@@ -1686,7 +1667,6 @@ static void plan_pass(PassPlan &pl, size_t &total) {
         pl.families |= 1 << pd.rec.family;
         if (pd.rec.family != RZ_FAMILY_SKYBOX && !(pd.rec.flags & RZ_DRAW_NARROW_TEXELS)) pl.narrow_texels = false;
     }
-    if (g.monolithic) pl.has_blend = true;
     total = (total + 255) & ~(size_t)255;
     pl.off_draws = total;
     total += sizeof(DrawRec) * D;
@@ -1858,8 +1838,9 @@ static void prepare_batch(const Batch &b, const FlushRecord &fr, bool reserve_on
     /* (32x8 tiles, or the two 16x8 blocks of each that rz_strip_kernel lists) */
     const size_t queue_capacity = (2 * tiles + RZ_QUEUE_WAYS - 1) / RZ_QUEUE_WAYS + b.members.size();    /* every pass's share rounded up */
     reserve(L.tile_listed, tiles, st);
-    reserve(L.queue, 3 * RZ_QUEUE_WAYS * queue_capacity, st);           /* blinn, pbr, RZ_ORDERED_LIST */
-    reserve(L.queue_counts, 3 * RZ_QUEUE_WAYS * RZ_QUEUE_PAD, st);
+    reserve(L.queue, RZ_LISTS * RZ_QUEUE_WAYS * queue_capacity, st);    /* blinn, pbr, RZ_ORDERED_LIST, RZ_VISIBILITY_LIST */
+    reserve(L.queue_counts, RZ_LISTS * RZ_QUEUE_WAYS * RZ_QUEUE_PAD + RZ_QUEUE_PAD, st);     /* the last: the number of crowded bins' squares */
+    reserve(L.crowd_list, 16 * bins, st);
     reserve(L.bin_list, lists, st);
     reserve(L.bin_boxes, lists, st);
     if (!b.has_blend || splits_blend(tiles, b.members.size())) reserve(L.ref, pixels, st);
@@ -1918,7 +1899,10 @@ static void prepare_batch(const Batch &b, const FlushRecord &fr, bool reserve_on
         P.ref = L.ref.ptr ? L.ref.ptr + ref_off : nullptr;
         P.ref_scanned = (b.families & (1 << RZ_FAMILY_SKYBOX)) != 0;
         P.counters = g.counting ? g.d_counters : nullptr;
-        P.debug_skip = g.debug_skip;
+        P.scan_list = !b.has_blend ? -1 : splits_blend(tiles, b.members.size()) ? (int)RZ_VISIBILITY_LIST : (int)RZ_ORDERED_LIST;
+        P.crowd_min = (b.has_blend || g.counting) ? 0u : g.crowd_min;
+        P.crowd_small = g.crowd_small;
+        P.crowd_list = L.crowd_list.ptr;
         P.micro_area = g.micro_area;
         P.micro_min_list = g.micro_min_list;
         P.tiles_x = (W + RZ_TILE_W - 1) / RZ_TILE_W;
@@ -1977,7 +1961,6 @@ static void launch_batch(const Batch &b, const std::vector<PassPlan> &plans, cha
     const dim3 tiles((unsigned)max_tiles_x, (unsigned)max_tiles_y, n);
     /* tile_order (kernels.h): whole bins, i.e. an even number of tile columns and a multiple of a bin's tile rows */
     const unsigned bin_columns = (unsigned)(max_tiles_x + 1) / 2, bin_rows = (unsigned)(max_tiles_y * RZ_TILE_H + RZ_BIN - 1) / RZ_BIN;
-    const dim3 ordered_tiles(bin_columns * 2 * n, bin_rows * (RZ_BIN / RZ_TILE_H));
     /* the shade kernels stride over work lists: enough workgroups to fill the device, no more */
     size_t batch_tiles = 0;
     for (size_t i : b.members)
@@ -1995,7 +1978,8 @@ static void launch_batch(const Batch &b, const std::vector<PassPlan> &plans, cha
         }
         if (L.bin_range.cap < bins || (g.sky_bins && L.sky_bins.cap < bins)) fatal("per-bin scratch of lane %d is smaller than the batch it is about to run", b.lane);
         const bool uses_ref = !(b.has_blend && !splits_blend(batch_tiles, n));
-        if (L.queue_counts.cap < 3 * RZ_QUEUE_WAYS * RZ_QUEUE_PAD || L.queue.cap < 3 * RZ_QUEUE_WAYS * (size_t)queue_capacity ||
+        if (L.crowd_list.cap < 16 * bins) fatal("the crowded-bin list of lane %d is smaller than the batch it is about to run", b.lane);
+        if (L.queue_counts.cap < RZ_LISTS * RZ_QUEUE_WAYS * RZ_QUEUE_PAD + RZ_QUEUE_PAD || L.queue.cap < RZ_LISTS * RZ_QUEUE_WAYS * (size_t)queue_capacity ||
             L.tile_listed.cap < batch_tiles || L.bin_boxes.cap < L.bin_list.cap || (uses_ref && (!L.ref.ptr || L.ref.cap < pixels)) || L.tri.cap < tris || L.bbox.cap < tris)
             fatal("scratch of lane %d is smaller than the batch it is about to run", b.lane);
     }
@@ -2014,35 +1998,31 @@ static void launch_batch(const Batch &b, const std::vector<PassPlan> &plans, cha
     /* a pass with blended draws: either everything in the ordered kernel (visibility and shading
      * together, fragment stacks), or visibility first, the ordered kernel for the tiles where
      * blended fragments pile up and the shade kernels for the rest */
-    const bool one_family = !g.generic_blend;
-    const int only = !one_family ? -1 : b.families == (1 << RZ_FAMILY_BLINN) ? 0 : b.families == (1 << RZ_FAMILY_PBR) ? 1 : -1;
-    bool in_strips = false, sky_done = false, sky_bins = false;       /* the shade lists hold 16x8 blocks; skybox fragments are shaded already */
+    const int only = b.families == (1 << RZ_FAMILY_BLINN) ? 0 : b.families == (1 << RZ_FAMILY_PBR) ? 1 : -1;
+    bool in_strips = false, sky_bins = false;       /* the shade lists hold 16x8 blocks; bins with nothing but sky are rz_sky_kernel's */
     if (b.has_blend && !splits_blend(batch_tiles, n)) {
-        auto kernel = rz_raster_kernel<false>;
-        if (only == 0) kernel = narrow ? rz_raster_kernel<false, 0, true> : rz_raster_kernel<false, 0, false>;
-        if (only == 1) kernel = narrow ? rz_raster_kernel<false, 1, true> : rz_raster_kernel<false, 1, false>;
-        kernel<<<ordered_tiles, dim3(256), 0, st>>>(
-            passes, L.tri.ptr, L.fan_tri.ptr, L.bin_list.ptr, L.vary.ptr, L.fan_vary.ptr, db, L.bin_range.ptr, n);
-        snprintf(g.last_raster_kernel, sizeof g.last_raster_kernel, "rz_raster_kernel<false, %d, %s>", only, narrow && only >= 0 ? "true" : "false");
+        /* over the tiles of the bins that are not empty (listed by rz_bin_scan_kernel) */
+        auto kernel = rz_raster_list_kernel<-1, false>;
+        if (only == 0) kernel = narrow ? rz_raster_list_kernel<0, true> : rz_raster_list_kernel<0, false>;
+        if (only == 1) kernel = narrow ? rz_raster_list_kernel<1, true> : rz_raster_list_kernel<1, false>;
+        kernel<<<shade_grid, dim3(256), 0, st>>>(
+            passes, L.tri.ptr, L.fan_tri.ptr, L.bin_list.ptr, L.vary.ptr, L.fan_vary.ptr, db, L.bin_range.ptr,
+            L.queue.ptr, L.queue_counts.ptr, queue_capacity);
+        snprintf(g.last_raster_kernel, sizeof g.last_raster_kernel, "rz_raster_list_kernel<%d, %s>", only, narrow && only >= 0 ? "true" : "false");
         stamp(); stamp(); stamp(); stamp();
     } else {
         if (b.has_blend) {
-            rz_visibility_kernel<2, true><<<ordered_tiles, dim3(128), 0, st>>>(passes, L.bin_list.ptr, L.bin_boxes.ptr, L.vary.ptr, L.fan_vary.ptr, db, L.bin_range.ptr, n);
+            rz_blend_visibility_kernel<<<shade_grid, dim3(128), 0, st>>>(passes, L.bin_list.ptr, L.vary.ptr, L.fan_vary.ptr, db, L.bin_range.ptr,
+                                                                     L.queue.ptr, L.queue_counts.ptr, queue_capacity);
             auto kernel = rz_raster_list_kernel<-1, false>;
             if (only == 0) kernel = narrow ? rz_raster_list_kernel<0, true> : rz_raster_list_kernel<0, false>;
             if (only == 1) kernel = narrow ? rz_raster_list_kernel<1, true> : rz_raster_list_kernel<1, false>;
             kernel<<<shade_grid, dim3(256), 0, st>>>(
                 passes, L.tri.ptr, L.fan_tri.ptr, L.bin_list.ptr, L.vary.ptr, L.fan_vary.ptr, db, L.bin_range.ptr,
                 L.queue.ptr, L.queue_counts.ptr, queue_capacity);
-        } else if (g.narrow_raster)
-            rz_raster_kernel<true><<<ordered_tiles, dim3(256), 0, st>>>(
-                passes, L.tri.ptr, L.fan_tri.ptr, L.bin_list.ptr, L.vary.ptr, L.fan_vary.ptr, db, L.bin_range.ptr, n);
-        else if (g.pixels_per_lane == 4)
-            rz_visibility_kernel<4><<<ordered_tiles, dim3(64), 0, st>>>(passes, L.bin_list.ptr, L.bin_boxes.ptr, L.vary.ptr, L.fan_vary.ptr, db, L.bin_range.ptr, n);
-        else if (g.strip == 0)
-            rz_visibility_kernel<2><<<ordered_tiles, dim3(128), 0, st>>>(passes, L.bin_list.ptr, L.bin_boxes.ptr, L.vary.ptr, L.fan_vary.ptr, db, L.bin_range.ptr, n);
-        else {
-            /* visibility and skybox shading together, a strip of 16x8 blocks per wave: the default */
+            snprintf(g.last_raster_kernel, sizeof g.last_raster_kernel, "rz_blend_visibility_kernel");
+        } else {
+            /* visibility, a strip of 16x8 blocks per wave */
             in_strips = true;
             uint32_t longest = 0;
             for (size_t i : b.members) longest = std::max(longest, plans[i].fb->longest_list);
@@ -2052,25 +2032,28 @@ static void launch_batch(const Batch &b, const std::vector<PassPlan> &plans, cha
             const int few = b.members.size() <= 2 ? 1 : b.members.size() <= 4 ? 2 : 8;
             const int strip = !g.strip_long ? g.strip : std::min(few, longest >= g.strip_long ? 1 : longest >= g.strip_long / 2 ? std::min(g.strip, 2) : g.strip);
             const unsigned strips_per_bin = RZ_BIN / (8u * strip);
-            sky_done = g.strip_sky;
-            auto kernel = g.strip_sky ? (strip == 8 ? rz_strip_kernel<8, true> : strip == 4 ? rz_strip_kernel<4, true> : strip == 2 ? rz_strip_kernel<2, true> : rz_strip_kernel<1, true>)
-                                      : (strip == 8 ? rz_strip_kernel<8, false> : strip == 4 ? rz_strip_kernel<4, false> : strip == 2 ? rz_strip_kernel<2, false> : rz_strip_kernel<1, false>);
+            auto kernel = strip == 8 ? rz_strip_kernel<8> : strip == 4 ? rz_strip_kernel<4> : strip == 2 ? rz_strip_kernel<2> : rz_strip_kernel<1>;
             /* bins with nothing but skybox triangles are left to rz_sky_kernel */
-            sky_bins = g.sky_bins && !g.strip_sky && g.sky_pixels_per_lane == 2 && (b.families & (1 << RZ_FAMILY_SKYBOX));
+            sky_bins = g.sky_bins && (b.families & (1 << RZ_FAMILY_SKYBOX));
             if (sky_bins) rz_sky_regions_kernel<<<dim3((unsigned)max_bins, n), dim3(64), 0, st>>>(passes, L.bin_list.ptr, L.bin_range.ptr, L.sky_bins.ptr);
             if (g.verbose) fprintf(stderr, "mi355r: batch of %u passes, longest bin list last time %u entries, strips of %d\n", n, longest, strip);
-            snprintf(g.last_raster_kernel, sizeof g.last_raster_kernel, "rz_strip_kernel<%d, %s>", strip, g.strip_sky ? "true" : "false");
+            snprintf(g.last_raster_kernel, sizeof g.last_raster_kernel, "rz_strip_kernel<%d>", strip);
+            /* crowded bins first, a workgroup per bin: the launch is as long as its fullest bin takes */
+            if (g.crowd_min && !g.counting) {
+                size_t batch_bins = 0;
+                for (size_t i : b.members)
+                    batch_bins += (size_t)((plans[i].fb->pub.width + RZ_BIN - 1) / RZ_BIN) * ((plans[i].fb->pub.height + RZ_BIN - 1) / RZ_BIN);
+                rz_crowd_kernel<<<dim3((unsigned)std::min<size_t>(16 * batch_bins, (size_t)g.shade_workgroups / 4)), dim3(64 * RZ_CROWD_WAVES), 0, st>>>(
+                    passes, L.bin_list.ptr, L.bin_boxes.ptr, L.vary.ptr, L.fan_vary.ptr, db, L.bin_range.ptr, L.crowd_list.ptr, L.queue_counts.ptr,
+                    (uint32_t)std::min<size_t>(16 * batch_bins, 0xffffffffu));
+            }
             kernel<<<dim3(bin_columns * 2 * n, bin_rows * strips_per_bin), dim3(128), 0, st>>>(
                 passes, L.bin_list.ptr, L.bin_boxes.ptr, L.vary.ptr, L.fan_vary.ptr, db, L.bin_range.ptr, n, sky_bins ? L.sky_bins.ptr : nullptr);
         }
         stamp();
-        if ((b.families & (1 << RZ_FAMILY_SKYBOX)) && !sky_done) {
-            if (g.sky_pixels_per_lane == 2)     /* four per lane: 11.9 us per frame against 11.1 */
-                rz_sky_kernel<2><<<tiles, dim3(128), 0, st>>>(passes, L.tri.ptr, L.fan_tri.ptr, L.vary.ptr, L.fan_vary.ptr, db, L.ref.ptr,
-                                                              L.bin_list.ptr, sky_bins ? L.sky_bins.ptr : nullptr);
-            else
-                rz_shade_kernel<2><<<tiles, dim3(256), 0, st>>>(passes, L.tri.ptr, L.fan_tri.ptr, L.vary.ptr, L.fan_vary.ptr, db, L.ref.ptr);
-        }
+        if (b.families & (1 << RZ_FAMILY_SKYBOX))
+            rz_sky_kernel<2><<<tiles, dim3(128), 0, st>>>(passes, L.tri.ptr, L.fan_tri.ptr, L.vary.ptr, L.fan_vary.ptr, db, L.ref.ptr,
+                                                          L.bin_list.ptr, sky_bins ? L.sky_bins.ptr : nullptr);
         stamp();
         if (b.families & (1 << RZ_FAMILY_BLINN)) {
             auto kernel = in_strips ? (narrow ? rz_shade_list_kernel<0, true, true> : rz_shade_list_kernel<0, false, true>)
@@ -2403,7 +2386,7 @@ extern "C" int texture_sync_noalloc(rz_texture *p) {
                 return RZ_NOALLOC_NOT_SUBMITTED;
             }
     const int w = t->pub.width, h = t->pub.height;
-    rz_texture_untile_kernel<<<dim3((w + 15) / 16, (h + 15) / 16), dim3(256), 0, st>>>(t->d_data, staging, w, h, t->flags, t->mbits);
+    rz_texture_untile_kernel<<<dim3((w + 15) / 16, (h + 15) / 16), dim3(256), 0, st>>>(t->d_data, staging, w, h, t->flags);
     HIP_OK(hipGetLastError());
     HIP_OK(hipMemcpyAsync(t->pub.buffer, staging, texels * sizeof(float4), hipMemcpyDeviceToHost, st));
     HIP_OK(hipStreamSynchronize(st));
@@ -2824,6 +2807,7 @@ extern "C" void mi355r_inspect_bins(unsigned int *counts, unsigned int *entries)
     size_t out = 0;
     std::vector<BinEntry> list;
     for (size_t b = 0; b < bins; b++) {
+        ranges[b].y &= ~RZ_BIN_CROWDED;
         counts[b] = ranges[b].y;
         list.resize(ranges[b].y);
         if (ranges[b].y)

@@ -2,15 +2,17 @@
  * The gfx950 kernels of the triangle pipeline.  A launch covers a batch of
  * passes (a pass = draws into one framebuffer; grid y or z = pass):
  *
- *   rz_vertex_kernel       vertex shaders incl. skeletal skinning, 1 thread / vertex
- *   rz_setup_kernel        cull -> viewport -> bbox for unclipped triangles, 1 thread / triangle
+ *   rz_vertex_kernel       vertex shaders incl. skeletal skinning, 1 thread / vertex; cull -> viewport -> bbox of
+ *                          triangles that need no clipping
  *   rz_clip_kernel         homogeneous clipping -> fan for the rest, 1 wave / triangle
  *   rz_bin_count / _scan / _fill_kernel   ordered lists per 64x64-pixel bin
- *   rz_visibility_kernel   passes without blending: coverage + depth, leaves depth and one
- *                          fragment reference per pixel; 1 wave / 16x8 pixels
+ *   rz_strip_kernel        passes without blending: coverage + depth, leaves depth and one
+ *                          fragment reference per pixel; 1 wave / strip of 16x8-pixel blocks
  *   rz_sky_kernel, rz_shade_list_kernel   per-family fragment shading of those references
- *   rz_raster_kernel / rz_raster_list_kernel   passes with blending: coverage, depth and
- *                          ordered in-kernel shading; 1 wave / 8x8 pixels
+ *   rz_raster_list_kernel  passes with blending: coverage, depth and ordered in-kernel shading; 1 wave / 8x8 pixels,
+ *                          over a list of tiles
+ *   rz_blend_visibility_kernel   the same passes in large framebuffers: visibility first, ordered shading only
+ *                          for the tiles where blended fragments pile up
  *   rz_clear_kernel, rz_*_to_texture(s)_kernel, rz_texture_*tile*_kernel   framebuffer / texture utilities
  *
  * All arithmetic that decides coverage, depth or colour follows the reference
@@ -21,14 +23,6 @@
 
 #include <type_traits>
 #include "shade.h"
-
-/* Timing experiments leave parts of the rasterisers out (PassParams::debug_skip, MI355R_DEBUG_SKIP).  The
- * switch exists only in builds made for that (-DRZ_MEASURE): the library's kernels do not test it. */
-#ifdef RZ_MEASURE
-#define RZ_SKIP(P) ((P).debug_skip)
-#else
-#define RZ_SKIP(P) 0
-#endif
 
 /* largest d with first_tri[d] <= t */
 RZ_DEV int find_draw(const uint32_t *first_tri, int num_draws, uint32_t t) {
@@ -76,7 +70,7 @@ __global__ void __launch_bounds__(256) rz_begin_kernel(const PassParams *__restr
     /* the pass's device-written scalars start at zero -- unless another pass of the flush ran out of
      * scratch and this one may depend on it: then it is marked to be left out and run again later */
     if (gv < 8u) P.control[gv] = (gv == 2u && P.level > 0 && *P.flush_flag != 0u) ? (uint32_t)RZ_ERR_SKIPPED : 0u;
-    if (blockIdx.y == 0 && gv < 3u * RZ_QUEUE_WAYS) P.queue_counts[gv * RZ_QUEUE_PAD] = 0;    /* ... and the batch's work-list lengths */
+    if (blockIdx.y == 0 && gv <= RZ_LISTS * RZ_QUEUE_WAYS) P.queue_counts[gv * RZ_QUEUE_PAD] = 0;   /* ... and the batch's work-list lengths (the last: its crowded bins) */
     for (uint32_t t = gv; t < (uint32_t)(P.tiles_x * P.tiles_y); t += gridDim.x * 256u) P.tile_listed[t] = 0;
     {   /* ... and the pass's (chunk, bin) matrix, which rz_bin_count_kernel adds into */
         const uint32_t cells = (((uint32_t)P.num_tris + 63u) / 64u) * (uint32_t)(P.bins_x * P.bins_y);
@@ -691,6 +685,7 @@ RZ_DEV int wave_max_i(int v) {
                max(__builtin_amdgcn_readlane(v, 47), __builtin_amdgcn_readlane(v, 63)));
 }
 
+#define RZ_CROWD_FINE 2048u         /* list entries from which a crowded bin is cut into 16x16 squares (rz_crowd_kernel) */
 /* 1024 threads = 64 bins x 16 segments of the chunk range */
 #define RZ_SCAN_SEGMENTS 16
 __global__ void __launch_bounds__(64 * RZ_SCAN_SEGMENTS) rz_bin_scan_kernel(const PassParams *__restrict__ passes) {
@@ -723,6 +718,7 @@ __global__ void __launch_bounds__(64 * RZ_SCAN_SEGMENTS) rz_bin_scan_kernel(cons
     }
     /* every segment's thread of a bin needs the list's start: segment 0 reserves it */
     __syncthreads();
+    bool crowded = false;
     if (segment == 0 && bin < bins) {
         uint32_t start = total ? atomicAdd(&P.control[1], total) : 0u;
         if (start + total > P.bin_capacity) {      /* control[1] still ends up as the entries the pass needs */
@@ -730,11 +726,35 @@ __global__ void __launch_bounds__(64 * RZ_SCAN_SEGMENTS) rz_bin_scan_kernel(cons
             atomicOr(P.flush_flag, 1u);
             total = 0;
         }
-        P.bin_range[bin] = make_uint2(start, total);
+        /* a crowded bin goes on the batch's list for rz_crowd_kernel and is marked for rz_strip_kernel to leave alone */
+        crowded = P.crowd_min != 0u && total >= P.crowd_min;
+        if (crowded) {              /* its squares: 4 of 32x32 pixels, or 16 of 16x16 (rz_crowd_kernel) */
+            const uint32_t fine = total >= RZ_CROWD_FINE ? 1u : 0u, squares = fine ? 16u : 4u;
+            const uint32_t at = atomicAdd(&P.queue_counts[RZ_CROWD_COUNT_AT], squares);
+            for (uint32_t q = 0; q < squares; q++)
+                P.crowd_list[at + q] = make_uint2(((uint32_t)blockIdx.y << 16) | (uint32_t)bin, q | (fine << 8));
+        }
+        P.bin_range[bin] = make_uint2(start, total | (crowded ? RZ_BIN_CROWDED : 0u));
         s_part[0][threadIdx.x & 63] = total ? start : 0xffffffffu;
+        /* a pass with blended draws: the bin's 32x8 tiles go on the work list of the kernel that rasterises it, unless
+         * there is nothing for that kernel to do in them */
+        if (P.scan_list >= 0 && (total != 0u || P.clear_color_pending || P.clear_depth_pending)) {
+            const uint32_t tx_first = (uint32_t)(bin % P.bins_x) * (RZ_BIN / RZ_TILE_W), ty_first = (uint32_t)(bin / P.bins_x) * (RZ_BIN / RZ_TILE_H);
+            for (uint32_t ty = ty_first; ty < min(ty_first + RZ_BIN / RZ_TILE_H, (uint32_t)P.tiles_y); ty++)
+                for (uint32_t tx = tx_first; tx < min(tx_first + RZ_BIN / RZ_TILE_W, (uint32_t)P.tiles_x); tx++) {
+                    const uint32_t tile = ty * (uint32_t)P.tiles_x + tx;
+                    /* by the tile's index in the batch: no part can get more than its even share */
+                    const uint32_t part = (uint32_t)P.scan_list * RZ_QUEUE_WAYS + ((P.tile_off + tile) & (RZ_QUEUE_WAYS - 1u));
+                    const uint32_t at = atomicAdd(&P.queue_counts[part * RZ_QUEUE_PAD], 1u);
+                    if (at < P.queue_capacity)
+                        P.queue[(size_t)part * P.queue_capacity + at] = ((uint32_t)blockIdx.y << 20) | (ty << 9) | tx;
+                    else
+                        atomicOr(&P.control[2], (uint32_t)RZ_ERR_QUEUE_OVERFLOW);
+                }
+        }
     }
-    if (segment == 0) {             /* the pass's longest list, for the host's choice of strip height next time */
-        uint32_t longest = bin < bins ? total : 0u;
+    if (segment == 0) {             /* the pass's longest list among those rz_strip_kernel walks, for the host's choice of strip height next time */
+        uint32_t longest = (bin < bins && !crowded) ? total : 0u;
         longest = (uint32_t)wave_max_i((int)longest);           /* entry counts stay far below 2^31 */
         if ((threadIdx.x & 63) == 0 && longest) atomicMax(&P.control[4], longest);
     }
@@ -1173,18 +1193,16 @@ RZ_DEV bool block_outside(float4 c0, float4 c1, float x0, float x1, float y0, fl
 }
 
 
-/* Rasteriser.  SPLIT = true: the pass has no blended draw, so one reference per
- * pixel is enough; the kernel resolves visibility only and leaves depth plus the
- * reference of the visible fragment for the per-family shade kernels.
- * SPLIT = false: general form with the two-level stack, shading in-kernel; FAMILY >= 0 when every
- * draw of every pass of the batch is of that one family (only its shader is compiled in, which
- * halves the registers of a blinn-only kernel), NARROW when all their images are 4-byte formats.
+/* The ordered rasteriser, for a pass (or the part of a pass) from its first blended draw on: coverage, depth
+ * and shading in one kernel, with the two-level stack above.  FAMILY >= 0 when every draw of every pass of the
+ * batch is of that one family (only its shader is compiled in, which halves the registers of a blinn-only
+ * kernel), NARROW when all their images are 4-byte formats.
  *
  * The read-only tables come in as separate const __restrict__ arguments so
  * that wave-uniform reads of them are issued as scalar loads.  Per 64 list
  * entries the candidates' records are fetched lane-parallel (one memory round
  * trip for all of them) and then broadcast one at a time in list order. */
-template <bool SPLIT, int FAMILY, bool NARROW>
+template <int FAMILY, bool NARROW>
 RZ_DEV void raster_tile(const PassParams &P, const uint32_t pass_index, const uint32_t tile_x, const uint32_t tile_y,
         const TriRec *__restrict__ tri_base, const TriRec *__restrict__ fan_base,
         const BinEntry *__restrict__ list_base,
@@ -1201,7 +1219,6 @@ RZ_DEV void raster_tile(const PassParams &P, const uint32_t pass_index, const ui
     const DrawRec *draw_table = (const DrawRec*)(upload_base + P.draws_off);
     const uint2 *bin_range_table = bin_range_base + P.bin_off;
     /* A workgroup owns a 32x8-pixel tile, wave w its w-th 8x8 block, lane = pixel. */
-    if (RZ_SKIP(P) == 3) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int tx0 = (int)tile_x * RZ_TILE_W, ty0 = (int)tile_y * RZ_TILE_H;
     const int bx0 = tx0 + wave * 8, by0 = ty0;
@@ -1211,16 +1228,13 @@ RZ_DEV void raster_tile(const PassParams &P, const uint32_t pass_index, const ui
     const int bin = (ty0 / RZ_BIN) * P.bins_x + tx0 / RZ_BIN;
     const uint2 range = bin_range_table[bin];          /* {first entry, entries} */
     const uint32_t count = range.y;
-    if (count == 0 && !P.clear_color_pending && !P.clear_depth_pending) {   /* uniform over the workgroup */
-        if (SPLIT && valid) P.ref[pixel] = RZ_REF_NONE;
-        return;
-    }
+    if (count == 0 && !P.clear_color_pending && !P.clear_depth_pending) return;     /* uniform over the workgroup */
 
     float zcur = P.clear_depth;
     uint32_t ccur = P.clear_color;
     if (valid) {
         if (!P.clear_depth_pending) zcur = P.depth[pixel];
-        if (!SPLIT && !P.clear_color_pending) ccur = P.color[pixel];
+        if (!P.clear_color_pending) ccur = P.color[pixel];
     }
     const BinEntry *list = list_table + range.x;
     const int bx1 = bx0 + 7, by1 = by0 + 7;
@@ -1229,17 +1243,15 @@ RZ_DEV void raster_tile(const PassParams &P, const uint32_t pass_index, const ui
     uint32_t ref0 = RZ_REF_NONE, ref1 = RZ_REF_NONE;
     int depth_of_stack = 0;
 
-    /* iterator over this block's triangles, in list order */
+    /* iterator over this block's triangles, in list order.  Every lane holds one WHOLE entry of the current group
+     * of 64 (five 16-byte loads of consecutive addresses: one memory round trip per group); the entries that survive
+     * the block test are then taken one at a time, their record passed round from the lane that holds it with
+     * readlane.  Fetched through scalar loads when their turn came, every survivor cost a memory round trip of its
+     * own -- in a bin where many do survive (layers of hair over each other) that was what the kernel's time went to. */
     uint32_t base = 0;
     unsigned long long todo = 0;
-    /* this lane's candidate of the NEXT group of 64 entries (edge data and box), loaded one group
-     * ahead so that the walk over a long list never waits for memory */
-    float4 n0 = make_float4(0, 0, 0, 0), n1 = n0;
-    float2 nbox = make_float2(0, 0);
-    if (lane < count) {
-        const float4 *e = (const float4*)&list[lane];              /* reference + record, 80 bytes */
-        n0 = e[1]; n1 = e[2]; nbox = *(const float2*)((const char*)e + 72);
-    }
+    float4 c1 = make_float4(0, 0, 0, 0), c2 = c1, c3 = c1, c4 = c1;
+    uint32_t cref = 0;
     bool have = false, exhausted = false;
     TriRec r;
     uint32_t ref = 0;
@@ -1252,32 +1264,33 @@ RZ_DEV void raster_tile(const PassParams &P, const uint32_t pass_index, const ui
         while (true) {
             if (!have) {
                 if (todo) {
-                    /* the wave-uniform entry index makes these scalar loads */
-                    const BinEntry *e = &list[base - 64u + (uint32_t)(__ffsll((long long)todo) - 1)];
+                    const int L = __ffsll((long long)todo) - 1;
                     todo &= todo - 1;
-                    ref = e->tri;
-                    r = e->rec;
+                    ref = (uint32_t)RZ_BCAST_I(cref, L);
+                    r.ax = RZ_BCAST_F(c1.x, L); r.ay = RZ_BCAST_F(c1.y, L); r.abx = RZ_BCAST_F(c1.z, L); r.aby = RZ_BCAST_F(c1.w, L);
+                    r.acx = RZ_BCAST_F(c2.x, L); r.acy = RZ_BCAST_F(c2.y, L); r.factor = RZ_BCAST_F(c2.z, L); r.z[0] = RZ_BCAST_F(c2.w, L);
+                    r.z[1] = RZ_BCAST_F(c3.x, L); r.z[2] = RZ_BCAST_F(c3.y, L); r.rw[0] = RZ_BCAST_F(c3.z, L); r.rw[1] = RZ_BCAST_F(c3.w, L);
+                    r.rw[2] = RZ_BCAST_F(c4.x, L); r.meta = (uint32_t)RZ_BCAST_I(__float_as_uint(c4.y), L);
+                    r.bx = (uint32_t)RZ_BCAST_I(__float_as_uint(c4.z), L); r.by = (uint32_t)RZ_BCAST_I(__float_as_uint(c4.w), L);
                     have = true;
                 } else {
-                    if (base >= count || RZ_SKIP(P) == 4) { exhausted = true; break; }
-                    const float4 c0 = n0, c1 = n1;
-                    const float2 cbox = nbox;
+                    if (base >= count) { exhausted = true; break; }
                     const bool present = base + lane < count;
-                    base += 64u;
-                    if (base + lane < count) {
-                        const float4 *e = (const float4*)&list[base + lane];
-                        n0 = e[1]; n1 = e[2]; nbox = *(const float2*)((const char*)e + 72);
+                    if (present) {
+                        const float4 *e = (const float4*)&list[base + lane];          /* reference + record, 80 bytes */
+                        cref = __float_as_uint(e[0].x);
+                        c1 = e[1]; c2 = e[2]; c3 = e[3]; c4 = e[4];
                     }
+                    base += 64u;
                     bool hit = false;
                     if (present) {
-                        hit = box_overlaps(make_uint2(__float_as_uint(cbox.x), __float_as_uint(cbox.y)), bx0, by0, bx1, by1);
-                        if (hit) hit = !block_outside(c0, c1, cx0, cx1, cy0, cy1);
+                        hit = box_overlaps(make_uint2(__float_as_uint(c4.z), __float_as_uint(c4.w)), bx0, by0, bx1, by1);
+                        if (hit) hit = !block_outside(c1, c2, cx0, cx1, cy0, cy1);
                     }
                     todo = __ballot(hit);
                     continue;
                 }
             }
-            if (RZ_SKIP(P) >= 2) { have = false; continue; }
             /* the triangle in r against this block */
             int x0 = (int)(r.bx & 0xffffu), x1 = (int)(r.bx >> 16);
             int y0 = (int)(r.by & 0xffffu), y1 = (int)(r.by >> 16);
@@ -1288,7 +1301,7 @@ RZ_DEV void raster_tile(const PassParams &P, const uint32_t pass_index, const ui
             float depth = r.z[0] * w0 + r.z[1] * w1 + r.z[2] * w2;                        /* :403-408 */
             bool pass = inside && depth <= zcur;                                          /* :523 */
             if (!__any(pass)) { have = false; continue; }
-            const bool blend = !SPLIT && RZ_META_BLEND(r.meta) != 0;
+            const bool blend = RZ_META_BLEND(r.meta) != 0;
             if (blend && __any(pass && depth_of_stack == 2)) { stack_full = true; break; }
             if (P.counters) {       /* fragments the reference would shade: [2] all, [6] skybox, [7] blended */
                 unsigned long long n = (unsigned long long)__popcll(__ballot(pass));
@@ -1319,15 +1332,13 @@ RZ_DEV void raster_tile(const PassParams &P, const uint32_t pass_index, const ui
                 zcur = depth;
                 if (blend && depth_of_stack == 1) { ref1 = ref; depth_of_stack = 2; }
                 else if (blend && depth_of_stack == 0) { ref0 = ref; depth_of_stack = 1; }
-                else if (!blend) { ref0 = SPLIT ? (ref | (RZ_META_FAMILY(r.meta) << 28)) : ref; depth_of_stack = 1; }
+                else if (!blend) { ref0 = ref; depth_of_stack = 1; }
             }
             have = false;
         }
-        if (SPLIT) break;
-
         /* ---- phase B: resolve the stacks, bottom level first */
         for (int level = 0; level < 2; level++) {
-            bool want = depth_of_stack > level && RZ_SKIP(P) == 0;
+            bool want = depth_of_stack > level;
             if (!__any(want)) break;
             TriRec m;
             const float *m0 = vary_table, *m1 = vary_table, *m2 = vary_table;
@@ -1341,39 +1352,7 @@ RZ_DEV void raster_tile(const PassParams &P, const uint32_t pass_index, const ui
 
     if (valid) {
         P.depth[pixel] = zcur;
-        if (SPLIT) {
-            /* the shade kernels write the colour of every pixel that has a fragment */
-            P.ref[pixel] = depth_of_stack ? ref0 : RZ_REF_NONE;
-            if (P.clear_color_pending && !depth_of_stack) P.color[pixel] = ccur;
-        } else {
-            P.color[pixel] = ccur;
-        }
-    }
-    if (SPLIT) {
-        /* Blinn and pbr fragments usually cover a small part of the screen: every tile that holds
-         * some goes on that family's work list (all passes of the batch together), and the shade
-         * kernel of the family walks the list.  The first wave of a tile to find such a fragment
-         * appends the tile (tile_listed keeps who was first); waves without any pay nothing.  A
-         * list is kept in RZ_QUEUE_WAYS parts, chosen by the tile's index, with counters a cache
-         * line apart, so that the appends of a whole batch do not pile up on one counter.  Skybox
-         * fragments are found by scanning the tiles. */
-        const uint32_t family = (ref0 >> 28) & 3u;                  /* 3 = no fragment */
-        for (uint32_t f = 0; f < 2; f++) {
-            if (!__any(depth_of_stack && family == f)) continue;
-            if (lane == 0) {
-                const uint32_t tile = tile_y * (uint32_t)P.tiles_x + tile_x;
-                const uint32_t before = atomicOr(&P.tile_listed[tile], 1u << f);
-                if (!(before >> f & 1u)) {
-                    /* by the tile's index in the batch: no part can get more than its even share */
-                    const uint32_t part = f * RZ_QUEUE_WAYS + ((P.tile_off + tile) & (RZ_QUEUE_WAYS - 1u));
-                    const uint32_t at = atomicAdd(&P.queue_counts[part * RZ_QUEUE_PAD], 1u);
-                    if (at < P.queue_capacity)
-                        P.queue[(size_t)part * P.queue_capacity + at] = (pass_index << 20) | (tile_y << 9) | tile_x;
-                    else
-                        atomicOr(&P.control[2], (uint32_t)RZ_ERR_QUEUE_OVERFLOW);
-                }
-            }
-        }
+        P.color[pixel] = ccur;
     }
 }
 
@@ -1401,21 +1380,11 @@ RZ_DEV TileOrder tile_order(uint32_t num_passes, uint32_t rows_per_bin) {
     return o;
 }
 
-/* over every tile of every pass (tile_order) */
-template <bool SPLIT, int FAMILY = -1, bool NARROW = false>
-__global__ void __launch_bounds__(256) rz_raster_kernel(const PassParams *__restrict__ passes,
-        const TriRec *__restrict__ tri_base, const TriRec *__restrict__ fan_base,
-        const BinEntry *__restrict__ list_base,
-        const float *__restrict__ vary_base, const float *__restrict__ fan_vary_base,
-        const char *__restrict__ upload_base, const uint2 *__restrict__ bin_range_base, uint32_t num_passes) {
-    const TileOrder o = tile_order(num_passes, RZ_BIN / RZ_TILE_H);
-    const PassParams P = passes[o.pass];              /* by value: one burst of scalar loads up front, not one wait per field */
-    raster_tile<SPLIT, FAMILY, NARROW>(P, o.pass, o.column, o.row, tri_base, fan_base, list_base, vary_base, fan_vary_base,
-                                       upload_base, bin_range_base);
-}
-
-/* over the batch's list of tiles that need ordered shading (RZ_ORDERED_LIST, filled by
- * rz_visibility_kernel<.., true>): a fixed number of workgroups strides over it */
+/* over the batch's list of tiles that need ordered shading (RZ_ORDERED_LIST: every tile of the passes' bins that
+ * are not empty, listed by rz_bin_scan_kernel, or -- large framebuffers -- the tiles rz_blend_visibility_kernel
+ * found blended fragments piling up in): a fixed number of workgroups strides over it.  Most of a frame's bins
+ * hold nothing of a blended pass; a wave per tile of the whole frame spent the launch on starting waves that
+ * read their pass's parameters and left (a million of them for 32 frames at 1080p). */
 template <int FAMILY, bool NARROW>
 __global__ void __launch_bounds__(256) rz_raster_list_kernel(const PassParams *__restrict__ passes,
         const TriRec *__restrict__ tri_base, const TriRec *__restrict__ fan_base,
@@ -1432,32 +1401,30 @@ __global__ void __launch_bounds__(256) rz_raster_list_kernel(const PassParams *_
         if (index >= (uint32_t)__builtin_amdgcn_readlane((int)my_count, (int)part)) continue;
         const uint32_t item = queue_base[(size_t)(RZ_ORDERED_LIST * RZ_QUEUE_WAYS + part) * queue_capacity + index];
         const PassParams P = passes[item >> 20];
-        raster_tile<false, FAMILY, NARROW>(P, item >> 20, item & 511u, (item >> 9) & 2047u, tri_base, fan_base, list_base, vary_base,
-                                           fan_vary_base, upload_base, bin_range_base);
+        raster_tile<FAMILY, NARROW>(P, item >> 20, item & 511u, (item >> 9) & 2047u, tri_base, fan_base, list_base, vary_base,
+                                    fan_vary_base, upload_base, bin_range_base);
     }
 }
 
-/* K4b  visibility only, for passes without blending (what rz_raster_kernel<true> computes), two
- * (PPL = 2) or four pixels per lane: a wave owns a block of 8*PPL x 8 pixels (lane = the pixel at
- * (lane & 7, lane >> 3) and those 8, 16, .. to its right), a workgroup of 4/PPL waves a 32x8 tile.
- * A fraction 1/PPL of the waves walk the lists, cull candidates and fetch survivors compared with
- * one pixel per lane; only the per-pixel arithmetic is the same.  Leaves depth, the tagged reference of the visible fragment and the shade work lists. */
-template <int PPL, bool BLEND = false>
-__global__ void __launch_bounds__(256 / PPL) rz_visibility_kernel(const PassParams *__restrict__ passes,
-        const BinEntry *__restrict__ list_base, const uint2 *__restrict__ box_base,
+/* K4b  visibility first, for a pass that has blended draws in a large framebuffer: a wave owns a block of
+ * 16x8 pixels (lane = the pixel at (lane & 7, lane >> 3) and the one 8 to its right), a workgroup of two waves
+ * a 32x8 tile.  A blended fragment over nothing else of this pass blends with the colour the framebuffer holds,
+ * which the shade kernels can do; one over another pending fragment of the pass needs them shaded in order:
+ * such a tile is left untouched and handed to rz_raster_list_kernel.  Everywhere else this leaves depth, the
+ * tagged reference of the visible fragment and the tile on its family's work list. */
+RZ_DEV void blend_visibility_tile(const PassParams P, const uint32_t pass_index, const uint32_t tile_x, const uint32_t tile_y,
+        const BinEntry *__restrict__ list_base,
         const float *__restrict__ vary_base, const float *__restrict__ fan_vary_base,
-        const char *__restrict__ upload_base, const uint2 *__restrict__ bin_range_base, uint32_t num_passes) {
-    const TileOrder o = tile_order(num_passes, RZ_BIN / RZ_TILE_H);
-    const PassParams P = passes[o.pass];
-    if ((int)o.column >= P.tiles_x || (int)o.row >= P.tiles_y) return;
-    if (RZ_SKIP(P) == 3) return;
+        const char *__restrict__ upload_base, const uint2 *__restrict__ bin_range_base) {
+    constexpr int PPL = 2;
+    if ((int)tile_x >= P.tiles_x || (int)tile_y >= P.tiles_y) return;
     if (P.control[2] != 0u) return;                             /* out of scratch, or left out: the pass is run again later */
     const BinEntry *list_table = list_base + P.list_off;
     const float *vary_table = vary_base + (size_t)P.tri_off * 3 * RZ_VARY_STRIDE;
     const float *fan_vary_table = fan_vary_base + (size_t)P.fan_off * RZ_MAX_POLY * RZ_VARY_STRIDE;
     const DrawRec *draw_table = (const DrawRec*)(upload_base + P.draws_off);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int tx0 = (int)o.column * RZ_TILE_W, ty0 = (int)o.row * RZ_TILE_H;
+    const int tx0 = (int)tile_x * RZ_TILE_W, ty0 = (int)tile_y * RZ_TILE_H;
     const int bx0 = tx0 + wave * 8 * PPL, by0 = ty0, bx1 = bx0 + 8 * PPL - 1, by1 = by0 + 7;
     const int py = by0 + (lane >> 3);
     int px[PPL];
@@ -1488,142 +1455,46 @@ __global__ void __launch_bounds__(256 / PPL) rz_visibility_kernel(const PassPara
     }
     float zcur[PPL];
     uint32_t ref_of[PPL];                                           /* tagged with the family; NONE = no fragment */
-    int ord_of[PPL];                                                /* its position in the bin's list; -1 = what the buffer held */
+    bool pending[PPL];                                              /* a fragment of this pass is the pixel's visible one so far */
     for (int q = 0; q < PPL; q++) {
         ref_of[q] = RZ_REF_NONE;
-        ord_of[q] = -1;
+        pending[q] = false;
         zcur[q] = P.clear_depth;
         if (valid[q] && !P.clear_depth_pending) zcur[q] = P.depth[pixel[q]];
     }
     const BinEntry *list = list_table + range.x;
-    const uint2 *boxes = box_base + P.list_off + range.x;
-
-    /* Small triangles.  Which fragment a pixel ends up with does not depend on the order the
-     * triangles are taken in: it is the one of least depth, the latest in submission order among
-     * equals (graphics.c:523 keeps a fragment when depth <= the stored depth).  Candidates whose
-     * box covers at most micro_area pixels of this wave's block are therefore set aside in a ring,
-     * and each time 64 have come together every lane rasterises one of them, pixel by pixel,
-     * into a per-pixel key in LDS: depth (as an order-preserving integer) above the complement of
-     * the list position, so that an atomic minimum keeps exactly that fragment.  The keys meet the
-     * registers of the one-triangle-per-step path when the list ends.  Triangles with an alpha
-     * cutoff and passes that count fragments stay on the ordered path. */
-    __shared__ unsigned long long micro_keys[256];
-    __shared__ uint32_t micro_ring[4 / PPL][128];
-    unsigned long long *keys = micro_keys + wave * 64 * PPL;
-    uint32_t *ring = micro_ring[wave];
-    /* short lists are not worth the keys' set-up and the final merge; blending needs the order */
-    const int micro_area = (BLEND || P.counters || count < (uint32_t)P.micro_min_list) ? 0 : P.micro_area;
-    /* BLEND: the pass has blended draws.  A blended fragment over nothing else of this pass blends
-     * with the colour the framebuffer holds, which the shade kernels can do; one over another
-     * pending fragment of the pass needs them shaded in order: such a tile is left untouched and
-     * handed to rz_raster_list_kernel. */
     __shared__ int s_ordered;
     bool needs_order = false;
-    if (BLEND) {
-        if (threadIdx.x == 0) s_ordered = 0;
-        __syncthreads();
-    }
-    uint32_t ring_head = 0, ring_tail = 0;                          /* wave-uniform */
-    if (micro_area)
-        for (int q = 0; q < PPL; q++) keys[q * 64 + lane] = ~0ull;
-    const int sx1 = min(bx1, P.width - 1), sy1 = min(by1, P.height - 1);
-    auto rasterise_ring = [&](uint32_t n) {                         /* one triangle per lane, the ring's oldest n <= 64 */
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        const bool on = (uint32_t)lane < n;
-        const uint32_t ord = on ? ring[(ring_head + (uint32_t)lane) & 127u] : 0u;
-        ring_head += n;
-        TriRec r;
-        int x0 = 0, x1 = -1, y0 = 0, y1 = -1;
-        if (on) {
-            const float4 *e = (const float4*)&list[ord];
-            const float4 a = e[1], b = e[2], c = e[3], d = e[4];
-            r.ax = a.x; r.ay = a.y; r.abx = a.z; r.aby = a.w;
-            r.acx = b.x; r.acy = b.y; r.factor = b.z; r.z[0] = b.w;
-            r.z[1] = c.x; r.z[2] = c.y;
-            const uint32_t bx = __float_as_uint(d.z), by = __float_as_uint(d.w);
-            x0 = max((int)(bx & 0xffffu), bx0); x1 = min((int)(bx >> 16), sx1);
-            y0 = max((int)(by & 0xffffu), by0); y1 = min((int)(by >> 16), sy1);
-        }
-        int x = x0, y = y0;
-        const uint32_t low = ~ord;
-        while (__any(y <= y1)) {
-            if (y <= y1) {
-                float w0, w1, w2;
-                pixel_weights(r, x, y, w0, w1, w2);
-                const float depth = r.z[0] * w0 + r.z[1] * w1 + r.z[2] * w2;                       /* :403-408 */
-                if (w0 > -RZ_EPS && w1 > -RZ_EPS && w2 > -RZ_EPS && depth == depth) {             /* :516-519 */
-                    const uint32_t bits = __float_as_uint(depth + 0.0f);
-                    const uint32_t up = bits ^ ((uint32_t)((int32_t)bits >> 31) | 0x80000000u);
-                    const int lx = x - bx0, ly = y - by0;
-                    atomicMin(&keys[(lx >> 3) * 64 + (ly << 3) + (lx & 7)], ((unsigned long long)up << 32) | low);
-                }
-                if (++x > x1) { x = x0; y++; }
-            }
-        }
-    };
+    __syncthreads();                                            /* the workgroup's tile before this one has been settled */
+    if (threadIdx.x == 0) s_ordered = 0;
+    __syncthreads();
 
-    /* This lane's candidate of the NEXT group of 64 entries, loaded one group ahead.  A short list
-     * is read from the entries themselves, box and edge data together (one round trip per group).
-     * A long list is walked through the 8-byte boxes -- 512 contiguous bytes per load, where the
-     * same fields out of the 80-byte entries are 64 cache lines and the loads, not the arithmetic,
-     * set the pace -- and the edge data of the few candidates whose box meets the block is fetched
-     * afterwards. */
-    const bool long_list = count >= (uint32_t)P.micro_min_list;    /* wave-uniform */
+    /* this lane's candidate of the NEXT group of 64 entries (box and edge data), loaded one group ahead */
     float4 n0 = make_float4(0, 0, 0, 0), n1 = n0;
     uint2 nbox = make_uint2(RZ_BBOX_EMPTY_X, 0u);
     if ((uint32_t)lane < count) {
-        if (long_list) {
-            nbox = boxes[lane];
-        } else {
-            const float4 *e = (const float4*)&list[lane];          /* reference + record, 80 bytes */
-            n0 = e[1]; n1 = e[2];
-            nbox = entry_box(e[4]);
-        }
+        const float4 *e = (const float4*)&list[lane];              /* reference + record, 80 bytes */
+        n0 = e[1]; n1 = e[2];
+        nbox = entry_box(e[4]);
     }
     /* block corners at pixel centres, for the conservative triangle/block test */
     const float cx0 = (float)bx0 + 0.5f, cx1 = (float)bx1 + 0.5f, cy0 = (float)by0 + 0.5f, cy1 = (float)by0 + 7.5f;
 
-    for (uint32_t base = 0; base < count && RZ_SKIP(P) != 4;) {
+    for (uint32_t base = 0; base < count;) {
         const uint2 cbox = nbox;
-        float4 c0 = n0, c1 = n1;
+        const float4 c0 = n0, c1 = n1;
         const bool present = base + lane < count;
         const BinEntry *group = list + base;
-        const uint32_t group_at = base;
         base += 64u;
         if (base + lane < count) {
-            if (long_list) {
-                nbox = boxes[base + lane];
-            } else {
-                const float4 *e = (const float4*)&list[base + lane];
-                n0 = e[1]; n1 = e[2];
-                nbox = entry_box(e[4]);
-            }
+            const float4 *e = (const float4*)&list[base + lane];
+            n0 = e[1]; n1 = e[2];
+            nbox = entry_box(e[4]);
         }
-        const bool cutoff = (cbox.y >> 31) != 0;
         bool hit = false;
         if (present) {
             hit = box_overlaps(make_uint2(cbox.x, cbox.y & 0x7fffffffu), bx0, by0, bx1, by1);
-            if (hit && long_list) {
-                const float4 *e = (const float4*)&group[lane];
-                c0 = e[1]; c1 = e[2];
-            }
             if (hit) hit = !block_outside(c0, c1, cx0, cx1, cy0, cy1);
-        }
-        if (micro_area) {
-            bool small = false;
-            if (hit) {
-                const uint32_t bx = cbox.x, by = cbox.y & 0x7fffffffu;
-                const int w = min((int)(bx >> 16), sx1) - max((int)(bx & 0xffffu), bx0) + 1;
-                const int h = min((int)(by >> 16), sy1) - max((int)(by & 0xffffu), by0) + 1;
-                small = w * h <= micro_area && !cutoff;
-            }
-            const unsigned long long smalls = __ballot(small);
-            if (smalls) {
-                if (small) ring[(ring_tail + __builtin_amdgcn_mbcnt_hi((uint32_t)(smalls >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)smalls, 0u))) & 127u] = group_at + (uint32_t)lane;
-                ring_tail += (uint32_t)__popcll(smalls);
-                hit = hit && !small;
-                if (ring_tail - ring_head >= 64u) rasterise_ring(64u);
-            }
         }
         unsigned long long todo = __ballot(hit);
         while (todo) {
@@ -1633,7 +1504,6 @@ __global__ void __launch_bounds__(256 / PPL) rz_visibility_kernel(const PassPara
             todo &= todo - 1;
             const uint32_t ref = e->tri;
             const TriRec r = e->rec;
-            if (RZ_SKIP(P) >= 2) continue;
             const int x0 = (int)(r.bx & 0xffffu), x1 = (int)(r.bx >> 16);
             const int y0 = (int)(r.by & 0xffffu), y1 = (int)(r.by >> 16);
             const bool row_in = py >= y0 && py <= y1;
@@ -1649,14 +1519,6 @@ __global__ void __launch_bounds__(256 / PPL) rz_visibility_kernel(const PassPara
             bool any_pass = false;
             for (int q = 0; q < PPL; q++) any_pass |= pass[q];
             if (!__any(any_pass)) continue;
-            if (P.counters) {       /* fragments the reference would shade: [2] all, [6] skybox */
-                unsigned long long n = 0;
-                for (int q = 0; q < PPL; q++) n += (unsigned long long)__popcll(__ballot(pass[q]));
-                if (lane == 0) {
-                    atomicAdd(P.counters + 2, n);
-                    if (RZ_META_FAMILY(r.meta) == 2) atomicAdd(P.counters + 6, n);
-                }
-            }
             if (RZ_META_CUTOFF(r.meta)) {
                 /* the shaders' discard test (blinn_shader.c:104-113, 220; pbr_shader.c:116-134, 452):
                  * alpha = base alpha * first map's alpha, from the interpolated texcoord */
@@ -1677,44 +1539,26 @@ __global__ void __launch_bounds__(256 / PPL) rz_visibility_kernel(const PassPara
                 }
             }
             const uint32_t tagged = ref | (RZ_META_FAMILY(r.meta) << 28);
-            if (BLEND && RZ_META_BLEND(r.meta))
-                for (int q = 0; q < PPL; q++) needs_order |= pass[q] && ord_of[q] >= 0;
-            for (int q = 0; q < PPL; q++) if (pass[q]) { zcur[q] = depth[q]; ref_of[q] = tagged; ord_of[q] = (int)(group_at + at); }
-        }
-    }
-    if (micro_area) {
-        if (ring_tail != ring_head) rasterise_ring(ring_tail - ring_head);
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        for (int q = 0; q < PPL; q++) {
-            const unsigned long long key = keys[q * 64 + lane];
-            if (key == ~0ull) continue;
-            const uint32_t up = (uint32_t)(key >> 32);
-            const float depth = __uint_as_float(up ^ ((up >> 31) ? 0x80000000u : 0xffffffffu));
-            const int ord = (int)~(uint32_t)key;
-            if (depth < zcur[q] || (depth == zcur[q] && ord > ord_of[q])) {
-                const BinEntry *e = &list[ord];
-                zcur[q] = depth;
-                ref_of[q] = e->tri | (RZ_META_FAMILY(e->rec.meta) << 28);
-            }
+            if (RZ_META_BLEND(r.meta))
+                for (int q = 0; q < PPL; q++) needs_order |= pass[q] && pending[q];
+            for (int q = 0; q < PPL; q++) if (pass[q]) { zcur[q] = depth[q]; ref_of[q] = tagged; pending[q] = true; }
         }
     }
 
-    if (BLEND) {
-        if (__any(needs_order) && lane == 0) s_ordered = 1;
-        __syncthreads();
-        if (s_ordered) {
-            for (int q = 0; q < PPL; q++) if (valid[q]) P.ref[pixel[q]] = RZ_REF_NONE;     /* nothing here for the shade kernels */
-            if (threadIdx.x == 0) {
-                const uint32_t tile = o.row * (uint32_t)P.tiles_x + o.column;
-                const uint32_t part = RZ_ORDERED_LIST * RZ_QUEUE_WAYS + ((P.tile_off + tile) & (RZ_QUEUE_WAYS - 1u));
-                const uint32_t at = atomicAdd(&P.queue_counts[part * RZ_QUEUE_PAD], 1u);
-                if (at < P.queue_capacity)
-                    P.queue[(size_t)part * P.queue_capacity + at] = ((uint32_t)o.pass << 20) | ((uint32_t)o.row << 9) | (uint32_t)o.column;
-                else
-                    atomicOr(&P.control[2], (uint32_t)RZ_ERR_QUEUE_OVERFLOW);
-            }
-            return;
+    if (__any(needs_order) && lane == 0) s_ordered = 1;
+    __syncthreads();
+    if (s_ordered) {
+        for (int q = 0; q < PPL; q++) if (valid[q]) P.ref[pixel[q]] = RZ_REF_NONE;     /* nothing here for the shade kernels */
+        if (threadIdx.x == 0) {
+            const uint32_t tile = tile_y * (uint32_t)P.tiles_x + tile_x;
+            const uint32_t part = RZ_ORDERED_LIST * RZ_QUEUE_WAYS + ((P.tile_off + tile) & (RZ_QUEUE_WAYS - 1u));
+            const uint32_t at = atomicAdd(&P.queue_counts[part * RZ_QUEUE_PAD], 1u);
+            if (at < P.queue_capacity)
+                P.queue[(size_t)part * P.queue_capacity + at] = (pass_index << 20) | (tile_y << 9) | tile_x;
+            else
+                atomicOr(&P.control[2], (uint32_t)RZ_ERR_QUEUE_OVERFLOW);
         }
+        return;
     }
     for (int q = 0; q < PPL; q++) {
         if (!valid[q]) continue;
@@ -1723,30 +1567,45 @@ __global__ void __launch_bounds__(256 / PPL) rz_visibility_kernel(const PassPara
         /* the shade kernels write the colour of every pixel that has a fragment */
         if (P.clear_color_pending && ref_of[q] == RZ_REF_NONE) P.color[pixel[q]] = P.clear_color;
     }
-    /* Blinn and pbr fragments usually cover a small part of the screen: every tile that holds some
-     * goes on that family's work list (all passes of the batch together), and the shade kernel of
-     * the family walks the list.  The first wave of a tile to find such a fragment appends the tile
-     * (tile_listed keeps who was first); waves without any pay nothing.  A list is kept in
-     * RZ_QUEUE_WAYS parts, chosen by the tile's index, with counters a cache line apart, so that the
-     * appends of a whole batch do not pile up on one counter.  Skybox fragments are found by
-     * scanning the tiles. */
+    /* every tile that holds blinn or pbr fragments goes on that family's work list (all passes of the batch
+     * together), appended by the first wave of the tile to find one (tile_listed keeps who was first).  A list is
+     * kept in RZ_QUEUE_WAYS parts, chosen by the tile's index, with counters a cache line apart, so that the appends
+     * of a whole batch do not pile up on one counter. */
     for (uint32_t f = 0; f < 2; f++) {
         bool mine = false;
         for (int q = 0; q < PPL; q++) mine |= ((ref_of[q] >> 28) & 3u) == f;
         if (!__any(mine)) continue;
         if (lane == 0) {
-            const uint32_t tile = o.row * (uint32_t)P.tiles_x + o.column;
+            const uint32_t tile = tile_y * (uint32_t)P.tiles_x + tile_x;
             const uint32_t before = atomicOr(&P.tile_listed[tile], 1u << f);
             if (!(before >> f & 1u)) {
                 /* by the tile's index in the batch: no part can get more than its even share */
                 const uint32_t part = f * RZ_QUEUE_WAYS + ((P.tile_off + tile) & (RZ_QUEUE_WAYS - 1u));
                 const uint32_t at = atomicAdd(&P.queue_counts[part * RZ_QUEUE_PAD], 1u);
                 if (at < P.queue_capacity)
-                    P.queue[(size_t)part * P.queue_capacity + at] = ((uint32_t)o.pass << 20) | ((uint32_t)o.row << 9) | (uint32_t)o.column;
+                    P.queue[(size_t)part * P.queue_capacity + at] = (pass_index << 20) | (tile_y << 9) | tile_x;
                 else
                     atomicOr(&P.control[2], (uint32_t)RZ_ERR_QUEUE_OVERFLOW);
             }
         }
+    }
+}
+
+/* ... over the batch's list of the tiles of bins that are not empty */
+__global__ void __launch_bounds__(128) rz_blend_visibility_kernel(const PassParams *__restrict__ passes,
+        const BinEntry *__restrict__ list_base,
+        const float *__restrict__ vary_base, const float *__restrict__ fan_vary_base,
+        const char *__restrict__ upload_base, const uint2 *__restrict__ bin_range_base,
+        const uint32_t *__restrict__ queue_base, const uint32_t *__restrict__ queue_counts, uint32_t queue_capacity) {
+    /* lane q holds the length of part q of the list of tiles to look at (RZ_VISIBILITY_LIST, rz_bin_scan_kernel) */
+    const uint32_t my_count = min(queue_counts[(RZ_VISIBILITY_LIST * RZ_QUEUE_WAYS + (threadIdx.x & 63u)) * RZ_QUEUE_PAD], queue_capacity);
+    const uint32_t longest = (uint32_t)wave_max_i((int)my_count);
+    for (uint32_t k = blockIdx.x; k < longest * RZ_QUEUE_WAYS; k += gridDim.x) {
+        const uint32_t part = k & (RZ_QUEUE_WAYS - 1u), index = k / RZ_QUEUE_WAYS;
+        if (index >= (uint32_t)__builtin_amdgcn_readlane((int)my_count, (int)part)) continue;
+        const uint32_t item = queue_base[(size_t)(RZ_VISIBILITY_LIST * RZ_QUEUE_WAYS + part) * queue_capacity + index];
+        blend_visibility_tile(passes[item >> 20], item >> 20, item & 511u, (item >> 9) & 2047u, list_base, vary_base, fan_vary_base,
+                              upload_base, bin_range_base);
     }
 }
 
@@ -1773,7 +1632,7 @@ struct SkyBin {
     uint32_t pad[5];
 };
 RZ_DEV bool sky_only_bin(const PassParams &P, const BinEntry *list, uint32_t count) {
-    if (count == 0u || count > RZ_SKY_ONLY_MAX || P.counters || RZ_SKIP(P)) return false;
+    if (count == 0u || count > RZ_SKY_ONLY_MAX || P.counters) return false;
     const uint32_t first = list[0].rec.meta, last = list[count - 1u].rec.meta;
     return RZ_META_FAMILY(first) == 2u && RZ_META_FAMILY(last) == 2u && RZ_META_DRAW(first) == RZ_META_DRAW(last);
 }
@@ -1784,7 +1643,8 @@ __global__ void __launch_bounds__(64) rz_sky_regions_kernel(const PassParams *__
         const BinEntry *__restrict__ list_base, const uint2 *__restrict__ bin_range_base, SkyBin *__restrict__ sky_base) {
     const PassParams &P = passes[blockIdx.y];
     if ((int)blockIdx.x >= P.bins_x * P.bins_y || P.control[2] != 0u) return;
-    const uint2 range = (bin_range_base + P.bin_off)[blockIdx.x];
+    uint2 range = (bin_range_base + P.bin_off)[blockIdx.x];
+    range.y &= ~RZ_BIN_CROWDED;
     const BinEntry *list = list_base + P.list_off + range.x;
     const bool sky = sky_only_bin(P, list, range.y);
     const int lane = threadIdx.x & 63;
@@ -1809,9 +1669,56 @@ __global__ void __launch_bounds__(64) rz_sky_regions_kernel(const PassParams *__
     if (lane == 34) rec->draw = draw;
 }
 
-/* K4c  visibility AND skybox shading for passes without blending, a STRIP of blocks per wave.
+/* What a wave does with a finished block of 16x8 pixels of a pass without blending (rz_strip_kernel,
+ * rz_crowd_kernel): depth, the clear colour where no fragment is, and -- for blocks that hold blinn or pbr
+ * fragments, or when a kernel that looks at every pixel's reference follows -- the references. */
+#define RZ_BLOCK_ITEM(pass, by, bx) (((uint32_t)(pass) << 21) | ((uint32_t)(by) << 10) | (uint32_t)(bx))
+RZ_DEV void finish_block(const PassParams &P, uint32_t pass_index, int bx0, int by0, int lane,
+                         const bool valid[2], const uint32_t pixel[2], const float zcur[2], const uint32_t ref_of[2]) {
+    constexpr int PPL = 2;
+    bool listed = false;
+    for (int q = 0; q < PPL; q++) {
+        if (valid[q] && (ref_of[q] != RZ_REF_NONE || P.clear_depth_pending)) P.depth[pixel[q]] = zcur[q];  /* else: what was there */
+        listed |= ((ref_of[q] >> 28) & 3u) < 2u;                /* RZ_REF_NONE reads as family 3 */
+        /* a pixel without a fragment shows the clear colour */
+        if (valid[q] && P.clear_color_pending && ref_of[q] == RZ_REF_NONE) P.color[pixel[q]] = P.clear_color;
+    }
+    /* the skybox's fragments are left to rz_sky_kernel, which looks at the references of every pixel */
+    if (P.ref_scanned && !__any(listed))
+        for (int q = 0; q < PPL; q++) if (valid[q]) P.ref[pixel[q]] = ref_of[q];
+    if (__any(listed)) {
+        /* the block holds blinn or pbr fragments: its references are written -- all of them, the
+         * family's shade kernel looks at every pixel of a listed block -- and the block goes on the
+         * work list of each family it holds (parts chosen by the block's index in its pass: a part
+         * gets at most its even share of every pass, rounded up) */
+        for (int q = 0; q < PPL; q++) if (valid[q]) P.ref[pixel[q]] = ref_of[q];
+        const uint32_t block_x = (uint32_t)bx0 / (8u * PPL), block_y = (uint32_t)by0 / 8u;
+        /* the block's index in its own pass: a block of the screen is on the same part, and with it on the same
+         * XCD's share of the shade kernel's workgroups (workgroup b runs on XCD b mod 8 and takes parts 2b and
+         * 2b + 1 mod 64), in every pass of the batch -- the views of a batch fetch much the same texels for it */
+        const uint32_t index = block_y * 2u * (uint32_t)P.tiles_x + block_x;
+        for (uint32_t f = 0; f < 2; f++) {
+            bool mine_f = false;
+            for (int q = 0; q < PPL; q++) mine_f |= ((ref_of[q] >> 28) & 3u) == f;
+            if (!__any(mine_f)) continue;
+            if (lane == 0) {
+                const uint32_t part = f * RZ_QUEUE_WAYS + (index & (RZ_QUEUE_WAYS - 1u));
+                const uint32_t at = atomicAdd(&P.queue_counts[part * RZ_QUEUE_PAD], 1u);
+                if (at < P.queue_capacity)
+                    P.queue[(size_t)part * P.queue_capacity + at] = RZ_BLOCK_ITEM(pass_index, block_y, block_x);
+                else
+                    atomicOr(&P.control[2], (uint32_t)RZ_ERR_QUEUE_OVERFLOW);
+            }
+        }
+    }
+}
+
+/* K4c  visibility for passes without blending: coverage + depth, leaves depth and one fragment reference per
+ * pixel.  A wave owns blocks of 16x8 pixels (lane = the pixel at (lane & 7, lane >> 3) and the one 8 to its right:
+ * half the waves walk the lists, cull candidates and fetch survivors compared with one pixel per lane), a STRIP of
+ * them per wave.
  *
- * rz_visibility_kernel spends its time waiting: a wave lives for some 14 000 cycles and issues 700
+ * With one block per wave a wave spends its time waiting: it lives for some 14 000 cycles and issues 700
  * instructions, the rest is a chain of dependent memory round trips (the pass's parameters, the bin's
  * range, the list's first entries, the surviving entries, the stores), paid by every wave for 128
  * pixels.  Here a wave keeps its 16-pixel column and takes STRIP blocks of 16x8 pixels one above the
@@ -1830,13 +1737,11 @@ __global__ void __launch_bounds__(64) rz_sky_regions_kernel(const PassParams *__
  * per block, all but the first of a strip leaving at once where the list is short -- gave the long lists
  * their waves but cost the short ones the workgroup starts again (helmet 11.9 -> 14.0 us).
  *
- * The epilogue shades skybox fragments in place (skybox_shader.c:21-29; what rz_sky_kernel does
- * from the reference plane): the sky fills most of a frame, and writing a reference per sky pixel only
- * to read it back in the next kernel was most of this stage's memory traffic.  References are written
- * only for blocks that hold blinn or pbr fragments; such a block is appended to its family's work list
- * (16x8 blocks, not 32x8 tiles: the wave that owns the block is the only one to list it). */
-#define RZ_BLOCK_ITEM(pass, by, bx) (((uint32_t)(pass) << 21) | ((uint32_t)(by) << 10) | (uint32_t)(bx))
-template <int STRIP, bool SKY>
+ * The epilogue writes depth and, for blocks that hold blinn or pbr fragments, the references; such a block is
+ * appended to its family's work list (16x8 blocks, not 32x8 tiles: the wave that owns the block is the only one
+ * to list it).  Skybox fragments are rz_sky_kernel's: it looks at the references of every pixel outside the bins
+ * it resolves itself, so in a batch with a sky box the references of all blocks are written. */
+template <int STRIP>
 __global__ void __launch_bounds__(128) rz_strip_kernel(const PassParams *__restrict__ passes,
         const BinEntry *__restrict__ list_base, const uint2 *__restrict__ box_base,
         const float *__restrict__ vary_base, const float *__restrict__ fan_vary_base,
@@ -1861,13 +1766,32 @@ __global__ void __launch_bounds__(128) rz_strip_kernel(const PassParams *__restr
     for (int q = 0; q < PPL; q++) px[q] = bx0 + 8 * q + (lane & 7);
     const int bin = (sy0 / RZ_BIN) * P.bins_x + tx0 / RZ_BIN;
     const uint2 range = (bin_range_base + P.bin_off)[bin];          /* {first entry, entries} */
-    const uint32_t elsewhere = (!SKY && sky_base) ? sky_base[P.bin_off + (uint32_t)bin].count : 0u;
+    const uint32_t elsewhere = sky_base ? sky_base[P.bin_off + (uint32_t)bin].count : 0u;
     if (failed != 0u) return;                                       /* out of scratch, or left out: the pass is run again later */
-    if (elsewhere != 0u) return;                                    /* rz_sky_kernel does all of it */
+    if (elsewhere != 0u || (range.y & RZ_BIN_CROWDED)) return;      /* rz_sky_kernel / rz_crowd_kernel does all of it */
     const uint32_t count = range.y;
     if (count == 0) {               /* nothing but the pending clears (uniform over the workgroup) */
-        const bool blank_refs = !SKY && P.ref_scanned;              /* a kernel that scans every pixel's reference follows */
+        const bool blank_refs = P.ref_scanned;                      /* a kernel that scans every pixel's reference follows */
         if (!P.clear_color_pending && !P.clear_depth_pending && !blank_refs) return;
+        if ((P.width & 3) == 0) {
+            /* rows of four pixels per thread: the workgroup's 32 columns are one 128-byte line per plane and row,
+             * written by eight threads side by side (two pixels per lane as the rasteriser holds them make 32-byte
+             * pieces: a frame without a sky box is mostly such bins, and their clears ran at a quarter of the
+             * memory's rate) */
+            const int x = tx0 + (int)(threadIdx.x & 7u) * 4;
+            if (x >= P.width) return;
+            const float d = P.clear_depth;
+            const uint32_t c = P.clear_color;
+            for (int row = (int)(threadIdx.x >> 3); row < 8 * STRIP; row += 16) {
+                const int py = sy0 + row;
+                if (py >= P.height) break;
+                const size_t pixel = (size_t)py * (size_t)P.width + (size_t)x;
+                if (P.clear_depth_pending) *(float4 RZ_GLOBAL*)(P.depth + pixel) = make_float4(d, d, d, d);
+                if (P.clear_color_pending) *(uint4 RZ_GLOBAL*)(P.color + pixel) = make_uint4(c, c, c, c);
+                if (blank_refs) *(uint4 RZ_GLOBAL*)(P.ref + pixel) = make_uint4(RZ_REF_NONE, RZ_REF_NONE, RZ_REF_NONE, RZ_REF_NONE);
+            }
+            return;
+        }
         for (int k = 0; k < STRIP; k++) {
             const int py = sy0 + 8 * k + (lane >> 3);
             for (int q = 0; q < PPL; q++) {
@@ -1883,7 +1807,15 @@ __global__ void __launch_bounds__(128) rz_strip_kernel(const PassParams *__restr
     const BinEntry *list = list_table + range.x;
     const uint2 *boxes = box_base + P.list_off + range.x;
 
-    /* small triangles, one per lane, into per-pixel keys in LDS: see rz_visibility_kernel */
+    /* Small triangles.  Which fragment a pixel ends up with does not depend on the order the
+     * triangles are taken in: it is the one of least depth, the latest in submission order among
+     * equals (graphics.c:523 keeps a fragment when depth <= the stored depth).  Candidates whose
+     * box covers at most micro_area pixels of this wave's block are therefore set aside in a ring,
+     * and each time 64 have come together every lane rasterises one of them, pixel by pixel,
+     * into a per-pixel key in LDS: depth (as an order-preserving integer) above the complement of
+     * the list position, so that an atomic minimum keeps exactly that fragment.  The keys meet the
+     * registers of the one-triangle-per-step path when the list ends.  Triangles with an alpha
+     * cutoff and passes that count fragments stay on the ordered path. */
     __shared__ unsigned long long micro_keys[256];
     __shared__ uint32_t micro_ring[2][128];
     unsigned long long *keys = micro_keys + wave * 64 * PPL;
@@ -1891,8 +1823,12 @@ __global__ void __launch_bounds__(128) rz_strip_kernel(const PassParams *__restr
     const int micro_area = (P.counters || count < (uint32_t)P.micro_min_list) ? 0 : P.micro_area;
     const int sx1 = min(bx1, P.width - 1);
 
-    /* this lane's candidate of the next group of 64 entries (see rz_visibility_kernel); a list of at
-     * most 64 entries is loaded once and serves every block of the strip */
+    /* This lane's candidate of the NEXT group of 64 entries, loaded one group ahead.  A short list
+     * is read from the entries themselves, box and edge data together (one round trip per group).
+     * A long list is walked through the 8-byte boxes -- 512 contiguous bytes per load, where the
+     * same fields out of the 80-byte entries are 64 cache lines and the loads, not the arithmetic,
+     * set the pace -- and the edge data of the few candidates whose box meets the block is fetched
+     * afterwards.  A list of at most 64 entries is loaded once and serves every block of the strip. */
     const bool long_list = count >= (uint32_t)P.micro_min_list;    /* wave-uniform */
     float4 n0 = make_float4(0, 0, 0, 0), n1 = n0;
     uint2 nbox = make_uint2(RZ_BBOX_EMPTY_X, 0u);
@@ -2084,97 +2020,226 @@ __global__ void __launch_bounds__(128) rz_strip_kernel(const PassParams *__restr
         /* the next block's first candidates: on their way while this block's epilogue runs */
         if (count > 64u && k + 1 < STRIP) request_first_group();
 
-        /* ---- epilogue: depth, skybox colour, references of blocks with blinn / pbr fragments ---- */
-        bool sky[PPL], any_sky = false, listed = false;
-        for (int q = 0; q < PPL; q++) {
-            if (valid[q] && (ref_of[q] != RZ_REF_NONE || P.clear_depth_pending)) P.depth[pixel[q]] = zcur[q];  /* else: what was there */
-            const uint32_t family = (ref_of[q] >> 28) & 3u;         /* RZ_REF_NONE reads as family 3 */
-            sky[q] = family == 2u;
-            any_sky |= sky[q];
-            listed |= family < 2u;
-            /* a pixel without a fragment shows the clear colour */
-            if (valid[q] && P.clear_color_pending && ref_of[q] == RZ_REF_NONE) P.color[pixel[q]] = P.clear_color;
-        }
-        if (SKY && __any(any_sky)) {
-            /* the colour below only lends its alpha byte; under a pending clear it is the clear colour */
-            uint32_t ccur[PPL];
-            for (int q = 0; q < PPL; q++) {
-                ccur[q] = P.clear_color;
-                if (sky[q] && !P.clear_color_pending) ccur[q] = P.color[pixel[q]];
-            }
-            int mine = -1;                                          /* a list position this lane's sky fragments come from */
-            for (int q = PPL - 1; q >= 0; q--) if (sky[q]) mine = ord_of[q];
-            const int first = __builtin_amdgcn_readlane(mine, __ffsll((long long)__ballot(any_sky)) - 1);
-            bool uniform = true;
-            for (int q = 0; q < PPL; q++) uniform = uniform && (!sky[q] || ord_of[q] == first);
-            if (__all(uniform)) {
-                /* one sky triangle under all of them: its record and varyings come through scalar loads */
-                const BinEntry *e = &list[first];
-                const uint32_t ref = e->tri;
-                const TriRec m = e->rec;
-                const float *m0, *m1, *m2;
-                ref_varyings(ref, vary_table, fan_vary_table, m0, m1, m2);
-                const DrawRec &D = draw_table[RZ_META_DRAW(m.meta)];
-                for (int q = 0; q < PPL; q++) {
-                    if (!sky[q]) continue;
-                    float w0, w1, w2, v[4];
-                    pixel_weights(m, px[q], py, w0, w1, w2);
-                    const float q0 = m.rw[0] * w0, q1 = m.rw[1] * w1, q2 = m.rw[2] * w2;    /* graphics.c:426-429 */
-                    const float norm = 1 / (q0 + q1 + q2);
-                    interpolate_uniform3(m0, m1, m2, q0, q1, q2, norm, v);
-                    P.color[pixel[q]] = sky_fragment(D, v, ccur[q]);            /* no blending in these passes */
-                }
-                if (P.counters) {       /* [8] fragments shaded on the device, [9] of those, skybox */
-                    unsigned long long n = 0;
-                    for (int q = 0; q < PPL; q++) n += (unsigned long long)__popcll(__ballot(sky[q]));
-                    if (lane == 0) { atomicAdd(P.counters + 8, n); atomicAdd(P.counters + 9, n); }
-                }
-            } else {
-                for (int q = 0; q < PPL; q++) {                     /* an edge of the sky box crosses the block */
-                    if (!__any(sky[q])) continue;
-                    TriRec m;
-                    const float *m0 = vary_table, *m1 = vary_table, *m2 = vary_table;
-                    if (sky[q]) {
-                        m = load_tri(&list[ord_of[q]].rec);
-                        ref_varyings(ref_of[q] & ~RZ_REF_FAMILY_BITS, vary_table, fan_vary_table, m0, m1, m2);
-                    }
-                    shade_lanes<2>(P, draw_table, sky[q], m, m0, m1, m2, px[q], py, ccur[q]);
-                    if (sky[q]) P.color[pixel[q]] = ccur[q];
-                }
-            }
-        }
-        /* without SKY the skybox's fragments are left to rz_sky_kernel, which looks at the references of every pixel */
-        if (!SKY && P.ref_scanned && !__any(listed))
-            for (int q = 0; q < PPL; q++) if (valid[q]) P.ref[pixel[q]] = ref_of[q];
-        if (__any(listed)) {
-            /* the block holds blinn or pbr fragments: its references are written -- all of them, the
-             * family's shade kernel looks at every pixel of a listed block -- and the block goes on the
-             * work list of each family it holds (parts chosen by the block's index in its pass: a part
-             * gets at most its even share of every pass, rounded up) */
-            for (int q = 0; q < PPL; q++) if (valid[q]) P.ref[pixel[q]] = ref_of[q];
-            const uint32_t block_x = (uint32_t)bx0 / (8u * PPL), block_y = (uint32_t)by0 / 8u;
-            /* the block's index in its own pass: a block of the screen is on the same part, and with it on the same
-             * XCD's share of the shade kernel's workgroups (workgroup b runs on XCD b mod 8 and takes parts 2b and
-             * 2b + 1 mod 64), in every pass of the batch -- the views of a batch fetch much the same texels for it */
-            const uint32_t index = block_y * 2u * (uint32_t)P.tiles_x + block_x;
-            for (uint32_t f = 0; f < 2; f++) {
-                bool mine_f = false;
-                for (int q = 0; q < PPL; q++) mine_f |= ((ref_of[q] >> 28) & 3u) == f;
-                if (!__any(mine_f)) continue;
-                if (lane == 0) {
-                    const uint32_t part = f * RZ_QUEUE_WAYS + (index & (RZ_QUEUE_WAYS - 1u));
-                    const uint32_t at = atomicAdd(&P.queue_counts[part * RZ_QUEUE_PAD], 1u);
-                    if (at < P.queue_capacity)
-                        P.queue[(size_t)part * P.queue_capacity + at] = RZ_BLOCK_ITEM(pass_index, block_y, block_x);
-                    else
-                        atomicOr(&P.control[2], (uint32_t)RZ_ERR_QUEUE_OVERFLOW);
-                }
-            }
-        }
+        finish_block(P, pass_index, bx0, by0, lane, valid, pixel, zcur, ref_of);
     }
 }
 
-/* K5  per-family fragment kernels for passes rasterised with SPLIT = true:
+/* K4d  crowded bins (a dense mesh far away: azura at 800x600 puts ten thousand triangles of a few pixels each
+ * into one 64x64 bin).  In rz_strip_kernel every one of the bin's 32 blocks is a wave that walks the whole list
+ * to find the few entries that touch it, and takes those one at a time with all 64 lanes: the walk is repeated
+ * 32 times and the lanes are 2 % busy.  Here a workgroup of eight waves takes a QUARTER of such a bin (32x32
+ * pixels; a sixteenth, 16x16, of a bin with a very long list, so that the fullest bin of a frame is spread over
+ * more of the device): the waves share the walk over the list's 8-byte boxes -- 512 contiguous bytes per load --
+ * and set aside the entries whose box meets the square in a ring; each time 64 have come together every lane
+ * rasterises one, into a plane of per-pixel keys in LDS, depth (as an order-preserving integer) above the
+ * complement of the list position.  Which fragment a pixel ends up with does not depend on the order the
+ * triangles are taken in: it is the one of least depth, the latest in submission order among equals
+ * (graphics.c:523 keeps a fragment when depth <= the stored depth), and an atomic minimum over such keys keeps
+ * exactly that one.  Alpha-cutoff discards (evaluated per fragment, order does not matter) keep a fragment out
+ * of the plane.  When the list is through, the waves turn to the square's blocks: keys against the depth buffer,
+ * then what rz_strip_kernel does with a finished block.
+ *
+ * Of the 64 entries of a turn, a lane whose triangle's box (cut to the square) is small walks it alone, pixel by
+ * pixel; a larger one is taken by the whole wave, 8x8 pixels per step, its record passed round from the lane
+ * that holds it with readlane (no second trip to memory).  Where the line between the two lies is settled per
+ * turn: the lanes' loop runs as long as the largest box among them, so the limit that makes (largest small box)
+ * x (a pixel's cost) + (boxes above it) x (a wave-wide step's cost) least is taken, among a few candidates up to
+ * crowd_small.
+ *
+ * Passes without blending only (like rz_strip_kernel), and not while fragments are counted (that count depends
+ * on the order).  grid: a fixed number of workgroups stride over the batch's list of squares, which
+ * rz_bin_scan_kernel wrote: {pass << 16 | bin, square | fine << 8}. */
+#define RZ_CROWD_WAVES 8
+__global__ void __launch_bounds__(64 * RZ_CROWD_WAVES) rz_crowd_kernel(const PassParams *__restrict__ passes,
+        const BinEntry *__restrict__ list_base, const uint2 *__restrict__ box_base,
+        const float *__restrict__ vary_base, const float *__restrict__ fan_vary_base,
+        const char *__restrict__ upload_base, const uint2 *__restrict__ bin_range_base,
+        const uint2 *__restrict__ crowd_list, const uint32_t *__restrict__ queue_counts, uint32_t crowd_capacity) {
+    __shared__ unsigned long long keys[32 * 32];                    /* row-major inside the square */
+    __shared__ uint32_t rings[RZ_CROWD_WAVES][128];
+    const int lane = threadIdx.x & 63, wave = (int)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    uint32_t *ring = rings[wave];
+    const uint32_t items = min(queue_counts[RZ_CROWD_COUNT_AT], crowd_capacity);
+    for (uint32_t item = blockIdx.x; item < items; item += gridDim.x) {
+        const uint2 word = crowd_list[item];
+        const uint32_t pass_index = word.x >> 16, bin = word.x & 0xffffu;
+        const PassParams P = passes[pass_index];
+        if (P.control[2] != 0u) continue;                           /* out of scratch, or left out: the pass is run again later (uniform) */
+        const uint2 range = (bin_range_base + P.bin_off)[bin];
+        const uint32_t count = range.y & ~RZ_BIN_CROWDED;
+        const BinEntry *list = list_base + P.list_off + range.x;
+        const uint2 *boxes = box_base + P.list_off + range.x;
+        const float *vary_table = vary_base + (size_t)P.tri_off * 3 * RZ_VARY_STRIDE;
+        const float *fan_vary_table = fan_vary_base + (size_t)P.fan_off * RZ_MAX_POLY * RZ_VARY_STRIDE;
+        const DrawRec *draw_table = (const DrawRec*)(upload_base + P.draws_off);
+        /* the square */
+        const int edge = (word.y >> 8) ? 16 : 32, per_row = RZ_BIN / edge, square = (int)(word.y & 0xffu);
+        const int sq_x0 = (int)(bin % (uint32_t)P.bins_x) * RZ_BIN + (square % per_row) * edge;
+        const int sq_y0 = (int)(bin / (uint32_t)P.bins_x) * RZ_BIN + (square / per_row) * edge;
+        if (sq_x0 >= P.width || sq_y0 >= P.height) continue;       /* uniform */
+        const int sq_x1 = min(sq_x0 + edge - 1, P.width - 1), sq_y1 = min(sq_y0 + edge - 1, P.height - 1);
+        for (uint32_t i = threadIdx.x; i < 32u * 32u; i += 64u * RZ_CROWD_WAVES) keys[i] = ~0ull;
+        __syncthreads();
+
+        /* 64 entries of the ring (or what is left of it), one per lane */
+        uint32_t ring_head = 0, ring_tail = 0;                      /* wave-uniform */
+        auto rasterise = [&](uint32_t n) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            const bool on = (uint32_t)lane < n;
+            const uint32_t ord = on ? ring[(ring_head + (uint32_t)lane) & 127u] : 0u;
+            ring_head += n;
+            float4 a = make_float4(0, 0, 0, 0), b = a, c = a;
+            uint2 box = make_uint2(RZ_BBOX_EMPTY_X, 0u);
+            if (on) {
+                const float4 *q = (const float4*)&list[ord];       /* reference + record, 80 bytes */
+                a = q[1]; b = q[2]; c = q[3];
+                box = boxes[ord];
+            }
+            /* the entry's box inside the square (find_bounding_box clamped it to the framebuffer, graphics.c:355-364) */
+            const int x0 = max((int)(box.x & 0xffffu), sq_x0), x1 = min((int)(box.x >> 16), sq_x1);
+            const int y0 = max((int)(box.y & 0xffffu), sq_y0), y1 = min((int)((box.y >> 16) & 0x7fffu), sq_y1);
+            const bool cutoff = (box.y >> 31) != 0;
+            const int area = (on && x1 >= x0 && y1 >= y0) ? (x1 - x0 + 1) * (y1 - y0 + 1) : 0;
+            /* the limit between "alone" and "wave-wide" for this turn */
+            int limit = 0;
+            {
+                int best = 0x7fffffff;
+                for (int t = 4; t <= 64; t *= 2) {
+                    if (t > P.crowd_small && t > 4) break;
+                    const bool above = area > t || (area > 0 && cutoff);
+                    const int cost = 30 * min(t, wave_max_i(above ? 0 : area)) + 48 * __popcll(__ballot(above));
+                    if (cost < best) { best = cost; limit = t; }
+                }
+                limit = min(limit, P.crowd_small);
+            }
+            const bool alone = area > 0 && area <= limit && !cutoff;
+            const uint32_t low = ~ord;                              /* the later entry wins among equal depths */
+            TriRec r;
+            r.ax = a.x; r.ay = a.y; r.abx = a.z; r.aby = a.w;
+            r.acx = b.x; r.acy = b.y; r.factor = b.z; r.z[0] = b.w;
+            r.z[1] = c.x; r.z[2] = c.y;
+            if (alone) {
+                int x = x0, y = y0;
+                while (y <= y1) {
+                    float w0, w1, w2;
+                    pixel_weights(r, x, y, w0, w1, w2);
+                    const float depth = r.z[0] * w0 + r.z[1] * w1 + r.z[2] * w2;                       /* :403-408 */
+                    if (w0 > -RZ_EPS && w1 > -RZ_EPS && w2 > -RZ_EPS && depth == depth) {             /* :516-519 */
+                        const uint32_t bits = __float_as_uint(depth + 0.0f);
+                        const uint32_t up = bits ^ ((uint32_t)((int32_t)bits >> 31) | 0x80000000u);
+                        atomicMin(&keys[(y - sq_y0) * 32 + (x - sq_x0)], ((unsigned long long)up << 32) | low);
+                    }
+                    if (++x > x1) { x = x0; y++; }
+                }
+            }
+            /* the others, one after the other, by the whole wave: lane = a pixel of an 8x8 step */
+            unsigned long long todo = __ballot(area > 0 && !alone);
+            const unsigned long long cutoffs = __ballot(cutoff);
+            while (todo) {
+                const int L = __ffsll((long long)todo) - 1;
+                todo &= todo - 1;
+                TriRec m;
+                m.ax = RZ_BCAST_F(a.x, L); m.ay = RZ_BCAST_F(a.y, L); m.abx = RZ_BCAST_F(a.z, L); m.aby = RZ_BCAST_F(a.w, L);
+                m.acx = RZ_BCAST_F(b.x, L); m.acy = RZ_BCAST_F(b.y, L); m.factor = RZ_BCAST_F(b.z, L); m.z[0] = RZ_BCAST_F(b.w, L);
+                m.z[1] = RZ_BCAST_F(c.x, L); m.z[2] = RZ_BCAST_F(c.y, L);
+                const int mx0 = RZ_BCAST_I(x0, L), mx1 = RZ_BCAST_I(x1, L), my0 = RZ_BCAST_I(y0, L), my1 = RZ_BCAST_I(y1, L);
+                const uint32_t mlow = (uint32_t)RZ_BCAST_I(low, L);
+                const bool mcut = (cutoffs >> L) & 1ull;
+                /* an entry with an alpha cutoff: the shaders' discard test (blinn_shader.c:104-113, 220; pbr_shader.c:116-134,
+                 * 452) needs the interpolated texcoord, i.e. 1/w per corner and the corners' varyings (scalar loads) */
+                const BinEntry *entry = &list[(uint32_t)~mlow];
+                float rw0 = 0, rw1 = 0, rw2 = 0;
+                const float *v0 = vary_table, *v1 = vary_table, *v2 = vary_table;
+                uint32_t draw = 0;
+                if (mcut) {
+                    rw0 = entry->rec.rw[0]; rw1 = entry->rec.rw[1]; rw2 = entry->rec.rw[2];
+                    draw = RZ_META_DRAW(entry->rec.meta);
+                    ref_varyings(entry->tri, vary_table, fan_vary_table, v0, v1, v2);
+                }
+                for (int sy = my0 & ~7; sy <= my1; sy += 8)
+                    for (int sx = mx0 & ~7; sx <= mx1; sx += 8) {
+                        const int x = sx + (lane & 7), y = sy + (lane >> 3);
+                        float w0, w1, w2;
+                        pixel_weights(m, x, y, w0, w1, w2);
+                        const float depth = m.z[0] * w0 + m.z[1] * w1 + m.z[2] * w2;                   /* :403-408 */
+                        bool inside = x >= mx0 && x <= mx1 && y >= my0 && y <= my1 &&
+                                      w0 > -RZ_EPS && w1 > -RZ_EPS && w2 > -RZ_EPS && depth == depth;   /* :516-519 */
+                        if (mcut && __any(inside)) {
+                            const DrawRec &D = draw_table[draw];
+                            const int tc = D.family == 0 ? RZ_BV_TEXCOORD : RZ_PV_TEXCOORD;
+                            const float q0 = rw0 * w0, q1 = rw1 * w1, q2 = rw2 * w2;
+                            const float norm = 1 / (q0 + q1 + q2);
+                            const float tu = (v0[tc] * q0 + v1[tc] * q1 + v2[tc] * q2) * norm;
+                            const float tv = (v0[tc + 1] * q0 + v1[tc + 1] * q1 + v2[tc + 1] * q2) * norm;
+                            if (inside) {
+                                float alpha = D.base[3];
+                                if (D.maps[0].data) alpha *= sample_repeat(D.maps[0], tu, tv).w;
+                                if (alpha < D.alpha_cutoff) inside = false;
+                            }
+                        }
+                        if (inside) {
+                            const uint32_t bits = __float_as_uint(depth + 0.0f);
+                            const uint32_t up = bits ^ ((uint32_t)((int32_t)bits >> 31) | 0x80000000u);
+                            atomicMin(&keys[(y - sq_y0) * 32 + (x - sq_x0)], ((unsigned long long)up << 32) | mlow);
+                        }
+                    }
+            }
+        };
+
+        /* ---- the walk: a group of 64 boxes per wave and turn, the next group asked for a turn ahead */
+        uint2 nbox = make_uint2(RZ_BBOX_EMPTY_X, 0u);
+        {
+            const uint32_t e = (uint32_t)wave * 64u + (uint32_t)lane;
+            if (e < count) nbox = boxes[e];
+        }
+        for (uint32_t base = (uint32_t)wave * 64u; base < count; base += 64u * RZ_CROWD_WAVES) {
+            const uint2 box = nbox;
+            const uint32_t e = base + (uint32_t)lane, next = e + 64u * RZ_CROWD_WAVES;
+            nbox = make_uint2(RZ_BBOX_EMPTY_X, 0u);
+            if (next < count) nbox = boxes[next];
+            const bool hit = e < count && box_overlaps(make_uint2(box.x, box.y & 0x7fffffffu), sq_x0, sq_y0, sq_x1, sq_y1);
+            const unsigned long long hits = __ballot(hit);
+            if (!hits) continue;
+            if (hit) ring[(ring_tail + __builtin_amdgcn_mbcnt_hi((uint32_t)(hits >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hits, 0u))) & 127u] = e;
+            ring_tail += (uint32_t)__popcll(hits);
+            if (ring_tail - ring_head >= 64u) rasterise(64u);
+        }
+        if (ring_tail != ring_head) rasterise(ring_tail - ring_head);
+        __syncthreads();
+
+        /* ---- the square's blocks of 16x8 pixels: keys against the depth buffer, then as rz_strip_kernel ends a block */
+        const int blocks_x = edge / 16, blocks = blocks_x * (edge / 8);
+        for (int block = wave; block < blocks; block += RZ_CROWD_WAVES) {
+            const int bx0 = sq_x0 + (block % blocks_x) * 16, by0 = sq_y0 + (block / blocks_x) * 8;
+            if (bx0 >= P.width || by0 >= P.height) continue;        /* uniform */
+            const int py = by0 + (lane >> 3);
+            bool valid[2];
+            uint32_t pixel[2], ref_of[2];
+            float zcur[2];
+            for (int q = 0; q < 2; q++) {
+                const int px = bx0 + 8 * q + (lane & 7);
+                valid[q] = px < P.width && py < P.height;
+                pixel[q] = (uint32_t)py * (uint32_t)P.width + (uint32_t)px;
+                ref_of[q] = RZ_REF_NONE;
+                zcur[q] = P.clear_depth;
+                if (valid[q] && !P.clear_depth_pending) zcur[q] = P.depth[pixel[q]];
+                const unsigned long long key = valid[q] ? keys[(py - sq_y0) * 32 + (px - sq_x0)] : ~0ull;
+                if (key == ~0ull) continue;
+                const uint32_t up = (uint32_t)(key >> 32);
+                const float depth = __uint_as_float(up ^ ((up >> 31) ? 0x80000000u : 0xffffffffu));
+                if (depth <= zcur[q]) {                                                             /* :523 */
+                    const BinEntry *e = &list[~(uint32_t)key];
+                    zcur[q] = depth;
+                    ref_of[q] = e->tri | (RZ_META_FAMILY(e->rec.meta) << 28);
+                }
+            }
+            finish_block(P, pass_index, bx0, by0, lane, valid, pixel, zcur, ref_of);
+        }
+        __syncthreads();                                            /* the keys are set up again for the next square */
+    }
+}
+
+/* K5  per-family fragment kernels behind rz_strip_kernel / rz_blend_visibility_kernel:
  * every lane shades the one fragment its pixel refers to. */
 template <int FAMILY, bool NARROW = false, class TABLES = GlobalTables>
 RZ_DEV void shade_pixel(const PassParams &P, const TriRec *__restrict__ tri_base, const TriRec *__restrict__ fan_base,
@@ -2190,7 +2255,6 @@ RZ_DEV void shade_pixel(const PassParams &P, const TriRec *__restrict__ tri_base
     const bool valid = px < P.width && py < P.height;
     const uint32_t pixel = (uint32_t)py * (uint32_t)P.width + (uint32_t)px;
     uint32_t myref = valid ? ref_table[pixel] : RZ_REF_NONE;
-    if (RZ_SKIP(P)) myref = RZ_REF_NONE;
     /* the rasteriser tagged the reference with the fragment's family (RZ_REF_NONE reads as family 3) */
     const bool want = ((myref >> 28) & 3u) == (uint32_t)FAMILY;
     if (!__any(want)) return;
@@ -2200,39 +2264,12 @@ RZ_DEV void shade_pixel(const PassParams &P, const TriRec *__restrict__ tri_base
     if (want && !P.clear_color_pending) ccur = P.color[pixel];
     TriRec m;
     const float *m0 = vary_table, *m1 = vary_table, *m2 = vary_table;
-    if (FAMILY == 2) {
-        /* a sky triangle usually spans the whole wave: then its record and varyings are the same
-         * for every lane and come through scalar loads */
-        const uint32_t first = (uint32_t)__builtin_amdgcn_readlane((int)myref, __ffsll((long long)__ballot(want)) - 1);
-        if (__all(!want || myref == first)) {
-            fetch_ref(first, tri_table, fan_table, vary_table, fan_vary_table, m, m0, m1, m2);
-            shade_lanes<FAMILY>(P, draw_table, want, m, m0, m1, m2, px, py, ccur);
-            if (want) P.color[pixel] = ccur;
-            return;
-        }
-    }
     if (want) fetch_ref(myref, tri_table, fan_table, vary_table, fan_vary_table, m, m0, m1, m2);
     shade_lanes<FAMILY, NARROW, TABLES>(P, draw_table, want, m, m0, m1, m2, px, py, ccur);
     if (want) P.color[pixel] = ccur;
 }
 
-/* over every tile of every pass (grid x, y = tile, z = pass): for a family that fills most of the
- * screen (the skybox).  Pixels are independent here, so a wave takes two 32-pixel rows of the tile:
- * reference and colour planes are read and written as whole 128-byte lines. */
-template <int FAMILY>
-__global__ void __launch_bounds__(256) rz_shade_kernel(const PassParams *__restrict__ passes,
-        const TriRec *__restrict__ tri_base, const TriRec *__restrict__ fan_base,
-        const float *__restrict__ vary_base, const float *__restrict__ fan_vary_base,
-        const char *__restrict__ upload_base, const uint32_t *__restrict__ ref_base) {
-    const PassParams P = passes[blockIdx.z];          /* by value: one burst of scalar loads up front, not one wait per field */
-    if ((int)blockIdx.x >= P.tiles_x || (int)blockIdx.y >= P.tiles_y) return;
-    if (P.control[2] != 0u) return;                   /* the pass did not run: its reference plane holds nothing */
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    shade_pixel<FAMILY>(P, tri_base, fan_base, vary_base, fan_vary_base, upload_base, ref_base,
-                        (int)blockIdx.x * RZ_TILE_W + (lane & 31), (int)blockIdx.y * RZ_TILE_H + wave * 2 + (lane >> 5));
-}
-
-/* The same for the skybox family with PPL pixels per lane: a wave takes 2 * PPL rows of the tile
+/* The skybox family, over every tile of every pass (grid x, y = tile, z = pass), PPL pixels per lane: a wave takes 2 * PPL rows of the tile
  * (lane = the pixel at (lane & 31, lane >> 5) of its rows and those 2, 4, .. rows below), so the
  * per-wave work -- the pass's parameters, the triangle's record and varyings, the draw's face
  * descriptors, all through scalar loads when one sky triangle spans the wave -- is paid once per
@@ -2406,7 +2443,7 @@ __global__ void __launch_bounds__(256 / PPL) rz_sky_kernel(const PassParams *__r
         }
     }
     for (int q = 0; q < PPL; q++)
-        myref[q] = (px < P.width && py[q] < P.height && !RZ_SKIP(P)) ? ref_table[pixel[q]] : RZ_REF_NONE;
+        myref[q] = (px < P.width && py[q] < P.height) ? ref_table[pixel[q]] : RZ_REF_NONE;
     for (int q = 0; q < PPL; q++) {
         want[q] = ((myref[q] >> 28) & 3u) == 2u;        /* RZ_REF_NONE reads as family 3 */
         any_want |= want[q];
@@ -2471,7 +2508,7 @@ __global__ void __launch_bounds__(256) rz_shade_list_kernel(const PassParams *__
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     LdsTables::fill();              /* a workgroup shades many blocks: the tables' copy is paid once */
     /* block lists come from rz_strip_kernel, which takes passes without blending only; tile lists may hold
-     * blended fragments (passes cut up by rz_visibility_kernel<2, true>), which need the colour itself */
+     * blended fragments (passes cut up by rz_blend_visibility_kernel), which need the colour itself */
     typedef typename std::conditional<BLOCKS, LdsTablesBytes, LdsTables>::type Tables;
     /* lane q holds the length of part q of this family's list */
     const uint32_t my_count = min(queue_counts[(FAMILY * RZ_QUEUE_WAYS + lane) * RZ_QUEUE_PAD], queue_capacity);
@@ -2607,7 +2644,7 @@ __global__ void __launch_bounds__(64) rz_overlay_texture_kernel(uint32_t *__rest
 }
 
 /* row-major float4 image -> device layout (8x8 tiles where the size allows) */
-__global__ void rz_texture_tile_kernel(const float4 *linear, float4 *texels, int w, int h, int flags, int mbits) {
+__global__ void rz_texture_tile_kernel(const float4 *linear, float4 *texels, int w, int h, int flags) {
     int x = blockIdx.x * 16 + (threadIdx.x & 15), y = blockIdx.y * 16 + (threadIdx.x >> 4);
     if (x >= w || y >= h) return;
     texels[texel_index(w, flags, x, y)] = linear[(size_t)y * w + x];
@@ -2632,7 +2669,7 @@ __global__ void rz_texture_display_kernel(const void *texels, uint32_t *bytes, s
     bytes[i] = pack_rgb(c, 0u);
 }
 
-__global__ void rz_texture_untile_kernel(const void *texels, float4 *linear, int w, int h, int flags, int mbits) {
+__global__ void rz_texture_untile_kernel(const void *texels, float4 *linear, int w, int h, int flags) {
     int x = blockIdx.x * 16 + (threadIdx.x & 15), y = blockIdx.y * 16 + (threadIdx.x >> 4);
     if (x >= w || y >= h) return;
     uint32_t i = texel_index(w, flags, x, y);

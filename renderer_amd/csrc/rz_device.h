@@ -55,6 +55,10 @@ enum { RZ_PV_WORLD = 0, RZ_PV_NORMAL = 3, RZ_PV_TANGENT = 6, RZ_PV_BITANGENT = 9
 #define RZ_ORDERED_LIST 2u          /* the third list, after the blinn and pbr families': tiles of a pass with blended draws
                                      * where a blended fragment lies over another fragment of the pass */
 #define RZ_QUEUE_PAD 32u            /* counters sit one 128-byte line apart: atomics on one line serialise */
+#define RZ_VISIBILITY_LIST 3u       /* the fourth: tiles of such a pass that rz_blend_visibility_kernel has to look at */
+#define RZ_LISTS 4u
+#define RZ_CROWD_COUNT_AT (RZ_LISTS * RZ_QUEUE_WAYS * RZ_QUEUE_PAD)    /* in queue_counts, behind the work lists' lengths */
+#define RZ_BIN_CROWDED 0x80000000u  /* in bin_range[].y: the bin is rz_crowd_kernel's, rz_strip_kernel leaves it alone */
 #define RZ_TILE_W 32                /* raster / shade workgroup tile: 4 waves of 8x8 side by side, */
 #define RZ_TILE_H 8                 /* so a tile row is one 128-byte line of a 4-byte plane */
 
@@ -68,13 +72,10 @@ enum { RZ_FMT_RGBA32F = 0, RZ_FMT_R32F = 1 };
  *   RGBE8   3 mantissa bytes + shared exponent byte e,         Radiance .hdr maps
  *           rgb = (float)mantissa * 2^(e - 136), alpha = 1 */
 enum { RZ_TEX_TILED = 1, RZ_TEX_R32F = 2, RZ_TEX_UNORM8 = 4, RZ_TEX_SRGB8 = 8, RZ_TEX_RGBE8 = 16,
-       /* layouts tried against the 8x8 row-major tiles (MI355R_TEX_LAYOUT=1 / 2): 16x16 tiles; 8x8 tiles with the
-        * texel's column and row bits interleaved (Z order) */
-       RZ_TEX_TILE16 = 32, RZ_TEX_MORTON = 64,
        /* not an image format but a plane derived from one: per texel the three bytes draw_fragment writes for
         * its colour (saturate, * 255, truncate: graphics.c:452-468, maths.c:33), for skybox faces */
        RZ_TEX_DISPLAY8 = 128,
-       RZ_TEX_LAYOUT = RZ_TEX_TILED | RZ_TEX_TILE16 | RZ_TEX_MORTON };
+       RZ_TEX_LAYOUT = RZ_TEX_TILED };
 
 /* a sampled image; data == nullptr means "no map bound" */
 struct DevTex {
@@ -192,7 +193,7 @@ struct PassParams {
     /* binning */
     int32_t bins_x, bins_y;
     rz_gptr<uint32_t> bin_counts;           /* [chunks of 64 triangles][bins]: entries, then first entry */
-    rz_gptr<uint2> bin_range;               /* per bin: {first entry, entries} */
+    rz_gptr<uint2> bin_range;               /* per bin: {first entry, entries | RZ_BIN_CROWDED} */
     rz_gptr<BinEntry> bin_list;
     rz_gptr<uint2> bin_boxes;               /* per list entry: x0 | x1 << 16, y0 | y1 << 16 | alpha-cutoff << 31 -- all that walking a list reads */
     uint32_t bin_capacity;
@@ -202,8 +203,8 @@ struct PassParams {
      * used, [2] error bits, [3] triangles queued for clipping */
     rz_gptr<uint32_t> control;
     rz_gptr<unsigned long long> counters;   /* nullptr unless counting is enabled */
-    int32_t debug_skip;             /* measurement only (MI355R_DEBUG_SKIP, read by builds with -DRZ_MEASURE; otherwise ignored): 1 no shading, 2 no coverage tests either,
-                                     * 3 no rasteriser at all, 4 the rasteriser without its walk over the bin lists */
+    uint32_t crowd_min;             /* a bin with at least this many list entries is taken by rz_crowd_kernel, one workgroup for the
+                                     * whole bin; 0 = none (passes with blended draws, fragment counting) */
     int32_t micro_area;             /* triangles whose box covers at most this many pixels of a wave's block
                                      * are rasterised one per lane; 0 = none */
     int32_t micro_min_list;         /* ... in bins whose list has at least this many entries */
@@ -234,7 +235,14 @@ struct PassParams {
      * host runs those passes again, in order, with scratch of the sizes they reported. */
     rz_gptr<uint32_t> flush_flag;
     int32_t level;                  /* 0: depends on no other pass of its flush */
+    int32_t crowd_small;            /* rz_crowd_kernel: largest box (pixels) a lane rasterises on its own */
+    /* a pass with blended draws: the list (RZ_ORDERED_LIST or RZ_VISIBILITY_LIST) rz_bin_scan_kernel puts the tiles of
+     * its bins on that are not empty -- the kernel behind it then starts no wave for the rest of the frame; -1: none */
+    int32_t scan_list;
     int32_t pad_;
+    /* per batch: the squares of its crowded bins ({pass << 16 | bin, square | fine << 8}), as many as
+     * queue_counts[RZ_CROWD_COUNT_AT] says */
+    rz_gptr<uint2> crowd_list;
 };
 
 enum { RZ_ERR_FAN_OVERFLOW = 1, RZ_ERR_BIN_OVERFLOW = 2, RZ_ERR_QUEUE_OVERFLOW = 4, RZ_ERR_SKIPPED = 8 };

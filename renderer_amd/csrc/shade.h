@@ -225,16 +225,6 @@ RZ_DEV uint32_t texel_index(int w, int flags, int c, int r) {
         uint32_t tile = __umul24((uint32_t)r >> 3, (uint32_t)w >> 3) + ((uint32_t)c >> 3);      /* sides stay below 2^16: a full-rate multiply */
         return (tile << 6) | (((uint32_t)r & 7u) << 3) | ((uint32_t)c & 7u);
     }
-    if (flags & RZ_TEX_TILE16) {
-        uint32_t tile = ((uint32_t)r >> 4) * ((uint32_t)w >> 4) + ((uint32_t)c >> 4);
-        return (tile << 8) | (((uint32_t)r & 15u) << 4) | ((uint32_t)c & 15u);
-    }
-    if (flags & RZ_TEX_MORTON) {
-        uint32_t tile = ((uint32_t)r >> 3) * ((uint32_t)w >> 3) + ((uint32_t)c >> 3);
-        const uint32_t x = (uint32_t)c, y = (uint32_t)r;
-        const uint32_t z = (x & 1u) | ((y & 1u) << 1) | ((x & 2u) << 1) | ((y & 2u) << 2) | ((x & 4u) << 2) | ((y & 4u) << 3);
-        return (tile << 6) | z;
-    }
     return (uint32_t)r * (uint32_t)w + (uint32_t)c;
 }
 
