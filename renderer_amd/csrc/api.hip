@@ -168,7 +168,8 @@ struct Lane {
     DevBuf<uint2> bbox;
     DevBuf<uint32_t> clip_list, ref;
     DevBuf<uint2> bin_range;
-    DevBuf<SkyBin> sky_bins;            /* per bin of the batch: rz_sky_regions_kernel's record */
+    DevBuf<SkyBin> sky_bins;            /* per bin of the batch: rz_bin_class_kernel's record */
+    DevBuf<uint32_t> bin_class;         /* per bin of the batch: what rz_strip_kernel has to do with it */
     DevBuf<uint32_t> bin_counts, queue, queue_counts, tile_listed;
     DevBuf<uint2> crowd_list;           /* per batch: the squares of its crowded bins (rz_crowd_kernel), at most 16 per bin */
     DevBuf<BinEntry> bin_list;
@@ -1833,6 +1834,7 @@ static void prepare_batch(const Batch &b, const FlushRecord &fr, bool reserve_on
     reserve(L.fan_vary, fans * RZ_MAX_POLY * RZ_VARY_STRIDE, st);
     reserve(L.bin_range, bins, st);
     if (g.sky_bins) reserve(L.sky_bins, bins, st);
+    reserve(L.bin_class, bins, st);
     reserve(L.bin_counts, matrix, st);
     /* tiles are dealt to the parts of a list by their index: a part holds at most its even share */
     /* (32x8 tiles, or the two 16x8 blocks of each that rz_strip_kernel lists) */
@@ -1976,7 +1978,7 @@ static void launch_batch(const Batch &b, const std::vector<PassPlan> &plans, cha
             tris += plans[i].T;
             bins += (size_t)((plans[i].fb->pub.width + RZ_BIN - 1) / RZ_BIN) * ((plans[i].fb->pub.height + RZ_BIN - 1) / RZ_BIN);
         }
-        if (L.bin_range.cap < bins || (g.sky_bins && L.sky_bins.cap < bins)) fatal("per-bin scratch of lane %d is smaller than the batch it is about to run", b.lane);
+        if (L.bin_range.cap < bins || L.bin_class.cap < bins || (g.sky_bins && L.sky_bins.cap < bins)) fatal("per-bin scratch of lane %d is smaller than the batch it is about to run", b.lane);
         const bool uses_ref = !(b.has_blend && !splits_blend(batch_tiles, n));
         if (L.crowd_list.cap < 16 * bins) fatal("the crowded-bin list of lane %d is smaller than the batch it is about to run", b.lane);
         if (L.queue_counts.cap < RZ_LISTS * RZ_QUEUE_WAYS * RZ_QUEUE_PAD + RZ_QUEUE_PAD || L.queue.cap < RZ_LISTS * RZ_QUEUE_WAYS * (size_t)queue_capacity ||
@@ -2033,12 +2035,13 @@ static void launch_batch(const Batch &b, const std::vector<PassPlan> &plans, cha
             const int strip = !g.strip_long ? g.strip : std::min(few, longest >= g.strip_long ? 1 : longest >= g.strip_long / 2 ? std::min(g.strip, 2) : g.strip);
             const unsigned strips_per_bin = RZ_BIN / (8u * strip);
             auto kernel = strip == 8 ? rz_strip_kernel<8> : strip == 4 ? rz_strip_kernel<4> : strip == 2 ? rz_strip_kernel<2> : rz_strip_kernel<1>;
-            /* bins with nothing but skybox triangles are left to rz_sky_kernel */
+            /* bins with nothing but skybox triangles are left to rz_sky_kernel; empty bins are finished by the kernel that says so */
             sky_bins = g.sky_bins && (b.families & (1 << RZ_FAMILY_SKYBOX));
-            if (sky_bins) rz_sky_regions_kernel<<<dim3((unsigned)max_bins, n), dim3(64), 0, st>>>(passes, L.bin_list.ptr, L.bin_range.ptr, L.sky_bins.ptr);
+            rz_bin_class_kernel<<<dim3((unsigned)max_bins, n), dim3(64), 0, st>>>(passes, L.bin_list.ptr, L.bin_range.ptr,
+                                                                             sky_bins ? L.sky_bins.ptr : nullptr, L.bin_class.ptr);
             if (g.verbose) fprintf(stderr, "mi355r: batch of %u passes, longest bin list last time %u entries, strips of %d\n", n, longest, strip);
             snprintf(g.last_raster_kernel, sizeof g.last_raster_kernel, "rz_strip_kernel<%d>", strip);
-            /* crowded bins first, a workgroup per bin: the launch is as long as its fullest bin takes */
+            /* crowded bins first, a workgroup per square of a bin: the launch is as long as its fullest square takes */
             if (g.crowd_min && !g.counting) {
                 size_t batch_bins = 0;
                 for (size_t i : b.members)
@@ -2047,8 +2050,12 @@ static void launch_batch(const Batch &b, const std::vector<PassPlan> &plans, cha
                     passes, L.bin_list.ptr, L.bin_boxes.ptr, L.vary.ptr, L.fan_vary.ptr, db, L.bin_range.ptr, L.crowd_list.ptr, L.queue_counts.ptr,
                     (uint32_t)std::min<size_t>(16 * batch_bins, 0xffffffffu));
             }
-            kernel<<<dim3(bin_columns * 2 * n, bin_rows * strips_per_bin), dim3(128), 0, st>>>(
-                passes, L.bin_list.ptr, L.bin_boxes.ptr, L.vary.ptr, L.fan_vary.ptr, db, L.bin_range.ptr, n, sky_bins ? L.sky_bins.ptr : nullptr);
+            /* passes of one size: a strip then finds its bin's class without reading its pass's parameters */
+            int uniform_w = plans[b.members[0]].fb->pub.width, uniform_h = plans[b.members[0]].fb->pub.height;
+            for (size_t i : b.members)
+                if (plans[i].fb->pub.width != uniform_w || plans[i].fb->pub.height != uniform_h) uniform_w = uniform_h = 0;
+            kernel<<<dim3(n, bin_columns * 2, bin_rows * strips_per_bin), dim3(128), 0, st>>>(
+                passes, L.bin_list.ptr, L.bin_boxes.ptr, L.vary.ptr, L.fan_vary.ptr, db, L.bin_range.ptr, L.bin_class.ptr, uniform_w, uniform_h);
         }
         stamp();
         if (b.families & (1 << RZ_FAMILY_SKYBOX))

@@ -1356,27 +1356,26 @@ RZ_DEV void raster_tile(const PassParams &P, const uint32_t pass_index, const ui
     }
 }
 
-/* The order in which the workgroups of a tile kernel start (that of their index) over the tiles of a
+/* The order in which the workgroups of rz_strip_kernel start (that of their index) over the strips of a
  * batch of passes.  The pass is the fastest part of the index, and columns and rows count outwards from
- * the middle of the frame: what takes long -- the tiles a model lies in, usually in the middle -- starts
- * first in every pass of the batch, and what is still running when the launch ends are the cheap tiles
- * at the frames' borders.  (With the pass as the slowest part the last frame's long tiles were the
- * launch's tail: 12.8 -> 11.0 us per frame in the strip kernel for the helmet at 1080p, 26.4 -> 19.6 for
+ * the middle of the frame: what takes long -- the strips a model lies in, usually in the middle -- starts
+ * first in every pass of the batch, and what is still running when the launch ends are the cheap strips
+ * at the frames' borders.  (With the pass as the slowest part the last frame's long strips were the
+ * launch's tail: 12.8 -> 11.0 us per frame for the helmet at 1080p, 26.4 -> 19.6 for
  * azura at 800x600, 80.7 -> 62.2 for dieselpunk at 4K.)  The unit of that order is the bin, not
- * the tile: the tiles of a bin walk the same list and start next to each other.
- * grid: x = pass + passes * column, y = row. */
+ * the strip: the strips of a bin walk the same list and start next to each other.
+ * grid: x = pass, y = column (whole bins: an even number of 32-pixel columns), z = row (rows_per_bin per bin row)
+ * -- three dimensions, so that no index has to be divided by a number of passes only known at run time: a
+ * wave that finds nothing to do in its bin must get there in a handful of scalar instructions. */
 struct TileOrder { uint32_t pass, column, row; };
 RZ_DEV uint32_t outwards(uint32_t turn, uint32_t count) {      /* 0, 1, 2, .. -> middle, middle + 1, middle - 1, .. */
     return (turn & 1u) ? (count - 1u) / 2u + (turn + 1u) / 2u : (count - 1u) / 2u - (turn + 1u) / 2u;
 }
-RZ_DEV TileOrder tile_order(uint32_t num_passes, uint32_t rows_per_bin) {
+RZ_DEV TileOrder tile_order(uint32_t rows_per_bin) {
     TileOrder o;
-    /* the grid covers whole bins: an even number of 32-pixel columns, rows_per_bin rows per bin row */
-    const uint32_t columns = gridDim.x / num_passes, rows = gridDim.y;
-    const uint32_t column_turn = blockIdx.x / num_passes;
-    o.pass = blockIdx.x % num_passes;
-    o.column = outwards(column_turn / 2u, columns / 2u) * 2u + (column_turn & 1u);
-    o.row = outwards(blockIdx.y / rows_per_bin, rows / rows_per_bin) * rows_per_bin + blockIdx.y % rows_per_bin;
+    o.pass = blockIdx.x;
+    o.column = outwards(blockIdx.y / 2u, gridDim.y / 2u) * 2u + (blockIdx.y & 1u);
+    o.row = outwards(blockIdx.z / rows_per_bin, gridDim.z / rows_per_bin) * rows_per_bin + blockIdx.z % rows_per_bin;
     return o;
 }
 
@@ -1616,7 +1615,7 @@ __global__ void __launch_bounds__(128) rz_blend_visibility_kernel(const PassPara
  * entries come through scalar loads, and depth, reference and colour make no round trip between two
  * kernels.  Not while fragments are counted (the counts belong to the rasteriser's stage).
  *
- * rz_sky_regions_kernel, one wave per bin, writes a record for EVERY bin of the batch: whether it is
+ * rz_bin_class_kernel, one wave per bin, writes a record for EVERY bin of the batch: whether it is
  * such a bin, where its list starts, its draw, and for each of the 32 REGIONS of 32x4 pixels a wave of
  * rz_sky_kernel takes the set of entries that can touch it (box and conservative edge test, as
  * rz_strip_kernel culls its blocks, lane = region).  The two triangles of a sky box face share their
@@ -1638,35 +1637,84 @@ RZ_DEV bool sky_only_bin(const PassParams &P, const BinEntry *list, uint32_t cou
 }
 RZ_DEV uint32_t sky_region_of(int tx0, int ry0) { return (uint32_t)(((ry0 % RZ_BIN) / 4) * 2 + (tx0 % RZ_BIN) / RZ_TILE_W); }
 
-/* grid x = bin, y = pass of the batch */
-__global__ void __launch_bounds__(64) rz_sky_regions_kernel(const PassParams *__restrict__ passes,
-        const BinEntry *__restrict__ list_base, const uint2 *__restrict__ bin_range_base, SkyBin *__restrict__ sky_base) {
+/* What rz_strip_kernel has to do with a bin, worked out once per bin (one wave each; grid x = bin, y = pass of the
+ * batch) instead of by every one of its strips: RZ_BIN_STRIP = walk its list, RZ_BIN_DONE = nothing --
+ *   an EMPTY bin is finished right here: pending clears (and the blank references a kernel that looks at every
+ *     pixel's reference wants) are written a row of four pixels per lane, 256 contiguous bytes per bin row and
+ *     plane -- a frame without a sky box is mostly such bins, and as 32-byte pieces out of strips whose waves had
+ *     each read their pass's parameters and the bin's range first, their clears ran at a quarter of the memory's rate;
+ *   a bin with nothing but one sky box's triangles is rz_sky_kernel's, and gets its SkyBin record (above);
+ *   a crowded bin is rz_crowd_kernel's.
+ * A strip whose batch has passes of one size finds its bin's class with two kernel arguments and its own index,
+ * before it has read anything else. */
+enum { RZ_BIN_STRIP = 0, RZ_BIN_DONE = 1 };
+__global__ void __launch_bounds__(64) rz_bin_class_kernel(const PassParams *__restrict__ passes,
+        const BinEntry *__restrict__ list_base, const uint2 *__restrict__ bin_range_base, SkyBin *__restrict__ sky_base,
+        uint32_t *__restrict__ class_base) {
     const PassParams &P = passes[blockIdx.y];
-    if ((int)blockIdx.x >= P.bins_x * P.bins_y || P.control[2] != 0u) return;
-    uint2 range = (bin_range_base + P.bin_off)[blockIdx.x];
-    range.y &= ~RZ_BIN_CROWDED;
-    const BinEntry *list = list_base + P.list_off + range.x;
-    const bool sky = sky_only_bin(P, list, range.y);
+    if ((int)blockIdx.x >= P.bins_x * P.bins_y) return;
     const int lane = threadIdx.x & 63;
+    uint32_t *bin_class = class_base + P.bin_off + blockIdx.x;
+    if (P.control[2] != 0u) {                                   /* out of scratch, or left out: the pass is run again later */
+        if (lane == 0) *bin_class = RZ_BIN_DONE;
+        return;
+    }
+    uint2 range = (bin_range_base + P.bin_off)[blockIdx.x];
+    const bool crowded = (range.y & RZ_BIN_CROWDED) != 0u;
+    range.y &= ~RZ_BIN_CROWDED;
     const int bin_x0 = (int)(blockIdx.x % (uint32_t)P.bins_x) * RZ_BIN, bin_y0 = (int)(blockIdx.x / (uint32_t)P.bins_x) * RZ_BIN;
-    const int rx0 = bin_x0 + RZ_TILE_W * (lane & 1), ry0 = bin_y0 + 4 * ((lane >> 1) & 15);
-    uint32_t mine = 0, draw = 0;
-    if (sky) {
-        draw = RZ_META_DRAW(list[0].rec.meta);
-        for (uint32_t e = 0; e < range.y; e++) {
-            const float4 *q = (const float4*)&list[e];
-            const float4 c0 = q[1], c1 = q[2];
-            const uint2 box = entry_box(q[4]);
-            const bool hit = box_overlaps(make_uint2(box.x, box.y & 0x7fffffffu), rx0, ry0, rx0 + RZ_TILE_W - 1, ry0 + 3) &&
-                             !block_outside(c0, c1, (float)rx0 + 0.5f, (float)(rx0 + RZ_TILE_W - 1) + 0.5f, (float)ry0 + 0.5f, (float)ry0 + 3.5f);
-            mine |= (hit ? 1u : 0u) << e;
+    if (range.y == 0u) {
+        const bool blank_refs = P.ref_scanned != 0;
+        if (P.clear_color_pending || P.clear_depth_pending || blank_refs) {
+            const float d = P.clear_depth;
+            const uint32_t c = P.clear_color;
+            if ((P.width & 3) == 0) {
+                const int x = bin_x0 + (lane & 15) * 4;
+                if (x < P.width)
+                    for (int row = lane >> 4; row < RZ_BIN; row += 4) {
+                        const int py = bin_y0 + row;
+                        if (py >= P.height) break;
+                        const size_t pixel = (size_t)py * (size_t)P.width + (size_t)x;
+                        if (P.clear_depth_pending) *(float4 RZ_GLOBAL*)(P.depth + pixel) = make_float4(d, d, d, d);
+                        if (P.clear_color_pending) *(uint4 RZ_GLOBAL*)(P.color + pixel) = make_uint4(c, c, c, c);
+                        if (blank_refs) *(uint4 RZ_GLOBAL*)(P.ref + pixel) = make_uint4(RZ_REF_NONE, RZ_REF_NONE, RZ_REF_NONE, RZ_REF_NONE);
+                    }
+            } else {
+                for (int i = lane; i < RZ_BIN * RZ_BIN; i += 64) {
+                    const int px = bin_x0 + (i & (RZ_BIN - 1)), py = bin_y0 + i / RZ_BIN;
+                    if (px >= P.width || py >= P.height) continue;
+                    const size_t pixel = (size_t)py * (size_t)P.width + (size_t)px;
+                    if (P.clear_depth_pending) P.depth[pixel] = d;
+                    if (P.clear_color_pending) P.color[pixel] = c;
+                    if (blank_refs) P.ref[pixel] = RZ_REF_NONE;
+                }
+            }
         }
     }
-    SkyBin *rec = sky_base + P.bin_off + blockIdx.x;
-    if (lane < 32) rec->entries_of_region[lane] = (uint8_t)mine;
-    if (lane == 32) rec->count = sky ? range.y : 0u;
-    if (lane == 33) rec->first = range.x;
-    if (lane == 34) rec->draw = draw;
+    bool sky = false;
+    if (sky_base) {
+        const BinEntry *list = list_base + P.list_off + range.x;
+        sky = !crowded && sky_only_bin(P, list, range.y);
+        const int rx0 = bin_x0 + RZ_TILE_W * (lane & 1), ry0 = bin_y0 + 4 * ((lane >> 1) & 15);
+        uint32_t mine = 0, draw = 0;
+        if (sky) {
+            draw = RZ_META_DRAW(list[0].rec.meta);
+            for (uint32_t e = 0; e < range.y; e++) {
+                const float4 *q = (const float4*)&list[e];
+                const float4 c0 = q[1], c1 = q[2];
+                const uint2 box = entry_box(q[4]);
+                const bool hit = box_overlaps(make_uint2(box.x, box.y & 0x7fffffffu), rx0, ry0, rx0 + RZ_TILE_W - 1, ry0 + 3) &&
+                                 !block_outside(c0, c1, (float)rx0 + 0.5f, (float)(rx0 + RZ_TILE_W - 1) + 0.5f, (float)ry0 + 0.5f, (float)ry0 + 3.5f);
+                mine |= (hit ? 1u : 0u) << e;
+            }
+        }
+        SkyBin *rec = sky_base + P.bin_off + blockIdx.x;
+        if (lane < 32) rec->entries_of_region[lane] = (uint8_t)mine;
+        if (lane == 32) rec->count = sky ? range.y : 0u;
+        if (lane == 33) rec->first = range.x;
+        if (lane == 34) rec->draw = draw;
+    }
+    if (lane == 0) *bin_class = (range.y == 0u || crowded || sky) ? (uint32_t)RZ_BIN_DONE : (uint32_t)RZ_BIN_STRIP;
 }
 
 /* What a wave does with a finished block of 16x8 pixels of a pass without blending (rz_strip_kernel,
@@ -1745,65 +1793,34 @@ template <int STRIP>
 __global__ void __launch_bounds__(128) rz_strip_kernel(const PassParams *__restrict__ passes,
         const BinEntry *__restrict__ list_base, const uint2 *__restrict__ box_base,
         const float *__restrict__ vary_base, const float *__restrict__ fan_vary_base,
-        const char *__restrict__ upload_base, const uint2 *__restrict__ bin_range_base, uint32_t num_passes,
-        const SkyBin *__restrict__ sky_base) {
+        const char *__restrict__ upload_base, const uint2 *__restrict__ bin_range_base,
+        const uint32_t *__restrict__ class_base, int uniform_width, int uniform_height) {
     constexpr int PPL = 2;
     static_assert(RZ_BIN % (8 * STRIP) == 0, "a strip lies inside one bin");
-    const TileOrder o = tile_order(num_passes, RZ_BIN / (8 * STRIP));
+    const TileOrder o = tile_order(RZ_BIN / (8 * STRIP));
     const uint32_t pass_index = o.pass, tile_column = o.column, strip_row = o.row;
+    const int sy0 = (int)strip_row * 8 * STRIP, tx0 = (int)tile_column * RZ_TILE_W;
+    /* the passes of the batch have one size (uniform_width != 0): what the bin's class says is known before the pass's
+     * parameters are asked for, and most strips of most frames end here */
+    if (uniform_width) {
+        if (tx0 >= uniform_width || sy0 >= uniform_height) return;
+        const uint32_t bins_x = ((uint32_t)uniform_width + RZ_BIN - 1u) / RZ_BIN, bins_y = ((uint32_t)uniform_height + RZ_BIN - 1u) / RZ_BIN;
+        if (class_base[pass_index * (bins_x * bins_y) + (uint32_t)(sy0 / RZ_BIN) * bins_x + (uint32_t)(tx0 / RZ_BIN)] != (uint32_t)RZ_BIN_STRIP) return;
+    }
     const PassParams P = passes[pass_index];
-    const int sy0 = (int)strip_row * 8 * STRIP;
     if ((int)tile_column >= P.tiles_x || sy0 >= P.height) return;
-    const uint32_t failed = P.control[2];       /* looked at below, together with what else the pass's parameters lead to: one round trip, not three */
     const BinEntry *list_table = list_base + P.list_off;
     const float *vary_table = vary_base + (size_t)P.tri_off * 3 * RZ_VARY_STRIDE;
     const float *fan_vary_table = fan_vary_base + (size_t)P.fan_off * RZ_MAX_POLY * RZ_VARY_STRIDE;
     const DrawRec *draw_table = (const DrawRec*)(upload_base + P.draws_off);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int tx0 = (int)tile_column * RZ_TILE_W;
     const int bx0 = tx0 + wave * 8 * PPL, bx1 = bx0 + 8 * PPL - 1;
     int px[PPL];
     for (int q = 0; q < PPL; q++) px[q] = bx0 + 8 * q + (lane & 7);
     const int bin = (sy0 / RZ_BIN) * P.bins_x + tx0 / RZ_BIN;
     const uint2 range = (bin_range_base + P.bin_off)[bin];          /* {first entry, entries} */
-    const uint32_t elsewhere = sky_base ? sky_base[P.bin_off + (uint32_t)bin].count : 0u;
-    if (failed != 0u) return;                                       /* out of scratch, or left out: the pass is run again later */
-    if (elsewhere != 0u || (range.y & RZ_BIN_CROWDED)) return;      /* rz_sky_kernel / rz_crowd_kernel does all of it */
-    const uint32_t count = range.y;
-    if (count == 0) {               /* nothing but the pending clears (uniform over the workgroup) */
-        const bool blank_refs = P.ref_scanned;                      /* a kernel that scans every pixel's reference follows */
-        if (!P.clear_color_pending && !P.clear_depth_pending && !blank_refs) return;
-        if ((P.width & 3) == 0) {
-            /* rows of four pixels per thread: the workgroup's 32 columns are one 128-byte line per plane and row,
-             * written by eight threads side by side (two pixels per lane as the rasteriser holds them make 32-byte
-             * pieces: a frame without a sky box is mostly such bins, and their clears ran at a quarter of the
-             * memory's rate) */
-            const int x = tx0 + (int)(threadIdx.x & 7u) * 4;
-            if (x >= P.width) return;
-            const float d = P.clear_depth;
-            const uint32_t c = P.clear_color;
-            for (int row = (int)(threadIdx.x >> 3); row < 8 * STRIP; row += 16) {
-                const int py = sy0 + row;
-                if (py >= P.height) break;
-                const size_t pixel = (size_t)py * (size_t)P.width + (size_t)x;
-                if (P.clear_depth_pending) *(float4 RZ_GLOBAL*)(P.depth + pixel) = make_float4(d, d, d, d);
-                if (P.clear_color_pending) *(uint4 RZ_GLOBAL*)(P.color + pixel) = make_uint4(c, c, c, c);
-                if (blank_refs) *(uint4 RZ_GLOBAL*)(P.ref + pixel) = make_uint4(RZ_REF_NONE, RZ_REF_NONE, RZ_REF_NONE, RZ_REF_NONE);
-            }
-            return;
-        }
-        for (int k = 0; k < STRIP; k++) {
-            const int py = sy0 + 8 * k + (lane >> 3);
-            for (int q = 0; q < PPL; q++) {
-                if (px[q] >= P.width || py >= P.height) continue;
-                const uint32_t pixel = (uint32_t)py * (uint32_t)P.width + (uint32_t)px[q];
-                if (P.clear_depth_pending) P.depth[pixel] = P.clear_depth;
-                if (P.clear_color_pending) P.color[pixel] = P.clear_color;
-                if (blank_refs) P.ref[pixel] = RZ_REF_NONE;
-            }
-        }
-        return;
-    }
+    if (!uniform_width && class_base[P.bin_off + (uint32_t)bin] != (uint32_t)RZ_BIN_STRIP) return;
+    const uint32_t count = range.y;                                 /* (a bin of this class is not empty and not marked crowded) */
     const BinEntry *list = list_table + range.x;
     const uint2 *boxes = box_base + P.list_off + range.x;
 
