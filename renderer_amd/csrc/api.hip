@@ -171,7 +171,6 @@ struct Lane {
     DevBuf<SkyBin> sky_bins;            /* per bin of the batch: rz_bin_class_kernel's record */
     DevBuf<uint32_t> bin_class;         /* per bin of the batch: what rz_strip_kernel has to do with it */
     DevBuf<uint32_t> bin_counts, queue, queue_counts, tile_listed;
-    DevBuf<uint2> crowd_list;           /* per batch: the squares of its crowded bins (rz_crowd_kernel), at most 16 per bin */
     DevBuf<BinEntry> bin_list;
     DevBuf<uint2> bin_boxes;
 };
@@ -200,8 +199,6 @@ struct Context {
      * 1080p frames lose as much to the three extra launches) */
     int split_blend = 2;
     bool verbose = false;                   /* MI355R_VERBOSE */
-    unsigned crowd_min = 0;                 /* MI355R_CROWD_MIN: bins with at least this many list entries go to rz_crowd_kernel; 0 = none */
-    int crowd_small = 64;                   /* MI355R_CROWD_SMALL: largest box (pixels) one lane of rz_crowd_kernel rasterises on its own */
     bool record_copies = true;              /* MI355R_RECORD_COPIES=0: texture_from_*buffer always flushes first */
     int micro_area = 32;                    /* MI355R_MICRO_AREA: largest box (pixels of a block) rasterised one triangle per lane; 0 = off */
     int shade_workgroups = 4096;            /* 256-thread workgroups per shade launch (compute units x 16) */
@@ -328,10 +325,6 @@ extern "C" int mi355r_init(int device) {
         env = getenv("MI355R_SPLIT_BLEND");
         if (env) g.split_blend = atoi(env) != 0 ? 1 : 0;
         g.verbose = getenv("MI355R_VERBOSE") != nullptr;
-        env = getenv("MI355R_CROWD_MIN");
-        if (env) g.crowd_min = (unsigned)std::max(0, atoi(env));
-        env = getenv("MI355R_CROWD_SMALL");
-        if (env) g.crowd_small = std::max(0, std::min(atoi(env), 64));
         env = getenv("MI355R_RECORD_COPIES");
         if (env) g.record_copies = atoi(env) != 0;
         env = getenv("MI355R_REPLAY");
@@ -1841,8 +1834,7 @@ static void prepare_batch(const Batch &b, const FlushRecord &fr, bool reserve_on
     const size_t queue_capacity = (2 * tiles + RZ_QUEUE_WAYS - 1) / RZ_QUEUE_WAYS + b.members.size();    /* every pass's share rounded up */
     reserve(L.tile_listed, tiles, st);
     reserve(L.queue, RZ_LISTS * RZ_QUEUE_WAYS * queue_capacity, st);    /* blinn, pbr, RZ_ORDERED_LIST, RZ_VISIBILITY_LIST */
-    reserve(L.queue_counts, RZ_LISTS * RZ_QUEUE_WAYS * RZ_QUEUE_PAD + RZ_QUEUE_PAD, st);     /* the last: the number of crowded bins' squares */
-    reserve(L.crowd_list, 16 * bins, st);
+    reserve(L.queue_counts, RZ_LISTS * RZ_QUEUE_WAYS * RZ_QUEUE_PAD, st);
     reserve(L.bin_list, lists, st);
     reserve(L.bin_boxes, lists, st);
     if (!b.has_blend || splits_blend(tiles, b.members.size())) reserve(L.ref, pixels, st);
@@ -1902,9 +1894,6 @@ static void prepare_batch(const Batch &b, const FlushRecord &fr, bool reserve_on
         P.ref_scanned = (b.families & (1 << RZ_FAMILY_SKYBOX)) != 0;
         P.counters = g.counting ? g.d_counters : nullptr;
         P.scan_list = !b.has_blend ? -1 : splits_blend(tiles, b.members.size()) ? (int)RZ_VISIBILITY_LIST : (int)RZ_ORDERED_LIST;
-        P.crowd_min = (b.has_blend || g.counting) ? 0u : g.crowd_min;
-        P.crowd_small = g.crowd_small;
-        P.crowd_list = L.crowd_list.ptr;
         P.micro_area = g.micro_area;
         P.micro_min_list = g.micro_min_list;
         P.tiles_x = (W + RZ_TILE_W - 1) / RZ_TILE_W;
@@ -1980,8 +1969,7 @@ static void launch_batch(const Batch &b, const std::vector<PassPlan> &plans, cha
         }
         if (L.bin_range.cap < bins || L.bin_class.cap < bins || (g.sky_bins && L.sky_bins.cap < bins)) fatal("per-bin scratch of lane %d is smaller than the batch it is about to run", b.lane);
         const bool uses_ref = !(b.has_blend && !splits_blend(batch_tiles, n));
-        if (L.crowd_list.cap < 16 * bins) fatal("the crowded-bin list of lane %d is smaller than the batch it is about to run", b.lane);
-        if (L.queue_counts.cap < RZ_LISTS * RZ_QUEUE_WAYS * RZ_QUEUE_PAD + RZ_QUEUE_PAD || L.queue.cap < RZ_LISTS * RZ_QUEUE_WAYS * (size_t)queue_capacity ||
+        if (L.queue_counts.cap < RZ_LISTS * RZ_QUEUE_WAYS * RZ_QUEUE_PAD || L.queue.cap < RZ_LISTS * RZ_QUEUE_WAYS * (size_t)queue_capacity ||
             L.tile_listed.cap < batch_tiles || L.bin_boxes.cap < L.bin_list.cap || (uses_ref && (!L.ref.ptr || L.ref.cap < pixels)) || L.tri.cap < tris || L.bbox.cap < tris)
             fatal("scratch of lane %d is smaller than the batch it is about to run", b.lane);
     }
@@ -2041,15 +2029,6 @@ static void launch_batch(const Batch &b, const std::vector<PassPlan> &plans, cha
                                                                              sky_bins ? L.sky_bins.ptr : nullptr, L.bin_class.ptr);
             if (g.verbose) fprintf(stderr, "mi355r: batch of %u passes, longest bin list last time %u entries, strips of %d\n", n, longest, strip);
             snprintf(g.last_raster_kernel, sizeof g.last_raster_kernel, "rz_strip_kernel<%d>", strip);
-            /* crowded bins first, a workgroup per square of a bin: the launch is as long as its fullest square takes */
-            if (g.crowd_min && !g.counting) {
-                size_t batch_bins = 0;
-                for (size_t i : b.members)
-                    batch_bins += (size_t)((plans[i].fb->pub.width + RZ_BIN - 1) / RZ_BIN) * ((plans[i].fb->pub.height + RZ_BIN - 1) / RZ_BIN);
-                rz_crowd_kernel<<<dim3((unsigned)std::min<size_t>(16 * batch_bins, (size_t)g.shade_workgroups / 4)), dim3(64 * RZ_CROWD_WAVES), 0, st>>>(
-                    passes, L.bin_list.ptr, L.bin_boxes.ptr, L.vary.ptr, L.fan_vary.ptr, db, L.bin_range.ptr, L.crowd_list.ptr, L.queue_counts.ptr,
-                    (uint32_t)std::min<size_t>(16 * batch_bins, 0xffffffffu));
-            }
             /* passes of one size: a strip then finds its bin's class without reading its pass's parameters */
             int uniform_w = plans[b.members[0]].fb->pub.width, uniform_h = plans[b.members[0]].fb->pub.height;
             for (size_t i : b.members)
@@ -2814,7 +2793,6 @@ extern "C" void mi355r_inspect_bins(unsigned int *counts, unsigned int *entries)
     size_t out = 0;
     std::vector<BinEntry> list;
     for (size_t b = 0; b < bins; b++) {
-        ranges[b].y &= ~RZ_BIN_CROWDED;
         counts[b] = ranges[b].y;
         list.resize(ranges[b].y);
         if (ranges[b].y)

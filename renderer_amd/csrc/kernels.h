@@ -70,7 +70,7 @@ __global__ void __launch_bounds__(256) rz_begin_kernel(const PassParams *__restr
     /* the pass's device-written scalars start at zero -- unless another pass of the flush ran out of
      * scratch and this one may depend on it: then it is marked to be left out and run again later */
     if (gv < 8u) P.control[gv] = (gv == 2u && P.level > 0 && *P.flush_flag != 0u) ? (uint32_t)RZ_ERR_SKIPPED : 0u;
-    if (blockIdx.y == 0 && gv <= RZ_LISTS * RZ_QUEUE_WAYS) P.queue_counts[gv * RZ_QUEUE_PAD] = 0;   /* ... and the batch's work-list lengths (the last: its crowded bins) */
+    if (blockIdx.y == 0 && gv < RZ_LISTS * RZ_QUEUE_WAYS) P.queue_counts[gv * RZ_QUEUE_PAD] = 0;    /* ... and the batch's work-list lengths */
     for (uint32_t t = gv; t < (uint32_t)(P.tiles_x * P.tiles_y); t += gridDim.x * 256u) P.tile_listed[t] = 0;
     {   /* ... and the pass's (chunk, bin) matrix, which rz_bin_count_kernel adds into */
         const uint32_t cells = (((uint32_t)P.num_tris + 63u) / 64u) * (uint32_t)(P.bins_x * P.bins_y);
@@ -618,31 +618,6 @@ RZ_DEV BinRect bin_rect_of(uint2 bb) {
 #define RZ_BCAST_F(v, j) __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), (j)))
 #define RZ_BCAST_I(v, j) __builtin_amdgcn_readlane((int)(v), (j))
 
-__global__ void __launch_bounds__(256) rz_bin_count_kernel(const PassParams *__restrict__ passes) {
-    const PassParams &P = passes[blockIdx.y];
-    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
-    const int lane = threadIdx.x & 63;
-    if ((t & ~63u) >= (uint32_t)P.num_tris) return;             /* uniform over the wave */
-    BinRect r;
-    r.entries = 0; r.bx0 = r.bx1 = r.by0 = r.by1 = 0;
-    if (t < (uint32_t)P.num_tris) r = bin_rect_of(P.bbox[t]);
-    uint32_t *row = P.bin_counts + (size_t)(t >> 6) * (uint32_t)(P.bins_x * P.bins_y);
-    const int w = r.bx1 - r.bx0 + 1, area = w * (r.by1 - r.by0 + 1);
-    /* a triangle over many bins (a sky box face) is spread over the wave's lanes */
-    unsigned long long big = __ballot(r.entries != 0 && area > 8);
-    if (r.entries != 0 && area <= 8) {
-        for (int by = r.by0; by <= r.by1; by++)
-            for (int bx = r.bx0; bx <= r.bx1; bx++) atomicAdd(&row[by * P.bins_x + bx], r.entries);
-    }
-    while (big) {
-        const int L = __ffsll((long long)big) - 1;
-        big &= big - 1;
-        const int x0 = RZ_BCAST_I(r.bx0, L), y0 = RZ_BCAST_I(r.by0, L), wL = RZ_BCAST_I(w, L), aL = RZ_BCAST_I(area, L);
-        const uint32_t e = (uint32_t)RZ_BCAST_I(r.entries, L);
-        for (int i = lane; i < aL; i += 64) atomicAdd(&row[(y0 + i / wL) * P.bins_x + x0 + i % wL], e);
-    }
-}
-
 /* Cross-lane steps of scans and reductions go through the VALU's data-parallel primitives (DPP): the
  * operand comes from a neighbouring lane's register inside the instruction itself, where __shfl makes a
  * trip through the LDS crossbar (ds_bpermute) and waits for it.  A lane whose source lies outside its row
@@ -685,7 +660,56 @@ RZ_DEV int wave_max_i(int v) {
                max(__builtin_amdgcn_readlane(v, 47), __builtin_amdgcn_readlane(v, 63)));
 }
 
-#define RZ_CROWD_FINE 2048u         /* list entries from which a crowded bin is cut into 16x16 squares (rz_crowd_kernel) */
+#define RZ_FILL_FEW_BINS 16         /* a chunk whose joint bin rectangle is at most this large is counted and filled triangle-parallel */
+__global__ void __launch_bounds__(256) rz_bin_count_kernel(const PassParams *__restrict__ passes) {
+    const PassParams &P = passes[blockIdx.y];
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    if ((t & ~63u) >= (uint32_t)P.num_tris) return;             /* uniform over the wave */
+    BinRect r;
+    r.entries = 0; r.bx0 = r.bx1 = r.by0 = r.by1 = 0;
+    if (t < (uint32_t)P.num_tris) r = bin_rect_of(P.bbox[t]);
+    uint32_t *row = P.bin_counts + (size_t)(t >> 6) * (uint32_t)(P.bins_x * P.bins_y);
+    const int w = r.bx1 - r.bx0 + 1, area = w * (r.by1 - r.by0 + 1);
+    /* A wave is a chunk and the chunk's row of the matrix is its own.  A dense mesh puts all 64 triangles into a
+     * handful of bins: an atomic per triangle and bin then hits the same few words 64 times over.  So when the
+     * chunk's joint bin rectangle is small its bins are taken one after the other, the triangles that touch a bin
+     * counted with a ballot (summed when a clipped triangle adds a whole fan), and lane i stores bin i's count
+     * (azura: 52 -> 20 us per launch of 32 passes). */
+    const unsigned long long active = __ballot(r.entries != 0);
+    if (!active) return;
+    const int ux0 = wave_min_i(r.entries ? r.bx0 : 0x7fffffff), ux1 = wave_max_i(r.entries ? r.bx1 : -1);
+    const int uy0 = wave_min_i(r.entries ? r.by0 : 0x7fffffff), uy1 = wave_max_i(r.entries ? r.by1 : -1);
+    const int uw = ux1 - ux0 + 1, ubins = uw * (uy1 - uy0 + 1);
+    if (ubins <= RZ_FILL_FEW_BINS) {
+        const bool fans = __ballot(r.entries > 1u) != 0ull;
+        uint32_t mine = 0;
+        for (int i = 0; i < ubins; i++) {
+            const int bx = ux0 + i % uw, by = uy0 + i / uw;
+            const bool touch = r.entries != 0 && bx >= r.bx0 && bx <= r.bx1 && by >= r.by0 && by <= r.by1;
+            uint32_t total;
+            if (fans) (void)wave_exclusive_scan(touch ? r.entries : 0u, &total);
+            else total = (uint32_t)__popcll(__ballot(touch));
+            if (lane == i) mine = total;
+        }
+        if (lane < ubins && mine) row[(uy0 + lane / uw) * P.bins_x + ux0 + lane % uw] = mine;
+        return;
+    }
+    /* a triangle over many bins (a sky box face) is spread over the wave's lanes */
+    unsigned long long big = __ballot(r.entries != 0 && area > 8);
+    if (r.entries != 0 && area <= 8) {
+        for (int by = r.by0; by <= r.by1; by++)
+            for (int bx = r.bx0; bx <= r.bx1; bx++) atomicAdd(&row[by * P.bins_x + bx], r.entries);
+    }
+    while (big) {
+        const int L = __ffsll((long long)big) - 1;
+        big &= big - 1;
+        const int x0 = RZ_BCAST_I(r.bx0, L), y0 = RZ_BCAST_I(r.by0, L), wL = RZ_BCAST_I(w, L), aL = RZ_BCAST_I(area, L);
+        const uint32_t e = (uint32_t)RZ_BCAST_I(r.entries, L);
+        for (int i = lane; i < aL; i += 64) atomicAdd(&row[(y0 + i / wL) * P.bins_x + x0 + i % wL], e);
+    }
+}
+
 /* 1024 threads = 64 bins x 16 segments of the chunk range */
 #define RZ_SCAN_SEGMENTS 16
 __global__ void __launch_bounds__(64 * RZ_SCAN_SEGMENTS) rz_bin_scan_kernel(const PassParams *__restrict__ passes) {
@@ -718,7 +742,6 @@ __global__ void __launch_bounds__(64 * RZ_SCAN_SEGMENTS) rz_bin_scan_kernel(cons
     }
     /* every segment's thread of a bin needs the list's start: segment 0 reserves it */
     __syncthreads();
-    bool crowded = false;
     if (segment == 0 && bin < bins) {
         uint32_t start = total ? atomicAdd(&P.control[1], total) : 0u;
         if (start + total > P.bin_capacity) {      /* control[1] still ends up as the entries the pass needs */
@@ -726,15 +749,7 @@ __global__ void __launch_bounds__(64 * RZ_SCAN_SEGMENTS) rz_bin_scan_kernel(cons
             atomicOr(P.flush_flag, 1u);
             total = 0;
         }
-        /* a crowded bin goes on the batch's list for rz_crowd_kernel and is marked for rz_strip_kernel to leave alone */
-        crowded = P.crowd_min != 0u && total >= P.crowd_min;
-        if (crowded) {              /* its squares: 4 of 32x32 pixels, or 16 of 16x16 (rz_crowd_kernel) */
-            const uint32_t fine = total >= RZ_CROWD_FINE ? 1u : 0u, squares = fine ? 16u : 4u;
-            const uint32_t at = atomicAdd(&P.queue_counts[RZ_CROWD_COUNT_AT], squares);
-            for (uint32_t q = 0; q < squares; q++)
-                P.crowd_list[at + q] = make_uint2(((uint32_t)blockIdx.y << 16) | (uint32_t)bin, q | (fine << 8));
-        }
-        P.bin_range[bin] = make_uint2(start, total | (crowded ? RZ_BIN_CROWDED : 0u));
+        P.bin_range[bin] = make_uint2(start, total);
         s_part[0][threadIdx.x & 63] = total ? start : 0xffffffffu;
         /* a pass with blended draws: the bin's 32x8 tiles go on the work list of the kernel that rasterises it, unless
          * there is nothing for that kernel to do in them */
@@ -753,8 +768,8 @@ __global__ void __launch_bounds__(64 * RZ_SCAN_SEGMENTS) rz_bin_scan_kernel(cons
                 }
         }
     }
-    if (segment == 0) {             /* the pass's longest list among those rz_strip_kernel walks, for the host's choice of strip height next time */
-        uint32_t longest = (bin < bins && !crowded) ? total : 0u;
+    if (segment == 0) {             /* the pass's longest list, for the host's choice of strip height next time */
+        uint32_t longest = bin < bins ? total : 0u;
         longest = (uint32_t)wave_max_i((int)longest);           /* entry counts stay far below 2^31 */
         if ((threadIdx.x & 63) == 0 && longest) atomicMax(&P.control[4], longest);
     }
@@ -780,7 +795,6 @@ __global__ void __launch_bounds__(64 * RZ_SCAN_SEGMENTS) rz_bin_scan_kernel(cons
 RZ_DEV uint2 entry_box(float4 q3) {
     return make_uint2(__float_as_uint(q3.z), __float_as_uint(q3.w) | (RZ_META_CUTOFF(__float_as_uint(q3.y)) << 31));
 }
-#define RZ_FILL_FEW_BINS 16         /* a chunk whose joint bin rectangle is at most this large is filled triangle-parallel */
 
 /* One workgroup of RZ_FILL_WAVES waves per chunk.  Lanes first hold the
  * chunk's 64 triangles (box, record), then turn into BINS: the chunk's joint
@@ -1643,8 +1657,7 @@ RZ_DEV uint32_t sky_region_of(int tx0, int ry0) { return (uint32_t)(((ry0 % RZ_B
  *     pixel's reference wants) are written a row of four pixels per lane, 256 contiguous bytes per bin row and
  *     plane -- a frame without a sky box is mostly such bins, and as 32-byte pieces out of strips whose waves had
  *     each read their pass's parameters and the bin's range first, their clears ran at a quarter of the memory's rate;
- *   a bin with nothing but one sky box's triangles is rz_sky_kernel's, and gets its SkyBin record (above);
- *   a crowded bin is rz_crowd_kernel's.
+ *   a bin with nothing but one sky box's triangles is rz_sky_kernel's, and gets its SkyBin record (above).
  * A strip whose batch has passes of one size finds its bin's class with two kernel arguments and its own index,
  * before it has read anything else. */
 enum { RZ_BIN_STRIP = 0, RZ_BIN_DONE = 1 };
@@ -1659,9 +1672,7 @@ __global__ void __launch_bounds__(64) rz_bin_class_kernel(const PassParams *__re
         if (lane == 0) *bin_class = RZ_BIN_DONE;
         return;
     }
-    uint2 range = (bin_range_base + P.bin_off)[blockIdx.x];
-    const bool crowded = (range.y & RZ_BIN_CROWDED) != 0u;
-    range.y &= ~RZ_BIN_CROWDED;
+    const uint2 range = (bin_range_base + P.bin_off)[blockIdx.x];
     const int bin_x0 = (int)(blockIdx.x % (uint32_t)P.bins_x) * RZ_BIN, bin_y0 = (int)(blockIdx.x / (uint32_t)P.bins_x) * RZ_BIN;
     if (range.y == 0u) {
         const bool blank_refs = P.ref_scanned != 0;
@@ -1694,7 +1705,7 @@ __global__ void __launch_bounds__(64) rz_bin_class_kernel(const PassParams *__re
     bool sky = false;
     if (sky_base) {
         const BinEntry *list = list_base + P.list_off + range.x;
-        sky = !crowded && sky_only_bin(P, list, range.y);
+        sky = sky_only_bin(P, list, range.y);
         const int rx0 = bin_x0 + RZ_TILE_W * (lane & 1), ry0 = bin_y0 + 4 * ((lane >> 1) & 15);
         uint32_t mine = 0, draw = 0;
         if (sky) {
@@ -1714,11 +1725,10 @@ __global__ void __launch_bounds__(64) rz_bin_class_kernel(const PassParams *__re
         if (lane == 33) rec->first = range.x;
         if (lane == 34) rec->draw = draw;
     }
-    if (lane == 0) *bin_class = (range.y == 0u || crowded || sky) ? (uint32_t)RZ_BIN_DONE : (uint32_t)RZ_BIN_STRIP;
+    if (lane == 0) *bin_class = (range.y == 0u || sky) ? (uint32_t)RZ_BIN_DONE : (uint32_t)RZ_BIN_STRIP;
 }
 
-/* What a wave does with a finished block of 16x8 pixels of a pass without blending (rz_strip_kernel,
- * rz_crowd_kernel): depth, the clear colour where no fragment is, and -- for blocks that hold blinn or pbr
+/* What a wave of rz_strip_kernel does with a finished block of 16x8 pixels: depth, the clear colour where no fragment is, and -- for blocks that hold blinn or pbr
  * fragments, or when a kernel that looks at every pixel's reference follows -- the references. */
 #define RZ_BLOCK_ITEM(pass, by, bx) (((uint32_t)(pass) << 21) | ((uint32_t)(by) << 10) | (uint32_t)(bx))
 RZ_DEV void finish_block(const PassParams &P, uint32_t pass_index, int bx0, int by0, int lane,
@@ -1820,7 +1830,7 @@ __global__ void __launch_bounds__(128) rz_strip_kernel(const PassParams *__restr
     const int bin = (sy0 / RZ_BIN) * P.bins_x + tx0 / RZ_BIN;
     const uint2 range = (bin_range_base + P.bin_off)[bin];          /* {first entry, entries} */
     if (!uniform_width && class_base[P.bin_off + (uint32_t)bin] != (uint32_t)RZ_BIN_STRIP) return;
-    const uint32_t count = range.y;                                 /* (a bin of this class is not empty and not marked crowded) */
+    const uint32_t count = range.y;                                 /* (a bin of this class is not empty) */
     const BinEntry *list = list_table + range.x;
     const uint2 *boxes = box_base + P.list_off + range.x;
 
@@ -2038,221 +2048,6 @@ __global__ void __launch_bounds__(128) rz_strip_kernel(const PassParams *__restr
         if (count > 64u && k + 1 < STRIP) request_first_group();
 
         finish_block(P, pass_index, bx0, by0, lane, valid, pixel, zcur, ref_of);
-    }
-}
-
-/* K4d  crowded bins (a dense mesh far away: azura at 800x600 puts ten thousand triangles of a few pixels each
- * into one 64x64 bin).  In rz_strip_kernel every one of the bin's 32 blocks is a wave that walks the whole list
- * to find the few entries that touch it, and takes those one at a time with all 64 lanes: the walk is repeated
- * 32 times and the lanes are 2 % busy.  Here a workgroup of eight waves takes a QUARTER of such a bin (32x32
- * pixels; a sixteenth, 16x16, of a bin with a very long list, so that the fullest bin of a frame is spread over
- * more of the device): the waves share the walk over the list's 8-byte boxes -- 512 contiguous bytes per load --
- * and set aside the entries whose box meets the square in a ring; each time 64 have come together every lane
- * rasterises one, into a plane of per-pixel keys in LDS, depth (as an order-preserving integer) above the
- * complement of the list position.  Which fragment a pixel ends up with does not depend on the order the
- * triangles are taken in: it is the one of least depth, the latest in submission order among equals
- * (graphics.c:523 keeps a fragment when depth <= the stored depth), and an atomic minimum over such keys keeps
- * exactly that one.  Alpha-cutoff discards (evaluated per fragment, order does not matter) keep a fragment out
- * of the plane.  When the list is through, the waves turn to the square's blocks: keys against the depth buffer,
- * then what rz_strip_kernel does with a finished block.
- *
- * Of the 64 entries of a turn, a lane whose triangle's box (cut to the square) is small walks it alone, pixel by
- * pixel; a larger one is taken by the whole wave, 8x8 pixels per step, its record passed round from the lane
- * that holds it with readlane (no second trip to memory).  Where the line between the two lies is settled per
- * turn: the lanes' loop runs as long as the largest box among them, so the limit that makes (largest small box)
- * x (a pixel's cost) + (boxes above it) x (a wave-wide step's cost) least is taken, among a few candidates up to
- * crowd_small.
- *
- * Passes without blending only (like rz_strip_kernel), and not while fragments are counted (that count depends
- * on the order).  grid: a fixed number of workgroups stride over the batch's list of squares, which
- * rz_bin_scan_kernel wrote: {pass << 16 | bin, square | fine << 8}. */
-#define RZ_CROWD_WAVES 8
-__global__ void __launch_bounds__(64 * RZ_CROWD_WAVES) rz_crowd_kernel(const PassParams *__restrict__ passes,
-        const BinEntry *__restrict__ list_base, const uint2 *__restrict__ box_base,
-        const float *__restrict__ vary_base, const float *__restrict__ fan_vary_base,
-        const char *__restrict__ upload_base, const uint2 *__restrict__ bin_range_base,
-        const uint2 *__restrict__ crowd_list, const uint32_t *__restrict__ queue_counts, uint32_t crowd_capacity) {
-    __shared__ unsigned long long keys[32 * 32];                    /* row-major inside the square */
-    __shared__ uint32_t rings[RZ_CROWD_WAVES][128];
-    const int lane = threadIdx.x & 63, wave = (int)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    uint32_t *ring = rings[wave];
-    const uint32_t items = min(queue_counts[RZ_CROWD_COUNT_AT], crowd_capacity);
-    for (uint32_t item = blockIdx.x; item < items; item += gridDim.x) {
-        const uint2 word = crowd_list[item];
-        const uint32_t pass_index = word.x >> 16, bin = word.x & 0xffffu;
-        const PassParams P = passes[pass_index];
-        if (P.control[2] != 0u) continue;                           /* out of scratch, or left out: the pass is run again later (uniform) */
-        const uint2 range = (bin_range_base + P.bin_off)[bin];
-        const uint32_t count = range.y & ~RZ_BIN_CROWDED;
-        const BinEntry *list = list_base + P.list_off + range.x;
-        const uint2 *boxes = box_base + P.list_off + range.x;
-        const float *vary_table = vary_base + (size_t)P.tri_off * 3 * RZ_VARY_STRIDE;
-        const float *fan_vary_table = fan_vary_base + (size_t)P.fan_off * RZ_MAX_POLY * RZ_VARY_STRIDE;
-        const DrawRec *draw_table = (const DrawRec*)(upload_base + P.draws_off);
-        /* the square */
-        const int edge = (word.y >> 8) ? 16 : 32, per_row = RZ_BIN / edge, square = (int)(word.y & 0xffu);
-        const int sq_x0 = (int)(bin % (uint32_t)P.bins_x) * RZ_BIN + (square % per_row) * edge;
-        const int sq_y0 = (int)(bin / (uint32_t)P.bins_x) * RZ_BIN + (square / per_row) * edge;
-        if (sq_x0 >= P.width || sq_y0 >= P.height) continue;       /* uniform */
-        const int sq_x1 = min(sq_x0 + edge - 1, P.width - 1), sq_y1 = min(sq_y0 + edge - 1, P.height - 1);
-        for (uint32_t i = threadIdx.x; i < 32u * 32u; i += 64u * RZ_CROWD_WAVES) keys[i] = ~0ull;
-        __syncthreads();
-
-        /* 64 entries of the ring (or what is left of it), one per lane */
-        uint32_t ring_head = 0, ring_tail = 0;                      /* wave-uniform */
-        auto rasterise = [&](uint32_t n) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            const bool on = (uint32_t)lane < n;
-            const uint32_t ord = on ? ring[(ring_head + (uint32_t)lane) & 127u] : 0u;
-            ring_head += n;
-            float4 a = make_float4(0, 0, 0, 0), b = a, c = a;
-            uint2 box = make_uint2(RZ_BBOX_EMPTY_X, 0u);
-            if (on) {
-                const float4 *q = (const float4*)&list[ord];       /* reference + record, 80 bytes */
-                a = q[1]; b = q[2]; c = q[3];
-                box = boxes[ord];
-            }
-            /* the entry's box inside the square (find_bounding_box clamped it to the framebuffer, graphics.c:355-364) */
-            const int x0 = max((int)(box.x & 0xffffu), sq_x0), x1 = min((int)(box.x >> 16), sq_x1);
-            const int y0 = max((int)(box.y & 0xffffu), sq_y0), y1 = min((int)((box.y >> 16) & 0x7fffu), sq_y1);
-            const bool cutoff = (box.y >> 31) != 0;
-            const int area = (on && x1 >= x0 && y1 >= y0) ? (x1 - x0 + 1) * (y1 - y0 + 1) : 0;
-            /* the limit between "alone" and "wave-wide" for this turn */
-            int limit = 0;
-            {
-                int best = 0x7fffffff;
-                for (int t = 4; t <= 64; t *= 2) {
-                    if (t > P.crowd_small && t > 4) break;
-                    const bool above = area > t || (area > 0 && cutoff);
-                    const int cost = 30 * min(t, wave_max_i(above ? 0 : area)) + 48 * __popcll(__ballot(above));
-                    if (cost < best) { best = cost; limit = t; }
-                }
-                limit = min(limit, P.crowd_small);
-            }
-            const bool alone = area > 0 && area <= limit && !cutoff;
-            const uint32_t low = ~ord;                              /* the later entry wins among equal depths */
-            TriRec r;
-            r.ax = a.x; r.ay = a.y; r.abx = a.z; r.aby = a.w;
-            r.acx = b.x; r.acy = b.y; r.factor = b.z; r.z[0] = b.w;
-            r.z[1] = c.x; r.z[2] = c.y;
-            if (alone) {
-                int x = x0, y = y0;
-                while (y <= y1) {
-                    float w0, w1, w2;
-                    pixel_weights(r, x, y, w0, w1, w2);
-                    const float depth = r.z[0] * w0 + r.z[1] * w1 + r.z[2] * w2;                       /* :403-408 */
-                    if (w0 > -RZ_EPS && w1 > -RZ_EPS && w2 > -RZ_EPS && depth == depth) {             /* :516-519 */
-                        const uint32_t bits = __float_as_uint(depth + 0.0f);
-                        const uint32_t up = bits ^ ((uint32_t)((int32_t)bits >> 31) | 0x80000000u);
-                        atomicMin(&keys[(y - sq_y0) * 32 + (x - sq_x0)], ((unsigned long long)up << 32) | low);
-                    }
-                    if (++x > x1) { x = x0; y++; }
-                }
-            }
-            /* the others, one after the other, by the whole wave: lane = a pixel of an 8x8 step */
-            unsigned long long todo = __ballot(area > 0 && !alone);
-            const unsigned long long cutoffs = __ballot(cutoff);
-            while (todo) {
-                const int L = __ffsll((long long)todo) - 1;
-                todo &= todo - 1;
-                TriRec m;
-                m.ax = RZ_BCAST_F(a.x, L); m.ay = RZ_BCAST_F(a.y, L); m.abx = RZ_BCAST_F(a.z, L); m.aby = RZ_BCAST_F(a.w, L);
-                m.acx = RZ_BCAST_F(b.x, L); m.acy = RZ_BCAST_F(b.y, L); m.factor = RZ_BCAST_F(b.z, L); m.z[0] = RZ_BCAST_F(b.w, L);
-                m.z[1] = RZ_BCAST_F(c.x, L); m.z[2] = RZ_BCAST_F(c.y, L);
-                const int mx0 = RZ_BCAST_I(x0, L), mx1 = RZ_BCAST_I(x1, L), my0 = RZ_BCAST_I(y0, L), my1 = RZ_BCAST_I(y1, L);
-                const uint32_t mlow = (uint32_t)RZ_BCAST_I(low, L);
-                const bool mcut = (cutoffs >> L) & 1ull;
-                /* an entry with an alpha cutoff: the shaders' discard test (blinn_shader.c:104-113, 220; pbr_shader.c:116-134,
-                 * 452) needs the interpolated texcoord, i.e. 1/w per corner and the corners' varyings (scalar loads) */
-                const BinEntry *entry = &list[(uint32_t)~mlow];
-                float rw0 = 0, rw1 = 0, rw2 = 0;
-                const float *v0 = vary_table, *v1 = vary_table, *v2 = vary_table;
-                uint32_t draw = 0;
-                if (mcut) {
-                    rw0 = entry->rec.rw[0]; rw1 = entry->rec.rw[1]; rw2 = entry->rec.rw[2];
-                    draw = RZ_META_DRAW(entry->rec.meta);
-                    ref_varyings(entry->tri, vary_table, fan_vary_table, v0, v1, v2);
-                }
-                for (int sy = my0 & ~7; sy <= my1; sy += 8)
-                    for (int sx = mx0 & ~7; sx <= mx1; sx += 8) {
-                        const int x = sx + (lane & 7), y = sy + (lane >> 3);
-                        float w0, w1, w2;
-                        pixel_weights(m, x, y, w0, w1, w2);
-                        const float depth = m.z[0] * w0 + m.z[1] * w1 + m.z[2] * w2;                   /* :403-408 */
-                        bool inside = x >= mx0 && x <= mx1 && y >= my0 && y <= my1 &&
-                                      w0 > -RZ_EPS && w1 > -RZ_EPS && w2 > -RZ_EPS && depth == depth;   /* :516-519 */
-                        if (mcut && __any(inside)) {
-                            const DrawRec &D = draw_table[draw];
-                            const int tc = D.family == 0 ? RZ_BV_TEXCOORD : RZ_PV_TEXCOORD;
-                            const float q0 = rw0 * w0, q1 = rw1 * w1, q2 = rw2 * w2;
-                            const float norm = 1 / (q0 + q1 + q2);
-                            const float tu = (v0[tc] * q0 + v1[tc] * q1 + v2[tc] * q2) * norm;
-                            const float tv = (v0[tc + 1] * q0 + v1[tc + 1] * q1 + v2[tc + 1] * q2) * norm;
-                            if (inside) {
-                                float alpha = D.base[3];
-                                if (D.maps[0].data) alpha *= sample_repeat(D.maps[0], tu, tv).w;
-                                if (alpha < D.alpha_cutoff) inside = false;
-                            }
-                        }
-                        if (inside) {
-                            const uint32_t bits = __float_as_uint(depth + 0.0f);
-                            const uint32_t up = bits ^ ((uint32_t)((int32_t)bits >> 31) | 0x80000000u);
-                            atomicMin(&keys[(y - sq_y0) * 32 + (x - sq_x0)], ((unsigned long long)up << 32) | mlow);
-                        }
-                    }
-            }
-        };
-
-        /* ---- the walk: a group of 64 boxes per wave and turn, the next group asked for a turn ahead */
-        uint2 nbox = make_uint2(RZ_BBOX_EMPTY_X, 0u);
-        {
-            const uint32_t e = (uint32_t)wave * 64u + (uint32_t)lane;
-            if (e < count) nbox = boxes[e];
-        }
-        for (uint32_t base = (uint32_t)wave * 64u; base < count; base += 64u * RZ_CROWD_WAVES) {
-            const uint2 box = nbox;
-            const uint32_t e = base + (uint32_t)lane, next = e + 64u * RZ_CROWD_WAVES;
-            nbox = make_uint2(RZ_BBOX_EMPTY_X, 0u);
-            if (next < count) nbox = boxes[next];
-            const bool hit = e < count && box_overlaps(make_uint2(box.x, box.y & 0x7fffffffu), sq_x0, sq_y0, sq_x1, sq_y1);
-            const unsigned long long hits = __ballot(hit);
-            if (!hits) continue;
-            if (hit) ring[(ring_tail + __builtin_amdgcn_mbcnt_hi((uint32_t)(hits >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hits, 0u))) & 127u] = e;
-            ring_tail += (uint32_t)__popcll(hits);
-            if (ring_tail - ring_head >= 64u) rasterise(64u);
-        }
-        if (ring_tail != ring_head) rasterise(ring_tail - ring_head);
-        __syncthreads();
-
-        /* ---- the square's blocks of 16x8 pixels: keys against the depth buffer, then as rz_strip_kernel ends a block */
-        const int blocks_x = edge / 16, blocks = blocks_x * (edge / 8);
-        for (int block = wave; block < blocks; block += RZ_CROWD_WAVES) {
-            const int bx0 = sq_x0 + (block % blocks_x) * 16, by0 = sq_y0 + (block / blocks_x) * 8;
-            if (bx0 >= P.width || by0 >= P.height) continue;        /* uniform */
-            const int py = by0 + (lane >> 3);
-            bool valid[2];
-            uint32_t pixel[2], ref_of[2];
-            float zcur[2];
-            for (int q = 0; q < 2; q++) {
-                const int px = bx0 + 8 * q + (lane & 7);
-                valid[q] = px < P.width && py < P.height;
-                pixel[q] = (uint32_t)py * (uint32_t)P.width + (uint32_t)px;
-                ref_of[q] = RZ_REF_NONE;
-                zcur[q] = P.clear_depth;
-                if (valid[q] && !P.clear_depth_pending) zcur[q] = P.depth[pixel[q]];
-                const unsigned long long key = valid[q] ? keys[(py - sq_y0) * 32 + (px - sq_x0)] : ~0ull;
-                if (key == ~0ull) continue;
-                const uint32_t up = (uint32_t)(key >> 32);
-                const float depth = __uint_as_float(up ^ ((up >> 31) ? 0x80000000u : 0xffffffffu));
-                if (depth <= zcur[q]) {                                                             /* :523 */
-                    const BinEntry *e = &list[~(uint32_t)key];
-                    zcur[q] = depth;
-                    ref_of[q] = e->tri | (RZ_META_FAMILY(e->rec.meta) << 28);
-                }
-            }
-            finish_block(P, pass_index, bx0, by0, lane, valid, pixel, zcur, ref_of);
-        }
-        __syncthreads();                                            /* the keys are set up again for the next square */
     }
 }
 

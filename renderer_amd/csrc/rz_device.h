@@ -57,8 +57,6 @@ enum { RZ_PV_WORLD = 0, RZ_PV_NORMAL = 3, RZ_PV_TANGENT = 6, RZ_PV_BITANGENT = 9
 #define RZ_QUEUE_PAD 32u            /* counters sit one 128-byte line apart: atomics on one line serialise */
 #define RZ_VISIBILITY_LIST 3u       /* the fourth: tiles of such a pass that rz_blend_visibility_kernel has to look at */
 #define RZ_LISTS 4u
-#define RZ_CROWD_COUNT_AT (RZ_LISTS * RZ_QUEUE_WAYS * RZ_QUEUE_PAD)    /* in queue_counts, behind the work lists' lengths */
-#define RZ_BIN_CROWDED 0x80000000u  /* in bin_range[].y: the bin is rz_crowd_kernel's, rz_strip_kernel leaves it alone */
 #define RZ_TILE_W 32                /* raster / shade workgroup tile: 4 waves of 8x8 side by side, */
 #define RZ_TILE_H 8                 /* so a tile row is one 128-byte line of a 4-byte plane */
 
@@ -193,7 +191,7 @@ struct PassParams {
     /* binning */
     int32_t bins_x, bins_y;
     rz_gptr<uint32_t> bin_counts;           /* [chunks of 64 triangles][bins]: entries, then first entry */
-    rz_gptr<uint2> bin_range;               /* per bin: {first entry, entries | RZ_BIN_CROWDED} */
+    rz_gptr<uint2> bin_range;               /* per bin: {first entry, entries} */
     rz_gptr<BinEntry> bin_list;
     rz_gptr<uint2> bin_boxes;               /* per list entry: x0 | x1 << 16, y0 | y1 << 16 | alpha-cutoff << 31 -- all that walking a list reads */
     uint32_t bin_capacity;
@@ -203,8 +201,7 @@ struct PassParams {
      * used, [2] error bits, [3] triangles queued for clipping */
     rz_gptr<uint32_t> control;
     rz_gptr<unsigned long long> counters;   /* nullptr unless counting is enabled */
-    uint32_t crowd_min;             /* a bin with at least this many list entries is taken by rz_crowd_kernel, one workgroup for the
-                                     * whole bin; 0 = none (passes with blended draws, fragment counting) */
+    int32_t reserved_;
     int32_t micro_area;             /* triangles whose box covers at most this many pixels of a wave's block
                                      * are rasterised one per lane; 0 = none */
     int32_t micro_min_list;         /* ... in bins whose list has at least this many entries */
@@ -235,14 +232,9 @@ struct PassParams {
      * host runs those passes again, in order, with scratch of the sizes they reported. */
     rz_gptr<uint32_t> flush_flag;
     int32_t level;                  /* 0: depends on no other pass of its flush */
-    int32_t crowd_small;            /* rz_crowd_kernel: largest box (pixels) a lane rasterises on its own */
     /* a pass with blended draws: the list (RZ_ORDERED_LIST or RZ_VISIBILITY_LIST) rz_bin_scan_kernel puts the tiles of
      * its bins on that are not empty -- the kernel behind it then starts no wave for the rest of the frame; -1: none */
     int32_t scan_list;
-    int32_t pad_;
-    /* per batch: the squares of its crowded bins ({pass << 16 | bin, square | fine << 8}), as many as
-     * queue_counts[RZ_CROWD_COUNT_AT] says */
-    rz_gptr<uint2> crowd_list;
 };
 
 enum { RZ_ERR_FAN_OVERFLOW = 1, RZ_ERR_BIN_OVERFLOW = 2, RZ_ERR_QUEUE_OVERFLOW = 4, RZ_ERR_SKIPPED = 8 };

@@ -143,8 +143,7 @@ sys.exit(0 if bad == 0 else 1)
                                  {"MI355R_STRIP": "4"}, {"MI355R_SKY_BINS": "0"}, {"MI355R_SKY_BYTES": "0"}, {"MI355R_STRIP": "2"},
                                  {"MI355R_STRIP_LONG": "1"}, {"MI355R_STRIP_LONG": "600"}, {"MI355R_STRIP": "1", "MI355R_MICRO_MIN_LIST": "0"},
                                  {"MI355R_SPLIT_BLEND": "0"}, {"MI355R_SPLIT_BLEND": "1"},
-                                 {"MI355R_MICRO_MIN_LIST": "0", "MI355R_MICRO_AREA": "128"},
-                                 {"MI355R_CROWD_MIN": "0"}, {"MI355R_CROWD_MIN": "64"}, {"MI355R_CROWD_MIN": "64", "MI355R_CROWD_SMALL": "4"}],
+                                 {"MI355R_MICRO_MIN_LIST": "0", "MI355R_MICRO_AREA": "128"}],
                          ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()))
 def test_gpu_alternative_code_paths_give_the_same_frames(gpu, env):
     """The default configuration is what every other GPU test checks against the goldens; here the
@@ -153,8 +152,7 @@ def test_gpu_alternative_code_paths_give_the_same_frames(gpu, env):
     rasteriser for no triangle / in every bin / for every triangle a block can hold, a flush
     in front of every framebuffer -> texture copy, strips of a fixed height, strips whose height
     follows the framebuffer's last frame from a list length every scene / only azura reaches, sky-only
-    bins through the general path, visibility-first blending on and off, and the crowded-bin kernel
-    off, for every bin of 64 entries, and with nearly every triangle on its wave-wide path."""
+    bins through the general path, and visibility-first blending on and off."""
     r = subprocess.run([sys.executable, "-c", VARIANT_SCRIPT % (REPO, os.path.join(REPO, "tests"))],
                        env=dict(os.environ, **env), capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "DIFFS 0" in r.stdout, r.stdout + r.stderr

@@ -1,4 +1,4 @@
-# frames/s of the configurations under settings of the crowded-bin kernel: tools/sweep_crowd.sh "<env>" "<env>" ...
+# frames/s of the configurations under environment settings: tools/sweep_configs2.sh "<env>" "<env>" ...
 for v in "$@"; do
   echo "== $v"
   for c in C1 C3 C4 C5 S1; do
