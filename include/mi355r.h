@@ -389,6 +389,10 @@ typedef struct {
 int mi355r_inspect_pass(rz_pass_info *info);
 void mi355r_inspect_boxes(unsigned int *boxes, unsigned int *fans);
 void mi355r_inspect_bins(unsigned int *counts, unsigned int *entries);
+/* The last pass's first triangle that belongs to a sky box kept out of the bins (its triangles sit on the pass's table
+ * of sky triangles: mi355r_inspect_boxes reports their boxes, mi355r_inspect_bins has no entries of theirs);
+ * = the pass's triangle count when there is none. */
+int mi355r_inspect_sky_first(void);
 
 /* Scratch estimates (tests).  The clipper's block table and the bin lists of a pass are sized by an
  * estimate before the pass runs; a pass that needs more does not touch its framebuffer, reports what

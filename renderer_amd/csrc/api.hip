@@ -169,6 +169,7 @@ struct Lane {
     DevBuf<uint32_t> clip_list, ref;
     DevBuf<uint2> bin_range;
     DevBuf<SkyBin> sky_bins;            /* per bin of the batch: rz_bin_class_kernel's record */
+    DevBuf<uint32_t> sky_table;         /* per pass of the batch: its table of sky triangles */
     DevBuf<uint32_t> bin_class;         /* per bin of the batch: what rz_strip_kernel has to do with it */
     DevBuf<uint32_t> bin_counts, queue, queue_counts, tile_listed;
     DevBuf<BinEntry> bin_list;
@@ -190,7 +191,8 @@ struct Context {
     bool sky_bytes = true;                  /* MI355R_SKY_BYTES=0: skybox fragments fetch the face's texel and convert it themselves */
     bool pack_textures = true;              /* MI355R_PACK=0: keep every image as float4 */
     int micro_min_list = 256;               /* MI355R_MICRO_MIN_LIST: small triangles are rasterised one per lane only in bins with at least this many list entries */
-    bool sky_bins = true;                   /* MI355R_SKY_BINS=0: bins that hold only skybox triangles go through rz_strip_kernel like any other */
+    bool sky_table = true;                  /* MI355R_SKY_TABLE=0: a sky box goes through the bins like any other draw */
+    int fill_waves = 1;                     /* MI355R_FILL_WAVES: waves that share a chunk of 64 triangles in rz_bin_fill_kernel (1, 2, 4) */
     unsigned strip_long = 2048;             /* MI355R_STRIP_LONG: a batch whose framebuffers had a bin list of this many entries in their last frame takes one block per wave,
                                              * of half as many two; 0, or MI355R_STRIP set = always `strip` */
     int strip = 4;                          /* MI355R_STRIP: 16x8 blocks a wave of rz_strip_kernel takes (8, 4, 2, 1) */
@@ -256,6 +258,7 @@ struct Context {
     /* the pass mi355r_inspect_* looks at: the last one submitted */
     PassParams last_pass;
     bool have_last_pass = false;
+    int last_pass_sky_first = 0;            /* its first triangle that is kept on the table of sky triangles (= its triangle count: none) */
 };
 
 static Context g;
@@ -318,8 +321,10 @@ extern "C" int mi355r_init(int device) {
         if (env) { const int v = atoi(env); if (v == 8 || v == 4 || v == 2 || v == 1) { g.strip = v; g.strip_long = 0; } }
         env = getenv("MI355R_SKY_BYTES");
         if (env) g.sky_bytes = atoi(env) != 0;
-        env = getenv("MI355R_SKY_BINS");
-        if (env) g.sky_bins = atoi(env) != 0;
+        env = getenv("MI355R_SKY_TABLE");
+        if (env) g.sky_table = atoi(env) != 0;
+        env = getenv("MI355R_FILL_WAVES");
+        if (env) { const int v = atoi(env); if (v == 1 || v == 2 || v == 4) g.fill_waves = v; }
         env = getenv("MI355R_STRIP_LONG");
         if (env) g.strip_long = (unsigned)atoi(env);
         env = getenv("MI355R_SPLIT_BLEND");
@@ -1640,7 +1645,9 @@ struct PassPlan {
     std::vector<size_t> side_at, verts_at;
     bool has_blend, samples_gpu_texture;
     bool narrow_texels;             /* every blinn / pbr draw samples 4-byte images only */
-    int families;
+    int families;                   /* bit f: draws of family f that go through the bins */
+    size_t sky_first;               /* the pass's last sky_draws draws are sky boxes kept on its table of sky triangles: the first of them */
+    int sky_draws;
     Fb *fb;
     int level;                      /* 0: depends on no other pass of the flush */
     size_t slot;                    /* its place in batch order: control block and PassParams of the pass */
@@ -1658,9 +1665,19 @@ static void plan_pass(PassPlan &pl, size_t &total) {
         pl.T += (size_t)pd.rec.num_faces;
         pl.has_blend |= (pd.rec.flags & RZ_DRAW_BLEND) != 0;
         pl.samples_gpu_texture |= !pd.gpu_textures.empty();
-        pl.families |= 1 << pd.rec.family;
         if (pd.rec.family != RZ_FAMILY_SKYBOX && !(pd.rec.flags & RZ_DRAW_NARROW_TEXELS)) pl.narrow_texels = false;
     }
+    /* sky boxes drawn last in a pass without blending (the frame driver's order, test_helper.c:480-506) stay out of the bins */
+    pl.sky_first = pl.last;
+    pl.sky_draws = 0;
+    if (g.sky_table && !g.counting && !pl.has_blend)
+        while (pl.sky_first > pl.first && pl.sky_draws < RZ_SKY_DRAWS) {
+            const DrawRec &r = g.pending[pl.sky_first - 1].rec;
+            if (r.family != RZ_FAMILY_SKYBOX || r.num_faces > RZ_SKY_FACES) break;
+            pl.sky_first--;
+            pl.sky_draws++;
+        }
+    for (size_t i = pl.first; i < pl.sky_first; i++) pl.families |= 1 << g.pending[i].rec.family;
     total = (total + 255) & ~(size_t)255;
     pl.off_draws = total;
     total += sizeof(DrawRec) * D;
@@ -1723,6 +1740,7 @@ static void fill_pass(const PassPlan &pl, char *hb, char *db) {
                 memcpy(hb + g_attach_jobs_at + sizeof(AttachJob) * g_attach_jobs_filled++, &job, sizeof job);
             }
         }
+        rec.sky_slot = pl.first + i >= pl.sky_first ? (int32_t)(pl.first + i - pl.sky_first) + 1 : 0;
         memcpy(hb + pl.off_draws + sizeof(DrawRec) * i, &rec, sizeof rec);
         first_tri[i] = running;
         running += (uint32_t)rec.num_faces;
@@ -1738,6 +1756,7 @@ struct Batch {
     size_t off_params;              /* PassParams[] of the members in the upload region */
     bool has_blend;
     int families;
+    bool sky_table = false;         /* one of its passes keeps sky boxes on its table of sky triangles */
 };
 
 /* What is kept of a flush until its control blocks have been looked at: enough to run any of its
@@ -1826,7 +1845,8 @@ static void prepare_batch(const Batch &b, const FlushRecord &fr, bool reserve_on
     reserve(L.fan_tri, fans * RZ_MAX_FAN, st);
     reserve(L.fan_vary, fans * RZ_MAX_POLY * RZ_VARY_STRIDE, st);
     reserve(L.bin_range, bins, st);
-    if (g.sky_bins) reserve(L.sky_bins, bins, st);
+    reserve(L.sky_bins, bins, st);
+    reserve(L.sky_table, b.members.size() * RZ_SKY_TABLE, st);
     reserve(L.bin_class, bins, st);
     reserve(L.bin_counts, matrix, st);
     /* tiles are dealt to the parts of a list by their index: a part holds at most its even share */
@@ -1891,7 +1911,8 @@ static void prepare_batch(const Batch &b, const FlushRecord &fr, bool reserve_on
         P.bin_boxes = L.bin_boxes.ptr + list_off;
         P.bin_capacity = (uint32_t)list_cap[k];
         P.ref = L.ref.ptr ? L.ref.ptr + ref_off : nullptr;
-        P.ref_scanned = (b.families & (1 << RZ_FAMILY_SKYBOX)) != 0;
+        P.sky_draws = pl.sky_draws;
+        P.sky_table = L.sky_table.ptr + k * RZ_SKY_TABLE;
         P.counters = g.counting ? g.d_counters : nullptr;
         P.scan_list = !b.has_blend ? -1 : splits_blend(tiles, b.members.size()) ? (int)RZ_VISIBILITY_LIST : (int)RZ_ORDERED_LIST;
         P.micro_area = g.micro_area;
@@ -1912,6 +1933,11 @@ static void prepare_batch(const Batch &b, const FlushRecord &fr, bool reserve_on
         memcpy(hb + b.off_params + sizeof(PassParams) * k, &P, sizeof P);
         g.last_pass = P;
         g.have_last_pass = true;
+        {
+            size_t before_sky = 0;
+            for (size_t d = pl.first; d < pl.sky_first; d++) before_sky += (size_t)g.pending[d].rec.num_faces;
+            g.last_pass_sky_first = (int)before_sky;
+        }
         tri_off += pl.T; fan_off += fan_cap[k]; list_off += list_cap[k];
         bin_off += (size_t)P.bins_x * P.bins_y;
         matrix_off += ((pl.T + 63) / 64) * (size_t)P.bins_x * P.bins_y;
@@ -1967,7 +1993,7 @@ static void launch_batch(const Batch &b, const std::vector<PassPlan> &plans, cha
             tris += plans[i].T;
             bins += (size_t)((plans[i].fb->pub.width + RZ_BIN - 1) / RZ_BIN) * ((plans[i].fb->pub.height + RZ_BIN - 1) / RZ_BIN);
         }
-        if (L.bin_range.cap < bins || L.bin_class.cap < bins || (g.sky_bins && L.sky_bins.cap < bins)) fatal("per-bin scratch of lane %d is smaller than the batch it is about to run", b.lane);
+        if (L.bin_range.cap < bins || L.bin_class.cap < bins || L.sky_bins.cap < bins || L.sky_table.cap < b.members.size() * RZ_SKY_TABLE) fatal("per-bin scratch of lane %d is smaller than the batch it is about to run", b.lane);
         const bool uses_ref = !(b.has_blend && !splits_blend(batch_tiles, n));
         if (L.queue_counts.cap < RZ_LISTS * RZ_QUEUE_WAYS * RZ_QUEUE_PAD || L.queue.cap < RZ_LISTS * RZ_QUEUE_WAYS * (size_t)queue_capacity ||
             L.tile_listed.cap < batch_tiles || L.bin_boxes.cap < L.bin_list.cap || (uses_ref && (!L.ref.ptr || L.ref.cap < pixels)) || L.tri.cap < tris || L.bbox.cap < tris)
@@ -1981,7 +2007,12 @@ static void launch_batch(const Batch &b, const std::vector<PassPlan> &plans, cha
     stamp();
     rz_bin_count_kernel<<<tgrid, dim3(256), 0, st>>>(passes);
     rz_bin_scan_kernel<<<dim3((unsigned)((max_bins + 63) / 64), n), dim3(64 * RZ_SCAN_SEGMENTS), 0, st>>>(passes);
-    rz_bin_fill_kernel<<<dim3((unsigned)((max_T + 63) / 64 * n)), dim3(64 * RZ_FILL_WAVES), 0, st>>>(passes, n);
+    {
+        const dim3 grid((unsigned)((max_T + 63) / 64 * n));
+        if (g.fill_waves == 1) rz_bin_fill_kernel<1><<<grid, dim3(64), 0, st>>>(passes, n);
+        else if (g.fill_waves == 2) rz_bin_fill_kernel<2><<<grid, dim3(128), 0, st>>>(passes, n);
+        else rz_bin_fill_kernel<4><<<grid, dim3(256), 0, st>>>(passes, n);
+    }
     stamp();
     bool narrow = true;
     for (size_t i : b.members) narrow = narrow && plans[i].narrow_texels;
@@ -1989,7 +2020,7 @@ static void launch_batch(const Batch &b, const std::vector<PassPlan> &plans, cha
      * together, fragment stacks), or visibility first, the ordered kernel for the tiles where
      * blended fragments pile up and the shade kernels for the rest */
     const int only = b.families == (1 << RZ_FAMILY_BLINN) ? 0 : b.families == (1 << RZ_FAMILY_PBR) ? 1 : -1;
-    bool in_strips = false, sky_bins = false;       /* the shade lists hold 16x8 blocks; bins with nothing but sky are rz_sky_kernel's */
+    bool in_strips = false;                         /* the shade lists hold 16x8 blocks */
     if (b.has_blend && !splits_blend(batch_tiles, n)) {
         /* over the tiles of the bins that are not empty (listed by rz_bin_scan_kernel) */
         auto kernel = rz_raster_list_kernel<-1, false>;
@@ -2023,10 +2054,9 @@ static void launch_batch(const Batch &b, const std::vector<PassPlan> &plans, cha
             const int strip = !g.strip_long ? g.strip : std::min(few, longest >= g.strip_long ? 1 : longest >= g.strip_long / 2 ? std::min(g.strip, 2) : g.strip);
             const unsigned strips_per_bin = RZ_BIN / (8u * strip);
             auto kernel = strip == 8 ? rz_strip_kernel<8> : strip == 4 ? rz_strip_kernel<4> : strip == 2 ? rz_strip_kernel<2> : rz_strip_kernel<1>;
-            /* bins with nothing but skybox triangles are left to rz_sky_kernel; empty bins are finished by the kernel that says so */
-            sky_bins = g.sky_bins && (b.families & (1 << RZ_FAMILY_SKYBOX));
-            rz_bin_class_kernel<<<dim3((unsigned)max_bins, n), dim3(64), 0, st>>>(passes, L.bin_list.ptr, L.bin_range.ptr,
-                                                                             sky_bins ? L.sky_bins.ptr : nullptr, L.bin_class.ptr);
+            /* empty bins are finished by the kernel that says so; a pass with a table of sky triangles gets its bins' records for rz_sky_kernel */
+            rz_bin_class_kernel<<<dim3((unsigned)max_bins, n), dim3(64), 0, st>>>(passes, L.tri.ptr, L.fan_tri.ptr, L.bin_range.ptr,
+                                                                             L.sky_bins.ptr, L.bin_class.ptr);
             if (g.verbose) fprintf(stderr, "mi355r: batch of %u passes, longest bin list last time %u entries, strips of %d\n", n, longest, strip);
             snprintf(g.last_raster_kernel, sizeof g.last_raster_kernel, "rz_strip_kernel<%d>", strip);
             /* passes of one size: a strip then finds its bin's class without reading its pass's parameters */
@@ -2037,9 +2067,13 @@ static void launch_batch(const Batch &b, const std::vector<PassPlan> &plans, cha
                 passes, L.bin_list.ptr, L.bin_boxes.ptr, L.vary.ptr, L.fan_vary.ptr, db, L.bin_range.ptr, L.bin_class.ptr, uniform_w, uniform_h);
         }
         stamp();
-        if (b.families & (1 << RZ_FAMILY_SKYBOX))
-            rz_sky_kernel<2><<<tiles, dim3(128), 0, st>>>(passes, L.tri.ptr, L.fan_tri.ptr, L.vary.ptr, L.fan_vary.ptr, db, L.ref.ptr,
-                                                          L.bin_list.ptr, sky_bins ? L.sky_bins.ptr : nullptr);
+        if (b.sky_table)
+            rz_sky_kernel<2><<<tiles, dim3(128), 0, st>>>(passes, L.tri.ptr, L.fan_tri.ptr, L.vary.ptr, L.fan_vary.ptr, db, L.sky_bins.ptr);
+        if (b.families & (1 << RZ_FAMILY_SKYBOX)) {     /* skybox fragments that came through the bins */
+            auto kernel = in_strips ? rz_shade_list_kernel<2, false, true> : rz_shade_list_kernel<2, false, false>;
+            kernel<<<shade_grid, dim3(256), 0, st>>>(passes, L.tri.ptr, L.fan_tri.ptr, L.vary.ptr, L.fan_vary.ptr, db, L.ref.ptr,
+                                                     L.queue.ptr, L.queue_counts.ptr, queue_capacity);
+        }
         stamp();
         if (b.families & (1 << RZ_FAMILY_BLINN)) {
             auto kernel = in_strips ? (narrow ? rz_shade_list_kernel<0, true, true> : rz_shade_list_kernel<0, false, true>)
@@ -2092,6 +2126,7 @@ static void run_again(FlushRecord &fr) {
             if (c[2] == 0) continue;
             r.members.push_back(i);
             r.families |= fr.plans[i].families;
+            r.sky_table = r.sky_table || fr.plans[i].sky_draws > 0;
             if (c[2] & RZ_ERR_FAN_OVERFLOW) g.fan_highwater = std::max<size_t>(g.fan_highwater, c[0]);
             if (c[2] & RZ_ERR_BIN_OVERFLOW) g.list_highwater = std::max<size_t>(g.list_highwater, c[1]);
         }
@@ -2602,9 +2637,10 @@ extern "C" void graphics_flush(void) {
                 };
                 for (size_t i = 0; i < plans.size(); i++) {
                     if (plans[i].level != l || (int)plans[i].has_blend != blend) continue;
-                    if (b.members.empty()) { b.has_blend = blend != 0; b.families = 0; }
+                    if (b.members.empty()) { b.has_blend = blend != 0; b.families = 0; b.sky_table = false; }
                     b.members.push_back(i);
                     b.families |= plans[i].families;
+                    b.sky_table = b.sky_table || plans[i].sky_draws > 0;
                     if (b.members.size() >= g.max_batch) close();
                 }
                 close();
@@ -2760,6 +2796,25 @@ extern "C" void mi355r_inspect_boxes(unsigned int *boxes, unsigned int *fans) {
     std::vector<TriRec> recs(T);
     HIP_OK(hipMemcpy(boxes, P.bbox, T * sizeof(uint2), hipMemcpyDeviceToHost));
     HIP_OK(hipMemcpy(recs.data(), P.tri, T * sizeof(TriRec), hipMemcpyDeviceToHost));
+    /* triangles of sky boxes that are kept on the pass's table have no box in the binning kernels' array: theirs
+     * are put together from the table and their records */
+    if (P.sky_draws > 0) {
+        std::vector<uint32_t> table(RZ_SKY_TABLE), first_tri((size_t)P.num_draws + 1);
+        HIP_OK(hipMemcpy(table.data(), P.sky_table, table.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        HIP_OK(hipMemcpy(first_tri.data(), P.first_tri, first_tri.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        for (int k = 0; k < P.sky_draws; k++) {
+            const int d = P.num_draws - P.sky_draws + k;
+            for (uint32_t t = first_tri[d]; t < first_tri[d + 1]; t++) {
+                const uint32_t *entry = &table[((size_t)k * RZ_SKY_FACES + (t - first_tri[d])) * RZ_MAX_FAN];
+                bool any = false;
+                for (int j = 0; j < RZ_MAX_FAN; j++) any = any || entry[j] != 0xffffffffu;
+                if (!any) continue;
+                const uint32_t fan = RZ_META_CLIPPED(recs[t].meta) ? RZ_META_FAN(recs[t].meta) : 1u;
+                boxes[2 * t] = recs[t].bx;
+                boxes[2 * t + 1] = (recs[t].by & 0x3fffu) | ((recs[t].by >> 16) << 14) | (fan << 28);
+            }
+        }
+    }
     for (size_t t = 0; t < T; t++) {
         /* device packing (pack_bin_box): y0 | y1 << 14 | entries << 28 */
         const bool empty = (boxes[2 * t] & 0xffffu) > (boxes[2 * t] >> 16);
@@ -2894,6 +2949,8 @@ extern "C" void mi355r_set_scratch_estimate(unsigned long long fan_blocks, unsig
 extern "C" unsigned long long mi355r_replayed_draws(void) { return g.replayed_draws; }
 
 extern "C" const char *mi355r_last_raster_kernel(void) { return g.last_raster_kernel; }
+
+extern "C" int mi355r_inspect_sky_first(void) { return g.have_last_pass ? g.last_pass_sky_first : 0; }
 
 extern "C" unsigned long long mi355r_passes_run_again(void) {
     ensure_ready();

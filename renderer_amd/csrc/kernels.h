@@ -72,6 +72,7 @@ __global__ void __launch_bounds__(256) rz_begin_kernel(const PassParams *__restr
     if (gv < 8u) P.control[gv] = (gv == 2u && P.level > 0 && *P.flush_flag != 0u) ? (uint32_t)RZ_ERR_SKIPPED : 0u;
     if (blockIdx.y == 0 && gv < RZ_LISTS * RZ_QUEUE_WAYS) P.queue_counts[gv * RZ_QUEUE_PAD] = 0;    /* ... and the batch's work-list lengths */
     for (uint32_t t = gv; t < (uint32_t)(P.tiles_x * P.tiles_y); t += gridDim.x * 256u) P.tile_listed[t] = 0;
+    if (P.sky_draws && gv < (uint32_t)RZ_SKY_TABLE) P.sky_table[gv] = 0xffffffffu;      /* RZ_REF_NONE: no sky triangle yet */
     {   /* ... and the pass's (chunk, bin) matrix, which rz_bin_count_kernel adds into */
         const uint32_t cells = (((uint32_t)P.num_tris + 63u) / 64u) * (uint32_t)(P.bins_x * P.bins_y);
         for (uint32_t t = gv; t < cells; t += gridDim.x * 256u) P.bin_counts[t] = 0;
@@ -194,7 +195,13 @@ __global__ void __launch_bounds__(256) rz_vertex_kernel(const PassParams *__rest
             if (make_tri(c, P.width, P.height, double_sided, (uint32_t)d, rec, x0, x1, y0, y1)) {
                 rec.meta |= class_bits;
                 store_tri(&P.tri[tri], rec);
-                P.bbox[tri] = pack_bin_box(rec.bx, rec.by, 1u);
+                if (D.sky_slot) {       /* a sky box on the pass's table: its place there instead of one in the bins */
+                    P.bbox[tri] = empty;
+                    if (x0 <= x1 && y0 <= y1)
+                        P.sky_table[((uint32_t)(D.sky_slot - 1) * RZ_SKY_FACES + (tri - P.first_tri[d])) * RZ_MAX_FAN] = tri;
+                } else {
+                    P.bbox[tri] = pack_bin_box(rec.bx, rec.by, 1u);
+                }
                 if (P.counters) atomicAdd(&P.counters[1], 1ull);
                 fate = 1;
             } else {
@@ -551,6 +558,9 @@ __global__ void __launch_bounds__(64) rz_clip_kernel(const PassParams *__restric
             rec.meta |= class_bits;
             store_tri(&P.fan_tri[(size_t)block * RZ_MAX_FAN + k], rec);
             bool any_px = x0 <= x1 && y0 <= y1;
+            if (D.sky_slot && any_px)   /* a sky box on the pass's table */
+                P.sky_table[((uint32_t)(D.sky_slot - 1) * RZ_SKY_FACES + (t - P.first_tri[d])) * RZ_MAX_FAN + (uint32_t)k] =
+                    0x80000000u | (block * RZ_MAX_FAN + (uint32_t)k);
             s_box[0][k] = any_px ? x0 : 65535; s_box[1][k] = any_px ? x1 : -1;
             s_box[2][k] = any_px ? y0 : 65535; s_box[3][k] = any_px ? y1 : -1;
         }
@@ -571,7 +581,7 @@ __global__ void __launch_bounds__(64) rz_clip_kernel(const PassParams *__restric
                 head.bx = (uint32_t)ux0 | ((uint32_t)ux1 << 16);
                 head.by = (uint32_t)uy0 | ((uint32_t)uy1 << 16);
                 store_tri(&P.tri[t], head);
-                P.bbox[t] = pack_bin_box(head.bx, head.by, (uint32_t)fan);
+                if (!D.sky_slot) P.bbox[t] = pack_bin_box(head.bx, head.by, (uint32_t)fan);    /* (a sky box on the pass's table is kept out of the bins) */
             }
         }
     }
@@ -675,7 +685,7 @@ __global__ void __launch_bounds__(256) rz_bin_count_kernel(const PassParams *__r
      * handful of bins: an atomic per triangle and bin then hits the same few words 64 times over.  So when the
      * chunk's joint bin rectangle is small its bins are taken one after the other, the triangles that touch a bin
      * counted with a ballot (summed when a clipped triangle adds a whole fan), and lane i stores bin i's count
-     * (azura: 52 -> 20 us per launch of 32 passes). */
+     * (azura at 800x600: 51 -> 8 us per launch of 32 passes). */
     const unsigned long long active = __ballot(r.entries != 0);
     if (!active) return;
     const int ux0 = wave_min_i(r.entries ? r.bx0 : 0x7fffffff), ux1 = wave_max_i(r.entries ? r.bx1 : -1);
@@ -796,16 +806,16 @@ RZ_DEV uint2 entry_box(float4 q3) {
     return make_uint2(__float_as_uint(q3.z), __float_as_uint(q3.w) | (RZ_META_CUTOFF(__float_as_uint(q3.y)) << 31));
 }
 
-/* One workgroup of RZ_FILL_WAVES waves per chunk.  Lanes first hold the
+/* One workgroup of WAVES waves per chunk.  Lanes first hold the
  * chunk's 64 triangles (box, record), then turn into BINS: the chunk's joint
  * bin rectangle is cut into rounds of 64 bins, wave w takes rounds w,
- * w + RZ_FILL_WAVES, ..., lane i of a round one bin, and walks the 64
+ * w + WAVES, ..., lane i of a round one bin, and walks the 64
  * triangles in order (their data broadcast with readlane), appending those
  * that touch its bin.  No lane waits on another and the only dependent loads
  * are the per-bin start offsets.  Every entry carries a copy of the
  * triangle's record. */
-#define RZ_FILL_WAVES 4
-__global__ void __launch_bounds__(64 * RZ_FILL_WAVES) rz_bin_fill_kernel(const PassParams *__restrict__ passes, uint32_t num_passes) {
+template <int WAVES>
+__global__ void __launch_bounds__(64 * WAVES) rz_bin_fill_kernel(const PassParams *__restrict__ passes, uint32_t num_passes) {
     /* Workgroups start in index order: the pass is the fastest part of the index and a pass's chunks are taken
      * from its last one down.  The chunks that run longest are those of triangles over many bins, i.e. the sky
      * box, which a frame draws last (test_helper.c:497-503): they start first in every pass instead of making
@@ -909,7 +919,7 @@ __global__ void __launch_bounds__(64 * RZ_FILL_WAVES) rz_bin_fill_kernel(const P
         return;
     }
 
-    for (int base = wave * 64; base < ubins; base += 64 * RZ_FILL_WAVES) {
+    for (int base = wave * 64; base < ubins; base += 64 * WAVES) {
         const int i = base + lane;
         const bool have = i < ubins;
         const int bx = ux0 + i % uw, by = uy0 + i / uw;
@@ -1451,18 +1461,12 @@ RZ_DEV void blend_visibility_tile(const PassParams P, const uint32_t pass_index,
     const int bin = (ty0 / RZ_BIN) * P.bins_x + tx0 / RZ_BIN;
     const uint2 range = (bin_range_base + P.bin_off)[bin];          /* {first entry, entries} */
     const uint32_t count = range.y;
-    if (count == 0 && !P.clear_color_pending && !P.clear_depth_pending) {   /* uniform over the workgroup */
-        /* nobody looks at the references of a tile that is on no work list, unless a family's kernel scans every tile */
-        if (P.ref_scanned)
-            for (int q = 0; q < PPL; q++) if (valid[q]) P.ref[pixel[q]] = RZ_REF_NONE;
-        return;
-    }
+    if (count == 0 && !P.clear_color_pending && !P.clear_depth_pending) return;     /* uniform over the workgroup; nobody looks at the references of a tile that is on no work list */
     if (count == 0) {               /* nothing but the pending clears (uniform over the workgroup) */
         for (int q = 0; q < PPL; q++) {
             if (!valid[q]) continue;
             if (P.clear_depth_pending) P.depth[pixel[q]] = P.clear_depth;
             if (P.clear_color_pending) P.color[pixel[q]] = P.clear_color;
-            if (P.ref_scanned) P.ref[pixel[q]] = RZ_REF_NONE;
         }
         return;
     }
@@ -1580,11 +1584,11 @@ RZ_DEV void blend_visibility_tile(const PassParams P, const uint32_t pass_index,
         /* the shade kernels write the colour of every pixel that has a fragment */
         if (P.clear_color_pending && ref_of[q] == RZ_REF_NONE) P.color[pixel[q]] = P.clear_color;
     }
-    /* every tile that holds blinn or pbr fragments goes on that family's work list (all passes of the batch
+    /* every tile that holds fragments goes on their family's work list (all passes of the batch
      * together), appended by the first wave of the tile to find one (tile_listed keeps who was first).  A list is
      * kept in RZ_QUEUE_WAYS parts, chosen by the tile's index, with counters a cache line apart, so that the appends
      * of a whole batch do not pile up on one counter. */
-    for (uint32_t f = 0; f < 2; f++) {
+    for (uint32_t f = 0; f < 3; f++) {
         bool mine = false;
         for (int q = 0; q < PPL; q++) mine |= ((ref_of[q] >> 28) & 3u) == f;
         if (!__any(mine)) continue;
@@ -1593,7 +1597,7 @@ RZ_DEV void blend_visibility_tile(const PassParams P, const uint32_t pass_index,
             const uint32_t before = atomicOr(&P.tile_listed[tile], 1u << f);
             if (!(before >> f & 1u)) {
                 /* by the tile's index in the batch: no part can get more than its even share */
-                const uint32_t part = f * RZ_QUEUE_WAYS + ((P.tile_off + tile) & (RZ_QUEUE_WAYS - 1u));
+                const uint32_t part = (f == 2u ? RZ_SKY_LIST : f) * RZ_QUEUE_WAYS + ((P.tile_off + tile) & (RZ_QUEUE_WAYS - 1u));
                 const uint32_t at = atomicAdd(&P.queue_counts[part * RZ_QUEUE_PAD], 1u);
                 if (at < P.queue_capacity)
                     P.queue[(size_t)part * P.queue_capacity + at] = (pass_index << 20) | (tile_y << 9) | tile_x;
@@ -1622,48 +1626,51 @@ __global__ void __launch_bounds__(128) rz_blend_visibility_kernel(const PassPara
     }
 }
 
-/* A bin whose list holds nothing but the triangles of one skybox draw (most of a frame around a model).
- * Lists are ascending in the triangle's index and a draw's triangles are consecutive, so the first and the
- * last entry tell.  For such a bin rz_strip_kernel does nothing at all and rz_sky_kernel resolves
- * visibility itself: it needs the weights of the visible triangle for the shader anyway, the few
- * entries come through scalar loads, and depth, reference and colour make no round trip between two
- * kernels.  Not while fragments are counted (the counts belong to the rasteriser's stage).
+/* The sky box.  A frame's sky is twelve triangles that cover every pixel the models leave free: as list entries
+ * they would sit in every bin of the frame (written there by the binning kernels, walked there by every strip).  A
+ * sky box that is drawn last in its pass -- the frame driver's order: opaque models, sky box, then the blended
+ * models, which start a pass of their own (test_helper.c:480-506) -- is kept out of the bins instead: the vertex
+ * and clip kernels put its triangles (clipped: their fans) on the pass's TABLE of sky triangles, in submission
+ * order, and rz_sky_kernel resolves them per pixel against what the strips left in the depth buffer.  Drawn last
+ * means: a sky fragment wins iff its depth <= the depth the models left (graphics.c:523), and among sky fragments
+ * the later one wins on equal depth -- the table's order.  Depth, colour and weights make no round trip between
+ * two kernels.  (A skybox program that draws more than 12 triangles, or not last, or while fragments are counted,
+ * goes through the bins like any other draw, and its fragments through rz_shade_list_kernel.)
  *
- * rz_bin_class_kernel, one wave per bin, writes a record for EVERY bin of the batch: whether it is
- * such a bin, where its list starts, its draw, and for each of the 32 REGIONS of 32x4 pixels a wave of
- * rz_sky_kernel takes the set of entries that can touch it (box and conservative edge test, as
- * rz_strip_kernel culls its blocks, lane = region).  The two triangles of a sky box face share their
- * box: testing both in every pixel of the face cost the sky kernel a third of its time again.  And a
- * wave learns all of this in one memory round trip where reading the bin's range, then the list's ends,
- * then entry after entry took four or more. */
-#define RZ_SKY_ONLY_MAX 8u
+ * rz_bin_class_kernel, one wave per bin, writes a SkyBin record for every bin of such a pass: the (up to
+ * RZ_SKY_BIN_MAX) table entries whose box meets the bin, and for each of the 32 REGIONS of 32x4 pixels a wave of
+ * rz_sky_kernel takes the set of those that can touch it (box and conservative edge test, as rz_strip_kernel culls
+ * its blocks, lane = region).  The two triangles of a sky box face share their box: testing both in every pixel of
+ * the face cost the sky kernel a third of its time again.  A wave learns all of this in one memory round trip. */
+#define RZ_SKY_BIN_MAX 8u
+#define RZ_SKY_BIN_OVERFLOW 0xffffffffu
 struct SkyBin {
-    uint8_t entries_of_region[32];  /* bit e: entry e of the list can touch the region */
-    uint32_t count;                 /* entries of the list; 0 = not a bin of this kind */
-    uint32_t first;                 /* the list's first entry in the pass's lists */
-    uint32_t draw;                  /* the draw all entries belong to */
-    uint32_t pad[5];
+    uint8_t entries_of_region[32];  /* bit e: entry e can touch the region */
+    uint32_t ref[RZ_SKY_BIN_MAX];   /* the entries, in table order: what the table holds for them (a triangle's index or its fan record's) */
+    uint32_t count;                 /* entries; RZ_SKY_BIN_OVERFLOW: more than fit, the whole table is looked at */
+    uint32_t fresh;                 /* the bin's list is empty: nothing has consumed the pass's pending clears for its pixels */
+    uint32_t pad[14];
 };
-RZ_DEV bool sky_only_bin(const PassParams &P, const BinEntry *list, uint32_t count) {
-    if (count == 0u || count > RZ_SKY_ONLY_MAX || P.counters) return false;
-    const uint32_t first = list[0].rec.meta, last = list[count - 1u].rec.meta;
-    return RZ_META_FAMILY(first) == 2u && RZ_META_FAMILY(last) == 2u && RZ_META_DRAW(first) == RZ_META_DRAW(last);
-}
+static_assert(sizeof(SkyBin) == 128, "one record = one memory line");
 RZ_DEV uint32_t sky_region_of(int tx0, int ry0) { return (uint32_t)(((ry0 % RZ_BIN) / 4) * 2 + (tx0 % RZ_BIN) / RZ_TILE_W); }
+/* the record a table entry (or any fragment reference) stands for */
+RZ_DEV const TriRec *ref_record(uint32_t ref, const TriRec *tri_table, const TriRec *fan_table) {
+    return (ref & RZ_REF_FAN) ? &fan_table[ref & ~RZ_REF_FAN] : &tri_table[ref];
+}
 
 /* What rz_strip_kernel has to do with a bin, worked out once per bin (one wave each; grid x = bin, y = pass of the
- * batch) instead of by every one of its strips: RZ_BIN_STRIP = walk its list, RZ_BIN_DONE = nothing --
- *   an EMPTY bin is finished right here: pending clears (and the blank references a kernel that looks at every
- *     pixel's reference wants) are written a row of four pixels per lane, 256 contiguous bytes per bin row and
- *     plane -- a frame without a sky box is mostly such bins, and as 32-byte pieces out of strips whose waves had
- *     each read their pass's parameters and the bin's range first, their clears ran at a quarter of the memory's rate;
- *   a bin with nothing but one sky box's triangles is rz_sky_kernel's, and gets its SkyBin record (above).
- * A strip whose batch has passes of one size finds its bin's class with two kernel arguments and its own index,
- * before it has read anything else. */
+ * batch) instead of by every one of its strips: RZ_BIN_STRIP = walk its list, RZ_BIN_DONE = nothing, the bin is
+ * EMPTY.  An empty bin is finished right here, unless the pass has a table of sky triangles (then rz_sky_kernel
+ * writes every pixel of it anyway): pending clears are written a row of four pixels per lane, 256 contiguous bytes
+ * per bin row and plane -- a frame without a sky box is mostly such bins, and as 32-byte pieces out of strips whose
+ * waves had each read their pass's parameters and the bin's range first, their clears ran at a quarter of the
+ * memory's rate.  A strip whose batch has passes of one size finds its bin's class with two kernel arguments and
+ * its own index, before it has read anything else.  For a pass with a table of sky triangles the bin's SkyBin
+ * record is written here too. */
 enum { RZ_BIN_STRIP = 0, RZ_BIN_DONE = 1 };
 __global__ void __launch_bounds__(64) rz_bin_class_kernel(const PassParams *__restrict__ passes,
-        const BinEntry *__restrict__ list_base, const uint2 *__restrict__ bin_range_base, SkyBin *__restrict__ sky_base,
-        uint32_t *__restrict__ class_base) {
+        const TriRec *__restrict__ tri_base, const TriRec *__restrict__ fan_base,
+        const uint2 *__restrict__ bin_range_base, SkyBin *__restrict__ sky_base, uint32_t *__restrict__ class_base) {
     const PassParams &P = passes[blockIdx.y];
     if ((int)blockIdx.x >= P.bins_x * P.bins_y) return;
     const int lane = threadIdx.x & 63;
@@ -1674,62 +1681,73 @@ __global__ void __launch_bounds__(64) rz_bin_class_kernel(const PassParams *__re
     }
     const uint2 range = (bin_range_base + P.bin_off)[blockIdx.x];
     const int bin_x0 = (int)(blockIdx.x % (uint32_t)P.bins_x) * RZ_BIN, bin_y0 = (int)(blockIdx.x / (uint32_t)P.bins_x) * RZ_BIN;
-    if (range.y == 0u) {
-        const bool blank_refs = P.ref_scanned != 0;
-        if (P.clear_color_pending || P.clear_depth_pending || blank_refs) {
-            const float d = P.clear_depth;
-            const uint32_t c = P.clear_color;
-            if ((P.width & 3) == 0) {
-                const int x = bin_x0 + (lane & 15) * 4;
-                if (x < P.width)
-                    for (int row = lane >> 4; row < RZ_BIN; row += 4) {
-                        const int py = bin_y0 + row;
-                        if (py >= P.height) break;
-                        const size_t pixel = (size_t)py * (size_t)P.width + (size_t)x;
-                        if (P.clear_depth_pending) *(float4 RZ_GLOBAL*)(P.depth + pixel) = make_float4(d, d, d, d);
-                        if (P.clear_color_pending) *(uint4 RZ_GLOBAL*)(P.color + pixel) = make_uint4(c, c, c, c);
-                        if (blank_refs) *(uint4 RZ_GLOBAL*)(P.ref + pixel) = make_uint4(RZ_REF_NONE, RZ_REF_NONE, RZ_REF_NONE, RZ_REF_NONE);
-                    }
-            } else {
-                for (int i = lane; i < RZ_BIN * RZ_BIN; i += 64) {
-                    const int px = bin_x0 + (i & (RZ_BIN - 1)), py = bin_y0 + i / RZ_BIN;
-                    if (px >= P.width || py >= P.height) continue;
-                    const size_t pixel = (size_t)py * (size_t)P.width + (size_t)px;
-                    if (P.clear_depth_pending) P.depth[pixel] = d;
-                    if (P.clear_color_pending) P.color[pixel] = c;
-                    if (blank_refs) P.ref[pixel] = RZ_REF_NONE;
+    if (lane == 0) *bin_class = range.y == 0u ? (uint32_t)RZ_BIN_DONE : (uint32_t)RZ_BIN_STRIP;
+    if (P.sky_draws == 0) {
+        if (range.y != 0u || !(P.clear_color_pending || P.clear_depth_pending)) return;
+        const float d = P.clear_depth;
+        const uint32_t c = P.clear_color;
+        if ((P.width & 3) == 0) {
+            const int x = bin_x0 + (lane & 15) * 4;
+            if (x < P.width)
+                for (int row = lane >> 4; row < RZ_BIN; row += 4) {
+                    const int py = bin_y0 + row;
+                    if (py >= P.height) break;
+                    const size_t pixel = (size_t)py * (size_t)P.width + (size_t)x;
+                    if (P.clear_depth_pending) *(float4 RZ_GLOBAL*)(P.depth + pixel) = make_float4(d, d, d, d);
+                    if (P.clear_color_pending) *(uint4 RZ_GLOBAL*)(P.color + pixel) = make_uint4(c, c, c, c);
                 }
+        } else {
+            for (int i = lane; i < RZ_BIN * RZ_BIN; i += 64) {
+                const int px = bin_x0 + (i & (RZ_BIN - 1)), py = bin_y0 + i / RZ_BIN;
+                if (px >= P.width || py >= P.height) continue;
+                const size_t pixel = (size_t)py * (size_t)P.width + (size_t)px;
+                if (P.clear_depth_pending) P.depth[pixel] = d;
+                if (P.clear_color_pending) P.color[pixel] = c;
             }
         }
+        return;
     }
-    bool sky = false;
-    if (sky_base) {
-        const BinEntry *list = list_base + P.list_off + range.x;
-        sky = sky_only_bin(P, list, range.y);
-        const int rx0 = bin_x0 + RZ_TILE_W * (lane & 1), ry0 = bin_y0 + 4 * ((lane >> 1) & 15);
-        uint32_t mine = 0, draw = 0;
-        if (sky) {
-            draw = RZ_META_DRAW(list[0].rec.meta);
-            for (uint32_t e = 0; e < range.y; e++) {
-                const float4 *q = (const float4*)&list[e];
-                const float4 c0 = q[1], c1 = q[2];
-                const uint2 box = entry_box(q[4]);
-                const bool hit = box_overlaps(make_uint2(box.x, box.y & 0x7fffffffu), rx0, ry0, rx0 + RZ_TILE_W - 1, ry0 + 3) &&
-                                 !block_outside(c0, c1, (float)rx0 + 0.5f, (float)(rx0 + RZ_TILE_W - 1) + 0.5f, (float)ry0 + 0.5f, (float)ry0 + 3.5f);
-                mine |= (hit ? 1u : 0u) << e;
-            }
+    /* ---- the bin's record for rz_sky_kernel: the table entries whose box meets the bin, in table order ... */
+    const TriRec *tri_table = tri_base + P.tri_off;
+    const TriRec *fan_table = fan_base + (size_t)P.fan_off * RZ_MAX_FAN;
+    __shared__ uint32_t s_sel[RZ_SKY_BIN_MAX];
+    uint32_t count = 0;                                         /* wave-uniform */
+    const int table_entries = P.sky_draws * RZ_SKY_FACES * RZ_MAX_FAN;
+    for (int first = 0; first < table_entries && count <= RZ_SKY_BIN_MAX; first += 64) {
+        const int at = first + lane;
+        const uint32_t ref = at < table_entries ? P.sky_table[at] : RZ_REF_NONE;
+        bool meets = false;
+        if (ref != RZ_REF_NONE) {
+            const float4 q3 = ((const float4*)ref_record(ref, tri_table, fan_table))[3];
+            meets = box_overlaps(make_uint2(__float_as_uint(q3.z), __float_as_uint(q3.w)), bin_x0, bin_y0, bin_x0 + RZ_BIN - 1, bin_y0 + RZ_BIN - 1);
         }
-        SkyBin *rec = sky_base + P.bin_off + blockIdx.x;
-        if (lane < 32) rec->entries_of_region[lane] = (uint8_t)mine;
-        if (lane == 32) rec->count = sky ? range.y : 0u;
-        if (lane == 33) rec->first = range.x;
-        if (lane == 34) rec->draw = draw;
+        const unsigned long long these = __ballot(meets);
+        const uint32_t place = count + __builtin_amdgcn_mbcnt_hi((uint32_t)(these >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)these, 0u));
+        if (meets && place < RZ_SKY_BIN_MAX) s_sel[place] = ref;
+        count += (uint32_t)__popcll(these);
     }
-    if (lane == 0) *bin_class = (range.y == 0u || sky) ? (uint32_t)RZ_BIN_DONE : (uint32_t)RZ_BIN_STRIP;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    const bool overflow = count > RZ_SKY_BIN_MAX;
+    /* ... and which of them can touch which of the bin's 32 regions (lane = region) */
+    const int rx0 = bin_x0 + RZ_TILE_W * (lane & 1), ry0 = bin_y0 + 4 * ((lane >> 1) & 15);
+    uint32_t mine = 0;
+    if (!overflow)
+        for (uint32_t e = 0; e < count; e++) {
+            const float4 *q = (const float4*)ref_record(s_sel[e], tri_table, fan_table);
+            const float4 c0 = q[0], c1 = q[1], q3 = q[3];
+            const bool hit = box_overlaps(make_uint2(__float_as_uint(q3.z), __float_as_uint(q3.w)), rx0, ry0, rx0 + RZ_TILE_W - 1, ry0 + 3) &&
+                             !block_outside(c0, c1, (float)rx0 + 0.5f, (float)(rx0 + RZ_TILE_W - 1) + 0.5f, (float)ry0 + 0.5f, (float)ry0 + 3.5f);
+            mine |= (hit ? 1u : 0u) << e;
+        }
+    SkyBin *rec = sky_base + P.bin_off + blockIdx.x;
+    if (lane < 32) rec->entries_of_region[lane] = (uint8_t)mine;
+    if (lane >= 32 && lane < 32 + (int)RZ_SKY_BIN_MAX) rec->ref[lane - 32] = (uint32_t)(lane - 32) < count ? s_sel[lane - 32] : RZ_REF_NONE;
+    if (lane == 40) rec->count = overflow ? RZ_SKY_BIN_OVERFLOW : count;
+    if (lane == 41) rec->fresh = range.y == 0u ? 1u : 0u;
 }
 
-/* What a wave of rz_strip_kernel does with a finished block of 16x8 pixels: depth, the clear colour where no fragment is, and -- for blocks that hold blinn or pbr
- * fragments, or when a kernel that looks at every pixel's reference follows -- the references. */
+/* What a wave of rz_strip_kernel does with a finished block of 16x8 pixels: depth, the clear colour where no
+ * fragment is, and -- for blocks that hold fragments -- the references. */
 #define RZ_BLOCK_ITEM(pass, by, bx) (((uint32_t)(pass) << 21) | ((uint32_t)(by) << 10) | (uint32_t)(bx))
 RZ_DEV void finish_block(const PassParams &P, uint32_t pass_index, int bx0, int by0, int lane,
                          const bool valid[2], const uint32_t pixel[2], const float zcur[2], const uint32_t ref_of[2]) {
@@ -1737,15 +1755,12 @@ RZ_DEV void finish_block(const PassParams &P, uint32_t pass_index, int bx0, int 
     bool listed = false;
     for (int q = 0; q < PPL; q++) {
         if (valid[q] && (ref_of[q] != RZ_REF_NONE || P.clear_depth_pending)) P.depth[pixel[q]] = zcur[q];  /* else: what was there */
-        listed |= ((ref_of[q] >> 28) & 3u) < 2u;                /* RZ_REF_NONE reads as family 3 */
+        listed |= ((ref_of[q] >> 28) & 3u) < 3u;                /* RZ_REF_NONE reads as family 3 */
         /* a pixel without a fragment shows the clear colour */
         if (valid[q] && P.clear_color_pending && ref_of[q] == RZ_REF_NONE) P.color[pixel[q]] = P.clear_color;
     }
-    /* the skybox's fragments are left to rz_sky_kernel, which looks at the references of every pixel */
-    if (P.ref_scanned && !__any(listed))
-        for (int q = 0; q < PPL; q++) if (valid[q]) P.ref[pixel[q]] = ref_of[q];
     if (__any(listed)) {
-        /* the block holds blinn or pbr fragments: its references are written -- all of them, the
+        /* the block holds fragments to shade: its references are written -- all of them, a
          * family's shade kernel looks at every pixel of a listed block -- and the block goes on the
          * work list of each family it holds (parts chosen by the block's index in its pass: a part
          * gets at most its even share of every pass, rounded up) */
@@ -1755,12 +1770,12 @@ RZ_DEV void finish_block(const PassParams &P, uint32_t pass_index, int bx0, int 
          * XCD's share of the shade kernel's workgroups (workgroup b runs on XCD b mod 8 and takes parts 2b and
          * 2b + 1 mod 64), in every pass of the batch -- the views of a batch fetch much the same texels for it */
         const uint32_t index = block_y * 2u * (uint32_t)P.tiles_x + block_x;
-        for (uint32_t f = 0; f < 2; f++) {
+        for (uint32_t f = 0; f < 3; f++) {
             bool mine_f = false;
             for (int q = 0; q < PPL; q++) mine_f |= ((ref_of[q] >> 28) & 3u) == f;
             if (!__any(mine_f)) continue;
             if (lane == 0) {
-                const uint32_t part = f * RZ_QUEUE_WAYS + (index & (RZ_QUEUE_WAYS - 1u));
+                const uint32_t part = (f == 2u ? RZ_SKY_LIST : f) * RZ_QUEUE_WAYS + (index & (RZ_QUEUE_WAYS - 1u));
                 const uint32_t at = atomicAdd(&P.queue_counts[part * RZ_QUEUE_PAD], 1u);
                 if (at < P.queue_capacity)
                     P.queue[(size_t)part * P.queue_capacity + at] = RZ_BLOCK_ITEM(pass_index, block_y, block_x);
@@ -2081,19 +2096,21 @@ RZ_DEV void shade_pixel(const PassParams &P, const TriRec *__restrict__ tri_base
     if (want) P.color[pixel] = ccur;
 }
 
-/* The skybox family, over every tile of every pass (grid x, y = tile, z = pass), PPL pixels per lane: a wave takes 2 * PPL rows of the tile
- * (lane = the pixel at (lane & 31, lane >> 5) of its rows and those 2, 4, .. rows below), so the
- * per-wave work -- the pass's parameters, the triangle's record and varyings, the draw's face
- * descriptors, all through scalar loads when one sky triangle spans the wave -- is paid once per
- * 64 * PPL pixels. */
+/* The sky boxes on the passes' tables, over every tile of every pass (grid x, y = tile, z = pass), two pixels
+ * per lane: a wave takes a region of 32x4 pixels (lane = the pixel at (lane & 31, lane >> 5) of its rows and
+ * the one two rows below), so the per-wave work -- the pass's parameters, the bin's record, a triangle's record
+ * and varyings, the draw's face descriptors, all through scalar loads -- is paid once per 128 pixels.
+ * Visibility among the table's triangles as in rz_strip_kernel (graphics.c:512-532), in table order, starting from
+ * the depth the pass's other triangles left -- or, in a bin whose list is empty, from the pending clear, which
+ * this kernel then carries out for the pixels no sky triangle covers. */
 template <int PPL>
 __global__ void __launch_bounds__(256 / PPL) rz_sky_kernel(const PassParams *__restrict__ passes,
         const TriRec *__restrict__ tri_base, const TriRec *__restrict__ fan_base,
         const float *__restrict__ vary_base, const float *__restrict__ fan_vary_base,
-        const char *__restrict__ upload_base, const uint32_t *__restrict__ ref_base,
-        const BinEntry *__restrict__ list_base, const SkyBin *__restrict__ sky_base) {
+        const char *__restrict__ upload_base, const SkyBin *__restrict__ sky_base) {
+    static_assert(PPL == 2, "a wave's region is 32x4 pixels");
     const PassParams P = passes[blockIdx.z];
-    if ((int)blockIdx.x >= P.tiles_x || (int)blockIdx.y >= P.tiles_y) return;
+    if ((int)blockIdx.x >= P.tiles_x || (int)blockIdx.y >= P.tiles_y || P.sky_draws == 0) return;
     const uint32_t failed = P.control[2];             /* looked at below, in the same round trip as the bin's record */
     const int lane = threadIdx.x & 63, wave = (int)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const TriRec *tri_table = tri_base + P.tri_off;
@@ -2101,209 +2118,136 @@ __global__ void __launch_bounds__(256 / PPL) rz_sky_kernel(const PassParams *__r
     const float *vary_table = vary_base + (size_t)P.tri_off * 3 * RZ_VARY_STRIDE;
     const float *fan_vary_table = fan_vary_base + (size_t)P.fan_off * RZ_MAX_POLY * RZ_VARY_STRIDE;
     const DrawRec *draw_table = (const DrawRec*)(upload_base + P.draws_off);
-    const uint32_t *ref_table = ref_base + P.ref_off;
     const int tx0 = (int)blockIdx.x * RZ_TILE_W, ry0 = (int)blockIdx.y * RZ_TILE_H + wave * 2 * PPL;
     const int px = tx0 + (lane & 31);
     int py[PPL];
-    uint32_t pixel[PPL], myref[PPL];
-    bool want[PPL];
-    bool any_want = false;
+    uint32_t pixel[PPL];
     for (int q = 0; q < PPL; q++) {
         py[q] = ry0 + 2 * q + (lane >> 5);
         pixel[q] = (uint32_t)py[q] * (uint32_t)P.width + (uint32_t)px;
     }
-    static_assert(PPL == 2, "a wave's region is 32x4 pixels");
     const uint32_t region = sky_region_of(tx0, ry0);
-    uint32_t sky_count = 0, sky_first = 0, sky_draw = 0, sky_word = 0;
-    if (sky_base) {
-        const SkyBin &bin = sky_base[P.bin_off + (uint32_t)((ry0 / RZ_BIN) * P.bins_x + tx0 / RZ_BIN)];
-        sky_count = bin.count; sky_first = bin.first; sky_draw = bin.draw;
-        sky_word = ((const uint32_t*)bin.entries_of_region)[region >> 2];
-    }
-    if (failed != 0u) return;                         /* the pass did not run: its reference plane holds nothing */
-    {
-        if (sky_count != 0u) {
-            /* visibility as in rz_strip_kernel (graphics.c:512-532), every entry through scalar loads */
-            const uint32_t entries = (sky_word >> ((region & 3u) * 8u)) & 0xffu;
-            const BinEntry *list = list_base + P.list_off + sky_first;
-            const DrawRec &D = draw_table[sky_draw];
-            bool valid[PPL];
-            float zcur[PPL], w[PPL][3];
-            int win[PPL];
-            for (int q = 0; q < PPL; q++) {
-                valid[q] = px < P.width && py[q] < P.height;
-                zcur[q] = P.clear_depth;
-                if (valid[q] && !P.clear_depth_pending) zcur[q] = P.depth[pixel[q]];
-                win[q] = -1;
-                w[q][0] = w[q][1] = w[q][2] = 0;
-            }
-            TriRec m;                                       /* the entry taken last, and its reference */
-            uint32_t m_ref = 0;
-            int m_at = -1;
-            for (uint32_t rest = entries; rest; rest &= rest - 1u) {
-                const int e = __ffs((int)rest) - 1;
-                m = list[e].rec;
-                m_ref = list[e].tri;
-                m_at = e;
-                const int x0 = (int)(m.bx & 0xffffu), x1 = (int)(m.bx >> 16);
-                const int y0 = (int)(m.by & 0xffffu), y1 = (int)(m.by >> 16);
-                for (int q = 0; q < PPL; q++) {
-                    float w0, w1, w2;
-                    pixel_weights(m, px, py[q], w0, w1, w2);
-                    const bool inside = valid[q] && py[q] >= y0 && py[q] <= y1 && px >= x0 && px <= x1 &&
-                                        w0 > -RZ_EPS && w1 > -RZ_EPS && w2 > -RZ_EPS;                 /* :516-519 */
-                    const float depth = m.z[0] * w0 + m.z[1] * w1 + m.z[2] * w2;                  /* :403-408 */
-                    if (inside && depth <= zcur[q]) {                                             /* :523 */
-                        zcur[q] = depth; win[q] = e;
-                        w[q][0] = w0; w[q][1] = w1; w[q][2] = w2;
-                    }
-                }
-            }
-            uint32_t ccur[PPL];
-            {
-                /* The usual region: one entry can touch it and every pixel shows it.  Said once for the wave,
-                 * what follows needs no lane masks around its loads and stores (they were a quarter of the
-                 * kernel's scalar instructions, and the scalar unit was busy 73 % of the time). */
-                bool every = true;
-                for (int q = 0; q < PPL; q++) every = every && win[q] >= 0;
-                if ((entries & (entries - 1u)) == 0u && __all(every)) {
-                    const float *m0, *m1, *m2;
-                    ref_varyings(m_ref, vary_table, fan_vary_table, m0, m1, m2);
-                    uint32_t below[PPL], at[PPL];
-                    float v[PPL][4];
-                    for (int q = 0; q < PPL; q++) {
-                        P.depth[pixel[q]] = zcur[q];
-                        below[q] = P.clear_color;           /* only lends its alpha byte */
-                        if (!P.clear_color_pending) below[q] = P.color[pixel[q]];
-                        const float q0 = m.rw[0] * w[q][0], q1 = m.rw[1] * w[q][1], q2 = m.rw[2] * w[q][2];    /* graphics.c:426-429 */
-                        const float norm = 1 / (q0 + q1 + q2);
-                        interpolate_uniform3(m0, m1, m2, q0, q1, q2, norm, v[q]);
-                    }
-                    if (D.flags & RZ_DRAW_SKY_BYTES) {      /* both texels asked for before either is waited for */
-                        const uint32_t RZ_GLOBAL *bytes = D.maps[0].data.as<const uint32_t>();
-                        for (int q = 0; q < PPL; q++) at[q] = sky_bytes_index(D, v[q]);
-                        uint32_t word[PPL];
-                        for (int q = 0; q < PPL; q++) word[q] = bytes[at[q]];
-                        for (int q = 0; q < PPL; q++) P.color[pixel[q]] = (word[q] & 0x00ffffffu) | (below[q] & 0xff000000u);
-                    } else {
-                        for (int q = 0; q < PPL; q++) P.color[pixel[q]] = sky_fragment(D, v[q], below[q]);
-                    }
-                    return;
-                }
-            }
-            for (int q = 0; q < PPL; q++) {
-                want[q] = win[q] >= 0;
-                any_want |= want[q];
-                if (valid[q] && (want[q] || P.clear_depth_pending)) P.depth[pixel[q]] = zcur[q];       /* else: what was there */
-                if (valid[q] && P.clear_color_pending && !want[q]) P.color[pixel[q]] = P.clear_color;
-                /* the colour below only lends its alpha byte; under a pending clear it is the clear colour */
-                ccur[q] = P.clear_color;
-                if (want[q] && !P.clear_color_pending) ccur[q] = P.color[pixel[q]];
-            }
-            if (!__any(any_want)) return;
-            int mine = -1;
-            for (int q = PPL - 1; q >= 0; q--) if (want[q]) mine = win[q];
-            const int first = __builtin_amdgcn_readlane(mine, __ffsll((long long)__ballot(any_want)) - 1);
-            bool uniform = true;
-            for (int q = 0; q < PPL; q++) uniform = uniform && (!want[q] || win[q] == first);
-            if (__all(uniform)) {
-                if (first != m_at) { m = list[first].rec; m_ref = list[first].tri; }       /* usually the only entry of the region */
-                const float *m0, *m1, *m2;
-                ref_varyings(m_ref, vary_table, fan_vary_table, m0, m1, m2);
-                for (int q = 0; q < PPL; q++) {
-                    if (!want[q]) continue;
-                    float v[4];
-                    const float q0 = m.rw[0] * w[q][0], q1 = m.rw[1] * w[q][1], q2 = m.rw[2] * w[q][2];    /* graphics.c:426-429 */
-                    const float norm = 1 / (q0 + q1 + q2);
-                    interpolate_uniform3(m0, m1, m2, q0, q1, q2, norm, v);
-                    P.color[pixel[q]] = sky_fragment(D, v, ccur[q]);
-                }
-                return;
-            }
-            /* An edge or the diagonal of a sky box face crosses the region (one region in five): the lanes drew
-             * from two or three entries.  Each lane takes the reciprocal w and the corner varyings of ITS entry --
-             * entry by entry through scalar loads, kept by the lanes that drew from it -- and all are shaded
-             * together: per-lane gathers of records and varyings made the texture data path this kernel's bound. */
-            for (int q = 0; q < PPL; q++) {
-                if (!__any(want[q])) continue;
-                float rw[3] = {0, 0, 0}, c0[3] = {0, 0, 0}, c1[3] = {0, 0, 0}, c2[3] = {0, 0, 0};
-                for (uint32_t rest = entries; rest; rest &= rest - 1u) {
-                    const int e = __ffs((int)rest) - 1;
-                    const bool mine = want[q] && win[q] == e;
-                    if (!__any(mine)) continue;
-                    const BinEntry *entry = &list[e];
-                    const float r0 = entry->rec.rw[0], r1 = entry->rec.rw[1], r2 = entry->rec.rw[2];
-                    const float *e0, *e1, *e2;
-                    ref_varyings(entry->tri, vary_table, fan_vary_table, e0, e1, e2);
-                    const rz_float4 a = *(const rz_float4 RZ_CONSTANT*)e0, b = *(const rz_float4 RZ_CONSTANT*)e1, c = *(const rz_float4 RZ_CONSTANT*)e2;
-                    if (mine) {
-                        c0[0] = a.x; c0[1] = a.y; c0[2] = a.z;
-                        c1[0] = b.x; c1[1] = b.y; c1[2] = b.z;
-                        c2[0] = c.x; c2[1] = c.y; c2[2] = c.z;
-                    }
-                    if (mine) { rw[0] = r0; rw[1] = r1; rw[2] = r2; }
-                }
-                if (want[q]) {
-                    const float q0 = rw[0] * w[q][0], q1 = rw[1] * w[q][1], q2 = rw[2] * w[q][2];    /* graphics.c:426-429 */
-                    const float norm = 1 / (q0 + q1 + q2);
-                    float v[4];
-                    for (int i = 0; i < 3; i++) v[i] = (c0[i] * q0 + c1[i] * q1 + c2[i] * q2) * norm;   /* :431-434 */
-                    P.color[pixel[q]] = sky_fragment(D, v, ccur[q]);
-                }
-            }
-            return;
-        }
-    }
-    for (int q = 0; q < PPL; q++)
-        myref[q] = (px < P.width && py[q] < P.height) ? ref_table[pixel[q]] : RZ_REF_NONE;
+    const SkyBin &bin = sky_base[P.bin_off + (uint32_t)((ry0 / RZ_BIN) * P.bins_x + tx0 / RZ_BIN)];
+    const uint32_t sky_count = bin.count, fresh = bin.fresh;
+    const uint32_t sky_word = ((const uint32_t*)bin.entries_of_region)[region >> 2];
+    uint32_t refs[RZ_SKY_BIN_MAX];
+    for (uint32_t e = 0; e < RZ_SKY_BIN_MAX; e++) refs[e] = bin.ref[e];
+    if (failed != 0u) return;                         /* the pass did not run */
+    const bool overflow = sky_count == RZ_SKY_BIN_OVERFLOW;
+    const uint32_t entries = overflow ? 0u : (sky_word >> ((region & 3u) * 8u)) & 0xffu;
+    /* in a bin whose list is empty nothing has consumed the pass's clears; elsewhere rz_strip_kernel has */
+    const bool clear_depth = fresh && P.clear_depth_pending, clear_color = fresh && P.clear_color_pending;
+    if (!overflow && entries == 0u && !clear_depth && !clear_color) return;     /* uniform */
+    bool valid[PPL];
+    float zcur[PPL], w[PPL][3];
+    uint32_t win[PPL];                                /* what this pixel's sky fragment comes from (a table entry); RZ_REF_NONE: none */
     for (int q = 0; q < PPL; q++) {
-        want[q] = ((myref[q] >> 28) & 3u) == 2u;        /* RZ_REF_NONE reads as family 3 */
-        any_want |= want[q];
-        myref[q] &= ~RZ_REF_FAMILY_BITS;
+        valid[q] = px < P.width && py[q] < P.height;
+        zcur[q] = P.clear_depth;
+        if (valid[q] && !clear_depth) zcur[q] = P.depth[pixel[q]];
+        win[q] = RZ_REF_NONE;
+        w[q][0] = w[q][1] = w[q][2] = 0;
     }
-    if (!__any(any_want)) return;
-    /* the colour below only lends its alpha byte; under a pending clear it is the clear colour */
-    uint32_t ccur[PPL];
-    for (int q = 0; q < PPL; q++) {
-        ccur[q] = P.clear_color;
-        if (want[q] && !P.clear_color_pending) ccur[q] = P.color[pixel[q]];
-    }
-    uint32_t first = 0;
-    bool uniform = true;
-    {
-        uint32_t mine = RZ_REF_NONE;                    /* a reference this lane wants, if any */
-        for (int q = PPL - 1; q >= 0; q--) if (want[q]) mine = myref[q];
-        first = (uint32_t)__builtin_amdgcn_readlane((int)mine, __ffsll((long long)__ballot(any_want)) - 1);
-        for (int q = 0; q < PPL; q++) uniform = uniform && (!want[q] || myref[q] == first);
-    }
-    if (__all(uniform)) {
-        TriRec m;
-        const float *m0, *m1, *m2;
-        fetch_ref(first, tri_table, fan_table, vary_table, fan_vary_table, m, m0, m1, m2);
-        const DrawRec &D = draw_table[RZ_META_DRAW(m.meta)];
+    TriRec m;                                         /* the entry taken last */
+    uint32_t m_ref = RZ_REF_NONE;
+    auto consider = [&](uint32_t ref) {               /* uniform */
+        m_ref = ref;
+        m = load_tri(ref_record(ref, tri_table, fan_table));
+        const int x0 = (int)(m.bx & 0xffffu), x1 = (int)(m.bx >> 16);
+        const int y0 = (int)(m.by & 0xffffu), y1 = (int)(m.by >> 16);
         for (int q = 0; q < PPL; q++) {
-            if (!want[q]) continue;
-            float w0, w1, w2, v[4];
+            float w0, w1, w2;
             pixel_weights(m, px, py[q], w0, w1, w2);
-            const float q0 = m.rw[0] * w0, q1 = m.rw[1] * w1, q2 = m.rw[2] * w2;    /* graphics.c:426-429 */
-            const float norm = 1 / (q0 + q1 + q2);
-            interpolate_uniform3(m0, m1, m2, q0, q1, q2, norm, v);
-            P.color[pixel[q]] = sky_fragment(D, v, ccur[q]);                    /* no blending in these passes */
+            const bool inside = valid[q] && py[q] >= y0 && py[q] <= y1 && px >= x0 && px <= x1 &&
+                                w0 > -RZ_EPS && w1 > -RZ_EPS && w2 > -RZ_EPS;                 /* :516-519 */
+            const float depth = m.z[0] * w0 + m.z[1] * w1 + m.z[2] * w2;                  /* :403-408 */
+            if (inside && depth <= zcur[q]) {                                             /* :523 */
+                zcur[q] = depth; win[q] = ref;
+                w[q][0] = w0; w[q][1] = w1; w[q][2] = w2;
+            }
         }
-        if (P.counters) {       /* [8] fragments shaded on the device, [9] of those, skybox */
-            unsigned long long n = 0;
-            for (int q = 0; q < PPL; q++) n += (unsigned long long)__popcll(__ballot(want[q]));
-            if (lane == 0) { atomicAdd(P.counters + 8, n); atomicAdd(P.counters + 9, n); }
+    };
+    if (!overflow) {
+#pragma unroll
+        for (uint32_t e = 0; e < RZ_SKY_BIN_MAX; e++) if (entries >> e & 1u) consider(refs[e]);
+    } else {
+        /* more table entries meet the bin than its record holds: all of the table, entry by entry */
+        for (int at = 0; at < P.sky_draws * RZ_SKY_FACES * RZ_MAX_FAN; at++) {
+            const uint32_t ref = P.sky_table[at];
+            if (ref != RZ_REF_NONE) consider(ref);
+        }
+    }
+    /* what the colour buffer lends is its alpha byte only (graphics.c:466-468); under a pending clear that is the
+     * clear colour's, whoever carries the clear out */
+    uint32_t below[PPL];
+    for (int q = 0; q < PPL; q++) {
+        below[q] = P.clear_color;
+        if (valid[q] && !P.clear_color_pending) below[q] = P.color[pixel[q]];
+    }
+    bool every = true, any_want = false;
+    for (int q = 0; q < PPL; q++) { every = every && win[q] != RZ_REF_NONE; any_want |= win[q] != RZ_REF_NONE; }
+    if (!overflow && (entries & (entries - 1u)) == 0u && __all(every)) {
+        /* The usual region: one entry can touch it and every pixel shows it.  Said once for the wave, what follows
+         * needs no lane masks around its loads and stores (they were a quarter of the kernel's scalar instructions,
+         * and the scalar unit was busy 73 % of the time). */
+        const DrawRec &D = draw_table[RZ_META_DRAW(m.meta)];
+        const float *m0, *m1, *m2;
+        ref_varyings(m_ref, vary_table, fan_vary_table, m0, m1, m2);
+        uint32_t at[PPL];
+        float v[PPL][4];
+        for (int q = 0; q < PPL; q++) {
+            P.depth[pixel[q]] = zcur[q];
+            if (!fresh) P.ref[pixel[q]] = RZ_REF_NONE;          /* a fragment of the pass's other triangles may have been here */
+            const float q0 = m.rw[0] * w[q][0], q1 = m.rw[1] * w[q][1], q2 = m.rw[2] * w[q][2];    /* graphics.c:426-429 */
+            const float norm = 1 / (q0 + q1 + q2);
+            interpolate_uniform3(m0, m1, m2, q0, q1, q2, norm, v[q]);
+        }
+        if (D.flags & RZ_DRAW_SKY_BYTES) {      /* both texels asked for before either is waited for */
+            const uint32_t RZ_GLOBAL *bytes = D.maps[0].data.as<const uint32_t>();
+            for (int q = 0; q < PPL; q++) at[q] = sky_bytes_index(D, v[q]);
+            uint32_t word[PPL];
+            for (int q = 0; q < PPL; q++) word[q] = bytes[at[q]];
+            for (int q = 0; q < PPL; q++) P.color[pixel[q]] = (word[q] & 0x00ffffffu) | (below[q] & 0xff000000u);
+        } else {
+            for (int q = 0; q < PPL; q++) P.color[pixel[q]] = sky_fragment(D, v[q], below[q]);
         }
         return;
     }
-    for (int q = 0; q < PPL; q++) {                     /* an edge of the sky box crosses the wave */
+    bool want[PPL];
+    for (int q = 0; q < PPL; q++) {
+        want[q] = win[q] != RZ_REF_NONE;
+        if (valid[q] && (want[q] || clear_depth)) P.depth[pixel[q]] = zcur[q];         /* else: what was there */
+        if (valid[q] && clear_color && !want[q]) P.color[pixel[q]] = P.clear_color;
+        if (want[q] && !fresh) P.ref[pixel[q]] = RZ_REF_NONE;   /* a fragment of the pass's other triangles may have been here */
+    }
+    if (!__any(any_want)) return;
+    /* The lanes drew from one entry, or -- an edge or the diagonal of a sky box face crosses the region (one region in
+     * five) -- from two or three.  Each lane takes the reciprocal w and the corner varyings of ITS entry, entry by entry
+     * through scalar loads, kept by the lanes that drew from it (per-lane gathers of records and varyings made the
+     * texture data path this kernel's bound); the entry's draw shades its lanes. */
+    for (int q = 0; q < PPL; q++) {
         if (!__any(want[q])) continue;
-        TriRec m;
-        const float *m0 = vary_table, *m1 = vary_table, *m2 = vary_table;
-        if (want[q]) fetch_ref(myref[q], tri_table, fan_table, vary_table, fan_vary_table, m, m0, m1, m2);
-        shade_lanes<2>(P, draw_table, want[q], m, m0, m1, m2, px, py[q], ccur[q]);
-        if (want[q]) P.color[pixel[q]] = ccur[q];
+        unsigned long long rest = __ballot(want[q]);
+        while (rest) {
+            const uint32_t ref = (uint32_t)__builtin_amdgcn_readlane((int)win[q], __ffsll((long long)rest) - 1);
+            const bool mine = want[q] && win[q] == ref;
+            rest &= ~__ballot(mine);
+            const TriRec *rec = ref_record(ref, tri_table, fan_table);
+            const float r0 = rec->rw[0], r1 = rec->rw[1], r2 = rec->rw[2];
+            const DrawRec &D = draw_table[RZ_META_DRAW(rec->meta)];
+            const float *e0, *e1, *e2;
+            ref_varyings(ref, vary_table, fan_vary_table, e0, e1, e2);
+            const rz_float4 a = *(const rz_float4 RZ_CONSTANT*)e0, b = *(const rz_float4 RZ_CONSTANT*)e1, c = *(const rz_float4 RZ_CONSTANT*)e2;
+            if (mine) {
+                const float q0 = r0 * w[q][0], q1 = r1 * w[q][1], q2 = r2 * w[q][2];                /* graphics.c:426-429 */
+                const float norm = 1 / (q0 + q1 + q2);
+                float v[4];
+                v[0] = (a.x * q0 + b.x * q1 + c.x * q2) * norm;                                   /* :431-434 */
+                v[1] = (a.y * q0 + b.y * q1 + c.y * q2) * norm;
+                v[2] = (a.z * q0 + b.z * q1 + c.z * q2) * norm;
+                P.color[pixel[q]] = sky_fragment(D, v, below[q]);
+            }
+        }
     }
 }
 
@@ -2323,7 +2267,8 @@ __global__ void __launch_bounds__(256) rz_shade_list_kernel(const PassParams *__
      * blended fragments (passes cut up by rz_blend_visibility_kernel), which need the colour itself */
     typedef typename std::conditional<BLOCKS, LdsTablesBytes, LdsTables>::type Tables;
     /* lane q holds the length of part q of this family's list */
-    const uint32_t my_count = min(queue_counts[(FAMILY * RZ_QUEUE_WAYS + lane) * RZ_QUEUE_PAD], queue_capacity);
+    constexpr uint32_t LIST = FAMILY == 2 ? RZ_SKY_LIST : (uint32_t)FAMILY;     /* (skybox fragments that came through the bins) */
+    const uint32_t my_count = min(queue_counts[(LIST * RZ_QUEUE_WAYS + lane) * RZ_QUEUE_PAD], queue_capacity);
     uint32_t longest = my_count;
     longest = (uint32_t)wave_max_i((int)longest);
     constexpr uint32_t per_turn = BLOCKS ? 2u : 1u;
@@ -2333,7 +2278,7 @@ __global__ void __launch_bounds__(256) rz_shade_list_kernel(const PassParams *__
     for (uint32_t k = blockIdx.x * per_turn + half; k < longest * RZ_QUEUE_WAYS; k += gridDim.x * per_turn) {
         const uint32_t part = k & (RZ_QUEUE_WAYS - 1u), index = k / RZ_QUEUE_WAYS;
         if (index >= (uint32_t)__builtin_amdgcn_readlane((int)my_count, (int)part)) continue;
-        const uint32_t item = queue_base[(size_t)(FAMILY * RZ_QUEUE_WAYS + part) * queue_capacity + index];
+        const uint32_t item = queue_base[(size_t)(LIST * RZ_QUEUE_WAYS + part) * queue_capacity + index];
         if constexpr (BLOCKS) {
             const PassParams P = passes[item >> 21];
             const int t = (int)(threadIdx.x & 127u);

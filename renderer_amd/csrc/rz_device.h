@@ -56,7 +56,14 @@ enum { RZ_PV_WORLD = 0, RZ_PV_NORMAL = 3, RZ_PV_TANGENT = 6, RZ_PV_BITANGENT = 9
                                      * where a blended fragment lies over another fragment of the pass */
 #define RZ_QUEUE_PAD 32u            /* counters sit one 128-byte line apart: atomics on one line serialise */
 #define RZ_VISIBILITY_LIST 3u       /* the fourth: tiles of such a pass that rz_blend_visibility_kernel has to look at */
-#define RZ_LISTS 4u
+#define RZ_SKY_LIST 4u              /* the fifth: blocks with skybox fragments that came through the bins (a sky box that is not on the
+                                     * pass's table: more than 12 triangles, not drawn last, fragments being counted) */
+#define RZ_LISTS 5u
+/* the table of a pass's sky boxes: up to RZ_SKY_DRAWS draws of up to RZ_SKY_FACES triangles, RZ_MAX_FAN entries each -- the
+ * triangle's index, RZ_REF_FAN | its fan records', or RZ_REF_NONE --, in submission order */
+#define RZ_SKY_DRAWS 4
+#define RZ_SKY_FACES 12
+#define RZ_SKY_TABLE (RZ_SKY_DRAWS * RZ_SKY_FACES * RZ_MAX_FAN)
 #define RZ_TILE_W 32                /* raster / shade workgroup tile: 4 waves of 8x8 side by side, */
 #define RZ_TILE_H 8                 /* so a tile row is one 128-byte line of a 4-byte plane */
 
@@ -134,7 +141,9 @@ struct DrawRec {
     int32_t workflow;               /* 0 metal-rough, 1 spec-gloss */
     float alpha_cutoff;
     int32_t layer_view;
-    int32_t pad;
+    /* a sky box drawn last in its pass (at most 12 triangles, no blending): slot + 1 of its triangles in the pass's
+     * table of sky triangles -- they are kept out of the bins --; 0: an ordinary draw */
+    int32_t sky_slot;
 };
 
 /* One rasterisable triangle: what rasterize_triangle (graphics.c:472-535)
@@ -196,7 +205,7 @@ struct PassParams {
     rz_gptr<uint2> bin_boxes;               /* per list entry: x0 | x1 << 16, y0 | y1 << 16 | alpha-cutoff << 31 -- all that walking a list reads */
     uint32_t bin_capacity;
     rz_gptr<uint32_t> ref;                  /* per pixel: reference of the visible fragment (split passes) */
-    int32_t ref_scanned;            /* a shade kernel of the batch reads the references of every tile (the skybox's) */
+    int32_t sky_draws;              /* draws of this pass whose triangles are on its table of sky triangles */
     /* scalars written by the device: [0] fan blocks used, [1] bin entries
      * used, [2] error bits, [3] triangles queued for clipping */
     rz_gptr<uint32_t> control;
@@ -235,6 +244,7 @@ struct PassParams {
     /* a pass with blended draws: the list (RZ_ORDERED_LIST or RZ_VISIBILITY_LIST) rz_bin_scan_kernel puts the tiles of
      * its bins on that are not empty -- the kernel behind it then starts no wave for the rest of the frame; -1: none */
     int32_t scan_list;
+    rz_gptr<uint32_t> sky_table;            /* RZ_SKY_TABLE entries (above); filled by the vertex and clip kernels */
 };
 
 enum { RZ_ERR_FAN_OVERFLOW = 1, RZ_ERR_BIN_OVERFLOW = 2, RZ_ERR_QUEUE_OVERFLOW = 4, RZ_ERR_SKIPPED = 8 };

@@ -112,11 +112,22 @@ def test_gpu_bins_match_cpu_binning_oracle(gpu, oracle, name, size, eye):
         results.append(pipe.geometry(scene, size[0], size[1], view))
         pipe.close_scene(scene)
     got, want = results
-    assert got["info"] == want["info"]
     assert np.array_equal(got["fans"], want["fans"])
     assert np.array_equal(got["boxes"], want["boxes"])
+    # a sky box drawn last in its pass is kept out of the library's bins (its triangles go on a table of their own):
+    # the lists must be the oracle's without those triangles' entries
+    sky_first = gpu.lib.mi355r_inspect_sky_first()
+    assert want["info"]["num_tris"] - sky_first in ((0, 12) if name == "helmet" else (0,))      # one box of 12 triangles
+    kept = want["entries"][:, 0] < sky_first
+    edge = want["info"]["bin_edge"]
+    if not kept.all():
+        counts, entries = brute_force_bins(want["boxes"][:sky_first], want["fans"][:sky_first], size[0], size[1], edge)
+        assert np.array_equal(entries, want["entries"][kept])
+        want = dict(want, counts=counts, entries=entries, info=dict(want["info"], bin_entries=len(entries)))
+    assert got["info"] == want["info"]
     assert np.array_equal(got["counts"], want["counts"])
     assert np.array_equal(got["entries"], want["entries"])
+    want = results[1]
     # and the oracle's lists are what brute force gives for these boxes
     bc, be = brute_force_bins(want["boxes"], want["fans"], size[0], size[1], want["info"]["bin_edge"])
     assert np.array_equal(want["counts"], bc) and np.array_equal(want["entries"], be)

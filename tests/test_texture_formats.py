@@ -140,7 +140,7 @@ sys.exit(0 if bad == 0 else 1)
 @pytest.mark.gpu
 @pytest.mark.parametrize("env", [{"MI355R_PACK": "0"}, {"MI355R_LANES": "1", "MI355R_BATCH": "1"},
                                  {"MI355R_MICRO_AREA": "0"}, {"MI355R_MICRO_MIN_LIST": "0"}, {"MI355R_RECORD_COPIES": "0"},
-                                 {"MI355R_STRIP": "4"}, {"MI355R_SKY_BINS": "0"}, {"MI355R_SKY_BYTES": "0"}, {"MI355R_STRIP": "2"},
+                                 {"MI355R_STRIP": "4"}, {"MI355R_SKY_TABLE": "0"}, {"MI355R_FILL_WAVES": "4"}, {"MI355R_SKY_BYTES": "0"}, {"MI355R_STRIP": "2"},
                                  {"MI355R_STRIP_LONG": "1"}, {"MI355R_STRIP_LONG": "600"}, {"MI355R_STRIP": "1", "MI355R_MICRO_MIN_LIST": "0"},
                                  {"MI355R_SPLIT_BLEND": "0"}, {"MI355R_SPLIT_BLEND": "1"},
                                  {"MI355R_MICRO_MIN_LIST": "0", "MI355R_MICRO_AREA": "128"}],
@@ -151,8 +151,8 @@ def test_gpu_alternative_code_paths_give_the_same_frames(gpu, env):
     variables read when it starts): float4 images only, no batching, the one-triangle-per-lane
     rasteriser for no triangle / in every bin / for every triangle a block can hold, a flush
     in front of every framebuffer -> texture copy, strips of a fixed height, strips whose height
-    follows the framebuffer's last frame from a list length every scene / only azura reaches, sky-only
-    bins through the general path, and visibility-first blending on and off."""
+    follows the framebuffer's last frame from a list length every scene / only azura reaches, sky boxes
+    through the bins like any other draw, and visibility-first blending on and off."""
     r = subprocess.run([sys.executable, "-c", VARIANT_SCRIPT % (REPO, os.path.join(REPO, "tests"))],
                        env=dict(os.environ, **env), capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "DIFFS 0" in r.stdout, r.stdout + r.stderr
