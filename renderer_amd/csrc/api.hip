@@ -192,7 +192,7 @@ struct Context {
     bool pack_textures = true;              /* MI355R_PACK=0: keep every image as float4 */
     int micro_min_list = 256;               /* MI355R_MICRO_MIN_LIST: small triangles are rasterised one per lane only in bins with at least this many list entries */
     bool sky_table = true;                  /* MI355R_SKY_TABLE=0: a sky box goes through the bins like any other draw */
-    int fill_waves = 1;                     /* MI355R_FILL_WAVES: waves that share a chunk of 64 triangles in rz_bin_fill_kernel (1, 2, 4) */
+    int fill_waves = 0;                     /* MI355R_FILL_WAVES: waves that share a chunk of 64 triangles in rz_bin_fill_kernel (1, 2, 4; unset: by the launch's size) */
     unsigned strip_long = 2048;             /* MI355R_STRIP_LONG: a batch whose framebuffers had a bin list of this many entries in their last frame takes one block per wave,
                                              * of half as many two; 0, or MI355R_STRIP set = always `strip` */
     int strip = 4;                          /* MI355R_STRIP: 16x8 blocks a wave of rz_strip_kernel takes (8, 4, 2, 1) */
@@ -2008,9 +2008,12 @@ static void launch_batch(const Batch &b, const std::vector<PassPlan> &plans, cha
     rz_bin_count_kernel<<<tgrid, dim3(256), 0, st>>>(passes);
     rz_bin_scan_kernel<<<dim3((unsigned)((max_bins + 63) / 64), n), dim3(64 * RZ_SCAN_SEGMENTS), 0, st>>>(passes);
     {
+        /* a chunk whose triangles lie far apart walks its bins in rounds of 64: with few chunks in the launch (a frame
+         * or two) the rounds are shared out over four waves, with many one wave per chunk keeps more chunks in flight */
         const dim3 grid((unsigned)((max_T + 63) / 64 * n));
-        if (g.fill_waves == 1) rz_bin_fill_kernel<1><<<grid, dim3(64), 0, st>>>(passes, n);
-        else if (g.fill_waves == 2) rz_bin_fill_kernel<2><<<grid, dim3(128), 0, st>>>(passes, n);
+        const int waves = g.fill_waves ? g.fill_waves : grid.x < 4096u ? 4 : 1;
+        if (waves == 1) rz_bin_fill_kernel<1><<<grid, dim3(64), 0, st>>>(passes, n);
+        else if (waves == 2) rz_bin_fill_kernel<2><<<grid, dim3(128), 0, st>>>(passes, n);
         else rz_bin_fill_kernel<4><<<grid, dim3(256), 0, st>>>(passes, n);
     }
     stamp();

@@ -472,6 +472,9 @@ RZ_DEV void store_tri(TriRec *dst, const TriRec &r) {
     o[3] = make_float4(r.rw[2], __uint_as_float(r.meta), __uint_as_float(r.bx), __uint_as_float(r.by));
 }
 
+#define RZ_BCAST_F(v, j) __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), (j)))
+#define RZ_BCAST_I(v, j) __builtin_amdgcn_readlane((int)(v), (j))
+
 /* K2b  clipping, one WAVE per queued triangle.  Lane c carries one float
  * "channel" of every polygon corner through the seven Sutherland-Hodgman
  * passes: channels 0-3 are the clip-space position, 4.. the varyings.  Inside
@@ -507,19 +510,33 @@ __global__ void __launch_bounds__(64) rz_clip_kernel(const PassParams *__restric
         int n = 3, cur = 0;
         for (int plane = PLANE_W; plane <= PLANE_NZ && n >= 3; plane++) {
             const int dst = cur ^ 1;
+            /* every lane's own channel of all corners, and in lane e the edge that ends in corner e (positions of
+             * corners e - 1 and e, which side of the plane they lie on, the crossing's ratio): one trip to LDS and one
+             * division per plane, where walking the edges one after the other made a trip and a division per edge */
+            float vals[RZ_MAX_POLY];
+#pragma unroll
+            for (int i = 0; i < RZ_MAX_POLY; i++) vals[i] = i < n ? poly[cur][i][lane & 31] : 0.0f;
+            const int e = lane < n ? lane : 0, j = (e - 1 + n) % n;
+            const float4 pa = *(const float4*)&poly[cur][j][0], pb = *(const float4*)&poly[cur][e][0];
+            const f4 a = mk4(pa.x, pa.y, pa.z, pa.w), b = mk4(pb.x, pb.y, pb.z, pb.w);
+            const bool a_in = plane_inside(a, plane), b_in = plane_inside(b, plane);
+            float r = 0;
+            if (a_in != b_in) r = plane_crossing(a, b, plane);
+            const uint32_t cross = (uint32_t)__ballot(lane < n && a_in != b_in), inside = (uint32_t)__ballot(lane < n && b_in);
+            float last = vals[0];
+#pragma unroll
+            for (int i = 1; i < RZ_MAX_POLY; i++) if (i == n - 1) last = vals[i];
             int out = 0;
-            for (int i = 0; i < n; i++) {
-                const int j = (i - 1 + n) % n;
-                f4 a = mk4(poly[cur][j][0], poly[cur][j][1], poly[cur][j][2], poly[cur][j][3]);
-                f4 b = mk4(poly[cur][i][0], poly[cur][i][1], poly[cur][i][2], poly[cur][i][3]);
-                bool a_in = plane_inside(a, plane), b_in = plane_inside(b, plane);
-                if (a_in != b_in && out < RZ_MAX_POLY) {
-                    float r = plane_crossing(a, b, plane);
-                    if (lane < 32) poly[dst][out][lane] = d_mix(poly[cur][j][lane & 31], poly[cur][i][lane & 31], r);
+#pragma unroll
+            for (int i = 0; i < RZ_MAX_POLY; i++) {
+                if (i >= n) break;                                  /* uniform, as every branch of this loop */
+                if (((cross >> i) & 1u) && out < RZ_MAX_POLY) {
+                    const float ratio = RZ_BCAST_F(r, i);
+                    if (lane < 32) poly[dst][out][lane] = d_mix(i == 0 ? last : vals[i > 0 ? i - 1 : 0], vals[i], ratio);
                     out++;
                 }
-                if (b_in && out < RZ_MAX_POLY) {
-                    if (lane < 32) poly[dst][out][lane] = poly[cur][i][lane & 31];
+                if (((inside >> i) & 1u) && out < RZ_MAX_POLY) {
+                    if (lane < 32) poly[dst][out][lane] = vals[i];
                     out++;
                 }
             }
@@ -625,8 +642,6 @@ RZ_DEV BinRect bin_rect_of(uint2 bb) {
     return r;
 }
 
-#define RZ_BCAST_F(v, j) __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), (j)))
-#define RZ_BCAST_I(v, j) __builtin_amdgcn_readlane((int)(v), (j))
 
 /* Cross-lane steps of scans and reductions go through the VALU's data-parallel primitives (DPP): the
  * operand comes from a neighbouring lane's register inside the instruction itself, where __shfl makes a
@@ -806,6 +821,32 @@ RZ_DEV uint2 entry_box(float4 q3) {
     return make_uint2(__float_as_uint(q3.z), __float_as_uint(q3.w) | (RZ_META_CUTOFF(__float_as_uint(q3.y)) << 31));
 }
 
+/* a triangle's entries (one, or its fan's) into a bin's list from position `at` on; fan records come from the
+ * chunk's staging area in LDS when they fitted there */
+RZ_DEV void fill_entries(const PassParams &P, uint32_t at, uint32_t ref, uint32_t entries, float4 r0, float4 r1, float4 r2, float4 r3,
+                         uint32_t slot, const float4 (*s_fan)[4], const TriRec *__restrict__ fan_tri) {
+    if (!(ref & RZ_REF_FAN)) {
+        float4 *dst = (float4*)&P.bin_list[at];
+        dst[0] = make_float4(__uint_as_float(ref), 0.0f, 0.0f, 0.0f);
+        dst[1] = r0; dst[2] = r1; dst[3] = r2; dst[4] = r3;
+        P.bin_boxes[at] = entry_box(r3);
+        return;
+    }
+    for (uint32_t k = 0; k < entries; k++) {
+        float4 q0, q1, q2, q3;
+        if (slot != 0xffffffffu) {
+            q0 = s_fan[slot + k][0]; q1 = s_fan[slot + k][1]; q2 = s_fan[slot + k][2]; q3 = s_fan[slot + k][3];
+        } else {
+            const float4 *src = (const float4*)&fan_tri[(ref & ~RZ_REF_FAN) + k];
+            q0 = src[0]; q1 = src[1]; q2 = src[2]; q3 = src[3];
+        }
+        float4 *dst = (float4*)&P.bin_list[at + k];
+        dst[0] = make_float4(__uint_as_float(ref + k), 0.0f, 0.0f, 0.0f);
+        dst[1] = q0; dst[2] = q1; dst[3] = q2; dst[4] = q3;
+        P.bin_boxes[at + k] = entry_box(q3);
+    }
+}
+
 /* One workgroup of WAVES waves per chunk.  Lanes first hold the
  * chunk's 64 triangles (box, record), then turn into BINS: the chunk's joint
  * bin rectangle is cut into rounds of 64 bins, wave w takes rounds w,
@@ -894,26 +935,51 @@ __global__ void __launch_bounds__(64 * WAVES) rz_bin_fill_kernel(const PassParam
                 uint32_t total;
                 before = wave_exclusive_scan(touch ? r.entries : 0u, &total);
             }
-            if (!touch) continue;
-            if (!(ref & RZ_REF_FAN)) {
-                float4 *dst = (float4*)&P.bin_list[start + before];
-                dst[0] = make_float4(__uint_as_float(ref), 0.0f, 0.0f, 0.0f);
-                dst[1] = r0; dst[2] = r1; dst[3] = r2; dst[4] = r3;
-                P.bin_boxes[start + before] = entry_box(r3);
+            if (touch) fill_entries(P, start + before, ref, r.entries, r0, r1, r2, r3, slot, s_fan, fan_tri);
+        }
+        return;
+    }
+
+    const int w = r.bx1 - r.bx0 + 1, h = r.by1 - r.by0 + 1;
+    if (__ballot(r.entries != 0 && (w > 3 || h > 3)) == 0ull) {
+        /* Small triangles that lie far apart (consecutive triangles of different parts of a mesh): the joint rectangle
+         * is large and nearly empty.  Lanes stay triangles; each walks the (at most 3 x 3) bins of its own box in
+         * ascending bin index, the wave takes the lowest bin any lane is at, the lanes at that bin find their places
+         * with a prefix over the lanes as above and move on.  One turn per DISTINCT bin the chunk touches, where the
+         * rounds below make 64 turns per 64 bins of the rectangle.  The starts of a lane's bins are asked for up front,
+         * in one memory round trip. */
+        if (wave != 0) return;
+        uint32_t start[9];
+#pragma unroll
+        for (int q = 0; q < 9; q++) {
+            const bool in_box = r.entries != 0 && q % 3 < w && q / 3 < h;
+            const int b = in_box ? (r.by0 + q / 3) * P.bins_x + r.bx0 + q % 3 : 0;     /* (every lane loads: nothing waits on a branch) */
+            const uint32_t first = row[b], kept = P.bin_range[b].y;
+            start[q] = in_box && kept != 0u ? first : 0xffffffffu;      /* not mine, or a list that is not kept (empty or overflowed) */
+        }
+        int px = 0, py = 0;
+        bool more = r.entries != 0;
+        for (;;) {
+            const int mine = more ? (r.by0 + py) * P.bins_x + r.bx0 + px : 0x7fffffff;
+            const int b = wave_min_i(mine);
+            if (b == 0x7fffffff) break;
+            const bool touch = mine == b;
+            const unsigned long long touching = __ballot(touch);
+            uint32_t before;
+            if (__ballot(touch && r.entries != 1u) == 0) {
+                before = __builtin_amdgcn_mbcnt_hi((uint32_t)(touching >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)touching, 0u));
             } else {
-                for (uint32_t k = 0; k < r.entries; k++) {
-                    float4 q0, q1, q2, q3;
-                    if (slot != 0xffffffffu) {
-                        q0 = s_fan[slot + k][0]; q1 = s_fan[slot + k][1]; q2 = s_fan[slot + k][2]; q3 = s_fan[slot + k][3];
-                    } else {
-                        const float4 *src = (const float4*)&fan_tri[(ref & ~RZ_REF_FAN) + k];
-                        q0 = src[0]; q1 = src[1]; q2 = src[2]; q3 = src[3];
-                    }
-                    float4 *dst = (float4*)&P.bin_list[start + before + k];
-                    dst[0] = make_float4(__uint_as_float(ref + k), 0.0f, 0.0f, 0.0f);
-                    dst[1] = q0; dst[2] = q1; dst[3] = q2; dst[4] = q3;
-                    P.bin_boxes[start + before + k] = entry_box(q3);
-                }
+                uint32_t total;
+                before = wave_exclusive_scan(touch ? r.entries : 0u, &total);
+            }
+            if (touch) {
+                const int at_slot = py * 3 + px;
+                uint32_t at = start[0];
+#pragma unroll
+                for (int q = 1; q < 9; q++) if (at_slot == q) at = start[q];
+                if (at != 0xffffffffu) fill_entries(P, at + before, ref, r.entries, r0, r1, r2, r3, slot, s_fan, fan_tri);
+                if (++px == w) { px = 0; py++; }
+                more = py < h;
             }
         }
         return;
