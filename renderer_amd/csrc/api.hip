@@ -1677,7 +1677,9 @@ static void plan_pass(PassPlan &pl, size_t &total) {
             pl.sky_first--;
             pl.sky_draws++;
         }
-    for (size_t i = pl.first; i < pl.sky_first; i++) pl.families |= 1 << g.pending[i].rec.family;
+    /* (a shadow pass's fragments are black: rz_strip_kernel writes them itself, no family's kernel has work from them) */
+    for (size_t i = pl.first; i < pl.sky_first; i++)
+        if (pl.has_blend || !(g.pending[i].rec.flags & RZ_DRAW_SHADOW_PASS)) pl.families |= 1 << g.pending[i].rec.family;
     total = (total + 255) & ~(size_t)255;
     pl.off_draws = total;
     total += sizeof(DrawRec) * D;

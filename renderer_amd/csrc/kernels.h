@@ -85,29 +85,63 @@ RZ_DEV bool fully_visible(f4 v);
 RZ_DEV uint2 pack_bin_box(uint32_t bx, uint32_t by, uint32_t entries);
 RZ_DEV void store_tri(TriRec *dst, const TriRec &r);
 
+/* what the rasteriser needs to know about a triangle's draw without loading it (or-ed into the record's meta word) */
+RZ_DEV uint32_t draw_class_bits(const DrawRec &D) {
+    const bool blend = (D.flags & RZ_DRAW_BLEND) != 0;
+    return (blend ? 1u << 22 : 0u) | (D.alpha_cutoff > 0 ? 1u << 23 : 0u) | ((uint32_t)D.family << 24) |
+           ((D.flags & RZ_DRAW_SHADOW_PASS) && !blend ? 1u << 26 : 0u);
+}
+
+/* the groups of four varyings anything reads of a draw's triangles, as a bit mask.  A shadow pass's fragments are
+ * black whatever their varyings (blinn_shader.c:101-115, pbr_shader.c:113-136): only the alpha cutoff's texture
+ * coordinates are ever looked at. */
+RZ_DEV uint32_t draw_vary_groups(const DrawRec &D) {
+    if (D.flags & RZ_DRAW_SHADOW_PASS) {
+        if (D.flags & RZ_DRAW_BLEND) return (1u << ((D.num_varyings + 3) / 4)) - 1u;
+        if (!(D.alpha_cutoff > 0)) return 0u;
+        return 1u << ((D.family == 0 ? RZ_BV_TEXCOORD : RZ_PV_TEXCOORD) / 4);
+    }
+    return (1u << ((D.num_varyings + 3) / 4)) - 1u;                 /* 1 skybox, 3 blinn, 6 pbr */
+}
+
 /* Vertex shaders and triangle set-up in one kernel.  A workgroup takes 85 triangles: thread 3k + i shades
- * corner i of triangle k (thread 255 idles) and leaves its clip-space position in LDS; the triangle's
- * first thread then does the set-up from the three positions -- trivial accept (graphics.c:275-277),
- * cull, record and pixel box, or the queue of the clipper -- and tells the other two what became of it.
+ * corner i of triangle k (thread 255 idles) and leaves its clip-space position in LDS; thread k then does
+ * triangle k's set-up from the three positions -- trivial accept (graphics.c:275-277), cull, record and pixel
+ * box, or the queue of the clipper -- and tells the corners' threads what became of it.
  * Varyings are stored for triangles that live (half of a closed mesh's are culled: nothing ever reads
- * theirs), clip-space positions only for triangles the clipper will read them of. */
+ * theirs), clip-space positions only for triangles the clipper will read them of.
+ *
+ * A wave's corners nearly always belong to one draw.  The wave takes the draws its lanes belong to one after the
+ * other, so that a draw's record -- four matrices, flags, pointers -- comes through scalar loads once per wave; read
+ * per lane those 60 words were three times the vertex itself and the kernel waited on the vector memory path. */
 #define RZ_VS_TRIS 85
 __global__ void __launch_bounds__(256) rz_vertex_kernel(const PassParams *__restrict__ passes) {
     const PassParams &P = passes[blockIdx.y];
     __shared__ float4 s_clip[256];
     __shared__ int s_fate[RZ_VS_TRIS + 1];          /* 0 culled, 1 alive, 2 for the clipper */
-    const uint32_t tri = blockIdx.x * (uint32_t)RZ_VS_TRIS + threadIdx.x / 3u, corner = threadIdx.x % 3u;
-    if (blockIdx.x * (uint32_t)RZ_VS_TRIS >= (uint32_t)P.num_tris) return;      /* uniform over the workgroup */
+    __shared__ int s_draw[RZ_VS_TRIS + 1];
+    const uint32_t first = blockIdx.x * (uint32_t)RZ_VS_TRIS;
+    if (first >= (uint32_t)P.num_tris) return;                                  /* uniform over the workgroup */
+    const uint32_t tri = first + threadIdx.x / 3u, corner = threadIdx.x % 3u;
     const bool mine = threadIdx.x < 3u * RZ_VS_TRIS && tri < (uint32_t)P.num_tris;
     const uint32_t gv = 3u * tri + corner;
-    int d = 0;
+    /* the draw of the workgroup's first triangle by a search every lane makes alike; a lane past that draw's end
+     * searches for itself */
+    int d = find_draw(P.first_tri, P.num_draws, first);
+    if (mine && tri >= P.first_tri[d + 1]) d = find_draw(P.first_tri, P.num_draws, tri);
     f4 clip = mk4(0, 0, 0, 0);
     float vary[RZ_VARY_STRIDE];     /* put together in registers, stored as whole groups of four below */
     for (int k = 0; k < RZ_VARY_STRIDE; k++) vary[k] = 0;
-    if (mine) {
-    d = find_draw(P.first_tri, P.num_draws, tri);
-    const DrawRec &D = P.draws[d];
-    uint32_t local = gv - 3u * P.first_tri[d];
+    uint32_t groups = 0;
+    unsigned long long rest = __ballot(mine);
+    while (rest) {
+    const int d_now = __builtin_amdgcn_readlane(d, __ffsll((long long)rest) - 1);
+    const bool now = mine && d == d_now;
+    rest &= ~__ballot(now);
+    const DrawRec &D = P.draws[d_now];
+    if (now) {
+    groups = draw_vary_groups(D);
+    uint32_t local = gv - 3u * P.first_tri[d_now];
     const float4 RZ_GLOBAL *src = (const float4 RZ_GLOBAL*)(D.vertices.as<const char>() + (size_t)local * 80u);
     float a[20];                    /* position 0-2, texcoord 3-4, normal 5-7, tangent 8-11, joint 12-15, weight 16-19 */
     for (int i = 0; i < 5; i++) {
@@ -174,17 +208,21 @@ __global__ void __launch_bounds__(256) rz_vertex_kernel(const PassParams *__rest
         }
     }
     }
+    }
     s_clip[threadIdx.x] = make_float4(clip.x, clip.y, clip.z, clip.w);
+    if (mine && corner == 0u) s_draw[threadIdx.x / 3u] = d;
     __syncthreads();
-    if (mine && corner == 0u) {
-        const DrawRec &D = P.draws[d];
+    /* the set-up, triangle k in thread k: the workgroup's first two waves, two lanes in three at work (in the corners'
+     * own threads it kept one lane in three of all four waves busy) */
+    if (threadIdx.x < (uint32_t)RZ_VS_TRIS && first + threadIdx.x < (uint32_t)P.num_tris) {
+        const uint32_t t = first + threadIdx.x;
+        const int dt = s_draw[threadIdx.x];
+        const DrawRec &D = P.draws[dt];
         const bool double_sided = (D.flags & RZ_DRAW_DOUBLE_SIDED) != 0;
-        /* what the rasteriser needs to know about the draw without loading it */
-        const uint32_t class_bits = ((D.flags & RZ_DRAW_BLEND) ? 1u << 22 : 0u) | (D.alpha_cutoff > 0 ? 1u << 23 : 0u) |
-                                    ((uint32_t)D.family << 24);
+        const uint32_t class_bits = draw_class_bits(D);
         f4 c[3];
         for (int i = 0; i < 3; i++) {
-            const float4 q = s_clip[threadIdx.x + i];
+            const float4 q = s_clip[3u * threadIdx.x + i];
             c[i] = mk4(q.x, q.y, q.z, q.w);
         }
         const uint2 empty = make_uint2(RZ_BBOX_EMPTY_X, RZ_BBOX_EMPTY_X);
@@ -192,38 +230,40 @@ __global__ void __launch_bounds__(256) rz_vertex_kernel(const PassParams *__rest
         if (fully_visible(c[0]) && fully_visible(c[1]) && fully_visible(c[2])) {        /* graphics.c:290-300 */
             TriRec rec;
             int x0, x1, y0, y1;
-            if (make_tri(c, P.width, P.height, double_sided, (uint32_t)d, rec, x0, x1, y0, y1)) {
+            if (make_tri(c, P.width, P.height, double_sided, (uint32_t)dt, rec, x0, x1, y0, y1)) {
                 rec.meta |= class_bits;
-                store_tri(&P.tri[tri], rec);
+                store_tri(&P.tri[t], rec);
                 if (D.sky_slot) {       /* a sky box on the pass's table: its place there instead of one in the bins */
-                    P.bbox[tri] = empty;
+                    P.bbox[t] = empty;
                     if (x0 <= x1 && y0 <= y1)
-                        P.sky_table[((uint32_t)(D.sky_slot - 1) * RZ_SKY_FACES + (tri - P.first_tri[d])) * RZ_MAX_FAN] = tri;
+                        P.sky_table[((uint32_t)(D.sky_slot - 1) * RZ_SKY_FACES + (t - P.first_tri[dt])) * RZ_MAX_FAN] = t;
                 } else {
-                    P.bbox[tri] = pack_bin_box(rec.bx, rec.by, 1u);
+                    P.bbox[t] = pack_bin_box(rec.bx, rec.by, 1u);
                 }
                 if (P.counters) atomicAdd(&P.counters[1], 1ull);
                 fate = 1;
             } else {
-                P.bbox[tri] = empty;
+                P.bbox[t] = empty;
             }
         } else {
             /* needs the clipper: queued for rz_clip_kernel, which fills tri/bbox */
-            P.bbox[tri] = empty;
-            P.clip_list[atomicAdd(&P.control[3], 1u)] = tri;
+            P.bbox[t] = empty;
+            P.clip_list[atomicAdd(&P.control[3], 1u)] = t;
             fate = 2;
         }
-        s_fate[threadIdx.x / 3u] = fate;
+        s_fate[threadIdx.x] = fate;
     }
     __syncthreads();
     if (!mine) return;
     const int fate = s_fate[threadIdx.x / 3u];
     if (fate == 0) return;
-    if (fate == 2) P.clip.as<float4>()[gv] = make_float4(clip.x, clip.y, clip.z, clip.w);
+    if (fate == 2) {
+        P.clip.as<float4>()[gv] = make_float4(clip.x, clip.y, clip.z, clip.w);
+        groups = (1u << ((P.draws[d].num_varyings + 3) / 4)) - 1u;          /* the clipper carries every varying along */
+    }
     float4 RZ_GLOBAL *out = (float4 RZ_GLOBAL*)(P.vary + (size_t)gv * RZ_VARY_STRIDE);
-    const int groups = (P.draws[d].num_varyings + 3) / 4;       /* 1 skybox, 3 blinn, 6 pbr */
     for (int i = 0; i < RZ_VARY_STRIDE / 4; i++)
-        if (i < groups) out[i] = make_float4(vary[4 * i], vary[4 * i + 1], vary[4 * i + 2], vary[4 * i + 3]);
+        if ((groups >> i) & 1u) out[i] = make_float4(vary[4 * i], vary[4 * i + 1], vary[4 * i + 2], vary[4 * i + 3]);
 }
 
 /* ========================================================================
@@ -495,8 +535,7 @@ __global__ void __launch_bounds__(64) rz_clip_kernel(const PassParams *__restric
         const DrawRec &D = P.draws[d];
         const int nv = D.num_varyings;
         const bool double_sided = (D.flags & RZ_DRAW_DOUBLE_SIDED) != 0;
-        const uint32_t class_bits = ((D.flags & RZ_DRAW_BLEND) ? 1u << 22 : 0u) | (D.alpha_cutoff > 0 ? 1u << 23 : 0u) |
-                                    ((uint32_t)D.family << 24);
+        const uint32_t class_bits = draw_class_bits(D);
         __syncthreads();
         if (lane < 32) {
             for (int i = 0; i < 3; i++) {
@@ -1812,8 +1851,13 @@ __global__ void __launch_bounds__(64) rz_bin_class_kernel(const PassParams *__re
     if (lane == 41) rec->fresh = range.y == 0u ? 1u : 0u;
 }
 
+/* the tag rz_strip_kernel puts on a fragment's reference: the family whose kernel shades it, or 3 for a fragment that
+ * is black whatever its inputs (the strip's epilogue writes those itself; RZ_REF_NONE reads as 3 too) */
+RZ_DEV uint32_t ref_tag(uint32_t meta) { return RZ_META_BLACK(meta) ? 3u : RZ_META_FAMILY(meta); }
+
 /* What a wave of rz_strip_kernel does with a finished block of 16x8 pixels: depth, the clear colour where no
- * fragment is, and -- for blocks that hold fragments -- the references. */
+ * fragment is, black (draw_fragment keeps the buffer's alpha byte, graphics.c:466-468) where a shadow pass's
+ * fragment is, and -- for blocks that hold fragments to shade -- the references. */
 #define RZ_BLOCK_ITEM(pass, by, bx) (((uint32_t)(pass) << 21) | ((uint32_t)(by) << 10) | (uint32_t)(bx))
 RZ_DEV void finish_block(const PassParams &P, uint32_t pass_index, int bx0, int by0, int lane,
                          const bool valid[2], const uint32_t pixel[2], const float zcur[2], const uint32_t ref_of[2]) {
@@ -1824,6 +1868,8 @@ RZ_DEV void finish_block(const PassParams &P, uint32_t pass_index, int bx0, int 
         listed |= ((ref_of[q] >> 28) & 3u) < 3u;                /* RZ_REF_NONE reads as family 3 */
         /* a pixel without a fragment shows the clear colour */
         if (valid[q] && P.clear_color_pending && ref_of[q] == RZ_REF_NONE) P.color[pixel[q]] = P.clear_color;
+        if (valid[q] && ref_of[q] != RZ_REF_NONE && ((ref_of[q] >> 28) & 3u) == 3u)
+            P.color[pixel[q]] = (P.clear_color_pending ? P.clear_color : P.color[pixel[q]]) & 0xff000000u;
     }
     if (__any(listed)) {
         /* the block holds fragments to shade: its references are written -- all of them, a
@@ -2103,7 +2149,7 @@ __global__ void __launch_bounds__(128) rz_strip_kernel(const PassParams *__restr
                         }
                     }
                 }
-                const uint32_t tagged = ref | (RZ_META_FAMILY(r.meta) << 28);
+                const uint32_t tagged = ref | (ref_tag(r.meta) << 28);
                 for (int q = 0; q < PPL; q++) if (pass[q]) { zcur[q] = depth[q]; ref_of[q] = tagged; ord_of[q] = (int)(group_at + at); }
             }
         }
@@ -2119,7 +2165,7 @@ __global__ void __launch_bounds__(128) rz_strip_kernel(const PassParams *__restr
                 if (depth < zcur[q] || (depth == zcur[q] && ord > ord_of[q])) {
                     const BinEntry *e = &list[ord];
                     zcur[q] = depth;
-                    ref_of[q] = e->tri | (RZ_META_FAMILY(e->rec.meta) << 28);
+                    ref_of[q] = e->tri | (ref_tag(e->rec.meta) << 28);
                     ord_of[q] = ord;
                 }
             }

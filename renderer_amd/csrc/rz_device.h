@@ -175,6 +175,7 @@ struct BinEntry {
 #define RZ_META_BLEND(m) (((m) >> 22) & 1u)
 #define RZ_META_CUTOFF(m) (((m) >> 23) & 1u)
 #define RZ_META_FAMILY(m) (((m) >> 24) & 3u)
+#define RZ_META_BLACK(m) (((m) >> 26) & 1u)     /* a shadow pass's fragment without blending: (0, 0, 0) whatever its inputs (blinn_shader.c:101-115, pbr_shader.c:113-136) */
 #define RZ_BBOX_EMPTY_X 0x0000ffffu  /* min 65535 > max 0 */
 
 struct PassParams {
