@@ -195,7 +195,7 @@ struct Context {
     int fill_waves = 0;                     /* MI355R_FILL_WAVES: waves that share a chunk of 64 triangles in rz_bin_fill_kernel (1, 2, 4; unset: by the launch's size) */
     unsigned strip_long = 2048;             /* MI355R_STRIP_LONG: a batch whose framebuffers had a bin list of this many entries in their last frame takes one block per wave,
                                              * of half as many two; 0, or MI355R_STRIP set = always `strip` */
-    int strip = 4;                          /* MI355R_STRIP: 16x8 blocks a wave of rz_strip_kernel takes (8, 4, 2, 1) */
+    int strip = 2;                          /* MI355R_STRIP: 16x8 blocks a wave of rz_strip_kernel takes (8, 4, 2, 1) */
     /* passes with blended draws: 0 = whole through the ordered kernel, 1 = visibility first and the ordered kernel only for
      * the tiles that need it, 2 = the latter for large framebuffers (MI355R_SPLIT_BLEND=0 / 1; measured: 4K frames gain 8 %,
      * 1080p frames lose as much to the three extra launches) */
@@ -2954,6 +2954,19 @@ extern "C" void mi355r_set_scratch_estimate(unsigned long long fan_blocks, unsig
 extern "C" unsigned long long mi355r_replayed_draws(void) { return g.replayed_draws; }
 
 extern "C" const char *mi355r_last_raster_kernel(void) { return g.last_raster_kernel; }
+#ifdef RZ_PROBE
+extern "C" int mi355r_debug_probe(unsigned long long *out, int max_records) {
+    HIP_OK(hipDeviceSynchronize());
+    unsigned int n = 0;
+    HIP_OK(hipMemcpyFromSymbol(&n, HIP_SYMBOL(rz_probe_count), sizeof n));
+    n = std::min(n, (unsigned)RZ_PROBE_MAX);
+    n = std::min(n, (unsigned)max_records);
+    if (out && n) HIP_OK(hipMemcpyFromSymbol(out, HIP_SYMBOL(rz_probe_data), (size_t)n * RZ_PROBE_WORDS * sizeof(unsigned long long)));
+    unsigned int zero = 0;
+    HIP_OK(hipMemcpyToSymbol(HIP_SYMBOL(rz_probe_count), &zero, sizeof zero));
+    return (int)n;
+}
+#endif
 
 extern "C" int mi355r_inspect_sky_first(void) { return g.have_last_pass ? g.last_pass_sky_first : 0; }
 

@@ -1912,9 +1912,12 @@ RZ_DEV void finish_block(const PassParams &P, uint32_t pass_index, int bx0, int 
  * the whole strip.  The first group of the next block's candidates is requested before the current
  * block's epilogue, which hides its latency behind the epilogue's arithmetic.
  *
- * How tall a strip should be depends on the lists.  Where they are short (sky, background) the fixed
- * costs of a wave and of starting its workgroup are what counts, and tall strips win (helmet at 1080p,
- * longest list 700 entries: 12.9 / 12.5 / 11.7 us per frame with 1 / 2 / 4 blocks).  A long list makes
+ * How tall a strip should be depends on the lists.  Where they are short the fixed costs of a wave and of
+ * starting its workgroup count; with the sky box in the bins (every bin of the frame a list of a dozen entries)
+ * tall strips won (helmet at 1080p, longest list 700 entries: 12.9 / 12.5 / 11.7 us per frame with 1 / 2 / 4
+ * blocks).  With the sky box on its own table only the bins a model touches have strips at all, a scene of a few
+ * thousand triangles has fewer waves than the device holds, and shorter strips finish sooner (helmet 6.4 / 6.6 /
+ * 7.0 us; kgirl at 1080p, 32 passes: 43.0 / 43.9 / 40.6 thousand frames per second): two blocks is the default.  A long list makes
  * the blocks themselves expensive: then four times as many waves, each a quarter as long, fill the
  * device better and leave a shorter tail (azura at 800x600, a few bins of 10 000 entries and more: 19.2 /
  * 30.6 / 46.8 us).  The host picks STRIP per batch from the longest list its framebuffers had in their
@@ -1926,6 +1929,12 @@ RZ_DEV void finish_block(const PassParams &P, uint32_t pass_index, int bx0, int 
  * appended to its family's work list (16x8 blocks, not 32x8 tiles: the wave that owns the block is the only one
  * to list it).  Skybox fragments are rz_sky_kernel's: it looks at the references of every pixel outside the bins
  * it resolves itself, so in a batch with a sky box the references of all blocks are written. */
+#ifdef RZ_PROBE
+#define RZ_PROBE_WORDS 12
+#define RZ_PROBE_MAX (1 << 19)
+__device__ unsigned long long rz_probe_data[RZ_PROBE_WORDS * RZ_PROBE_MAX];
+__device__ unsigned int rz_probe_count;
+#endif
 template <int STRIP>
 __global__ void __launch_bounds__(128) rz_strip_kernel(const PassParams *__restrict__ passes,
         const BinEntry *__restrict__ list_base, const uint2 *__restrict__ box_base,
@@ -1958,6 +1967,10 @@ __global__ void __launch_bounds__(128) rz_strip_kernel(const PassParams *__restr
     const uint2 range = (bin_range_base + P.bin_off)[bin];          /* {first entry, entries} */
     if (!uniform_width && class_base[P.bin_off + (uint32_t)bin] != (uint32_t)RZ_BIN_STRIP) return;
     const uint32_t count = range.y;                                 /* (a bin of this class is not empty) */
+#ifdef RZ_PROBE
+    const unsigned long long probe_t0 = wall_clock64();
+    unsigned long long probe_ordered = 0, probe_ring = 0, probe_groups = 0, probe_hits = 0, probe_survivors = 0, probe_cutoffs = 0, probe_batches = 0, probe_small = 0;
+#endif
     const BinEntry *list = list_table + range.x;
     const uint2 *boxes = box_base + P.list_off + range.x;
 
@@ -2095,11 +2108,26 @@ __global__ void __launch_bounds__(128) rz_strip_kernel(const PassParams *__restr
                 if (smalls) {
                     if (small) ring[(ring_tail + __builtin_amdgcn_mbcnt_hi((uint32_t)(smalls >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)smalls, 0u))) & 127u] = group_at + (uint32_t)lane;
                     ring_tail += (uint32_t)__popcll(smalls);
+#ifdef RZ_PROBE
+                    probe_small += __popcll(smalls);
+#endif
                     hit = hit && !small;
-                    if (ring_tail - ring_head >= 64u) rasterise_ring(64u);
+                    if (ring_tail - ring_head >= 64u) {
+#ifdef RZ_PROBE
+                        const unsigned long long t = clock64(); probe_batches++;
+#endif
+                        rasterise_ring(64u);
+#ifdef RZ_PROBE
+                        probe_ring += clock64() - t;
+#endif
+                    }
                 }
             }
             unsigned long long todo = __ballot(hit);
+#ifdef RZ_PROBE
+            probe_groups++; probe_survivors += __popcll(todo); probe_cutoffs += __popcll(__ballot(hit && cutoff));
+            const unsigned long long to = clock64();
+#endif
             while (todo) {
                 /* the wave-uniform entry index makes these scalar loads */
                 const uint32_t at = (uint32_t)__ffsll((long long)todo) - 1u;
@@ -2152,9 +2180,18 @@ __global__ void __launch_bounds__(128) rz_strip_kernel(const PassParams *__restr
                 const uint32_t tagged = ref | (ref_tag(r.meta) << 28);
                 for (int q = 0; q < PPL; q++) if (pass[q]) { zcur[q] = depth[q]; ref_of[q] = tagged; ord_of[q] = (int)(group_at + at); }
             }
+#ifdef RZ_PROBE
+            probe_ordered += clock64() - to;
+#endif
         }
         if (micro_area) {
+#ifdef RZ_PROBE
+            const unsigned long long tr = clock64(); if (ring_tail != ring_head) probe_batches++;
+#endif
             if (ring_tail != ring_head) rasterise_ring(ring_tail - ring_head);
+#ifdef RZ_PROBE
+            probe_ring += clock64() - tr;
+#endif
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             for (int q = 0; q < PPL; q++) {
                 const unsigned long long key = keys[q * 64 + lane];
@@ -2176,6 +2213,16 @@ __global__ void __launch_bounds__(128) rz_strip_kernel(const PassParams *__restr
 
         finish_block(P, pass_index, bx0, by0, lane, valid, pixel, zcur, ref_of);
     }
+#ifdef RZ_PROBE
+    if (lane == 0) {
+        const unsigned int at = atomicAdd(&rz_probe_count, 1u);
+        if (at < RZ_PROBE_MAX) {
+            unsigned long long *o = rz_probe_data + (size_t)at * RZ_PROBE_WORDS;
+            o[0] = pass_index; o[1] = (unsigned long long)bin; o[2] = count; o[3] = probe_groups; o[4] = probe_survivors; o[5] = probe_cutoffs;
+            o[6] = probe_batches; o[7] = wall_clock64() - probe_t0; o[8] = probe_ordered; o[9] = probe_ring; o[10] = probe_small; o[11] = probe_t0;
+        }
+    }
+#endif
 }
 
 /* K5  per-family fragment kernels behind rz_strip_kernel / rz_blend_visibility_kernel:
