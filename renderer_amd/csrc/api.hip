@@ -20,6 +20,8 @@
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
+#include <array>
+#include <map>
 #include <unordered_map>
 #include <unordered_set>
 #include <chrono>

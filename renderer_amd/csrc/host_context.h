@@ -42,6 +42,14 @@ struct CubeDisplay {
     unsigned long long version[6] = {};     /* Tex::image_version of the faces it was made from */
 };
 
+/* the maps of a material side by side (DrawRec::bundle) */
+struct Bundle {
+    uint32_t *d = nullptr;
+    size_t texels = 0;
+    int words = 0;
+    unsigned long long version[6] = {};     /* Tex::image_version of the maps it was made from */
+};
+
 struct rz_program {
     int family;
     int attrib_bytes, varying_bytes, uniform_bytes;
@@ -174,6 +182,8 @@ struct Context {
     std::unordered_map<const void*, Mesh> meshes;
     std::unordered_map<const void*, DevTex*> cubes;     /* rz_cubemap* -> DevTex[6] */
     std::unordered_map<const void*, CubeDisplay> cube_displays;     /* rz_cubemap* -> its plane of display bytes */
+    std::map<std::array<const void*, 6>, Bundle> bundles;           /* a material's textures (in map order, nullptr = none) -> their bundle */
+    bool bundle_maps = true;                /* MI355R_BUNDLE=0: every map is sampled from its own image */
     std::unordered_map<const void*, DevIbl*> ibls;      /* rz_ibldata* -> DevIbl */
     std::unordered_map<const void*, bool> ibl_narrow;   /* ... and whether all its images have 4-byte formats */
     std::unordered_set<rz_pose_source*> pose_sources;
@@ -280,6 +290,8 @@ extern "C" int mi355r_init(int device) {
         if (env) g.micro_area = std::max(0, std::min(atoi(env), 128));
         env = getenv("MI355R_MICRO_MIN_LIST");
         if (env) g.micro_min_list = std::max(0, atoi(env));
+        env = getenv("MI355R_BUNDLE");
+        if (env) g.bundle_maps = atoi(env) != 0;
         env = getenv("MI355R_PACK");
         if (env) g.pack_textures = atoi(env) != 0;
         env = getenv("MI355R_BATCH");

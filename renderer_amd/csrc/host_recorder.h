@@ -66,6 +66,10 @@ static void snapshot_uniforms_once(rz_program *p, Pending &pd, int num_joints) {
         r.maps[2] = dev_tex(u->emission_map);
         r.alpha_cutoff = u->alpha_cutoff;
         if (u->shadow_pass) r.flags |= RZ_DRAW_SHADOW_PASS;
+        else {
+            rz_texture *const maps[3] = {u->diffuse_map, u->specular_map, u->emission_map};
+            r.bundle = material_bundle(maps, 3, r.maps, 4);
+        }
     } else {
         const rz_pbr_uniforms *u = (const rz_pbr_uniforms*)p->uniforms;
         r.num_varyings = 21;
@@ -103,6 +107,11 @@ static void snapshot_uniforms_once(rz_program *p, Pending &pd, int num_joints) {
         r.alpha_cutoff = u->alpha_cutoff;
         r.layer_view = u->layer_view;
         if (u->shadow_pass) r.flags |= RZ_DRAW_SHADOW_PASS;
+        else {
+            rz_texture *const maps[6] = {u->workflow == 0 ? u->basecolor_map : u->diffuse_map, u->workflow == 0 ? u->metalness_map : u->specular_map,
+                                         u->workflow == 0 ? u->roughness_map : u->glossiness_map, u->normal_map, u->occlusion_map, u->emission_map};
+            r.bundle = material_bundle(maps, 6, r.maps, 8);
+        }
     }
     if (p->family != RZ_FAMILY_SKYBOX) {
         bool narrow = !r.shadow_map.data || (r.shadow_map.flags & RZ_TEX_NARROW_FORMATS);

@@ -296,6 +296,49 @@ static DevTex dev_tex(rz_texture *p) {
     return d;
 }
 
+/* The bundle of a material's maps (DrawRec::bundle), made when a draw first uses that set of textures and again when one
+ * of their images has been rewritten since; nullptr when the maps do not qualify: fewer than two of them, sizes, layouts
+ * or a format that is not 4 bytes wide, or an image that the GPU writes. */
+static const uint32_t *material_bundle(rz_texture *const *maps, int count, const DevTex *devs, int words) {
+    if (!g.bundle_maps) return nullptr;
+    std::array<const void*, 6> key = {};
+    Tex *tex[6] = {};
+    int present = 0, w = 0, h = 0, layout = 0;
+    for (int k = 0; k < count; k++) {
+        if (!devs[k].data) continue;
+        Tex *t = as_tex(maps[k]);
+        if (!(devs[k].flags & RZ_TEX_NARROW_FORMATS) || t->pending_write || t->write_lane >= 0) return nullptr;
+        if (present == 0) { w = devs[k].w; h = devs[k].h; layout = devs[k].flags & RZ_TEX_LAYOUT; }
+        else if (devs[k].w != w || devs[k].h != h || (devs[k].flags & RZ_TEX_LAYOUT) != layout) return nullptr;
+        tex[k] = t;
+        key[k] = t;
+        present++;
+    }
+    if (present < 2) return nullptr;
+    Bundle &b = g.bundles[key];
+    const size_t texels = (size_t)w * (size_t)h;
+    bool fresh = b.d != nullptr && b.texels == texels && b.words == words;
+    for (int k = 0; k < count; k++) fresh = fresh && b.version[k] == (tex[k] ? tex[k]->image_version : 0ull);
+    if (fresh) return b.d;
+    /* recorded draws and passes in flight may still read the bundle that is about to be rewritten */
+    if (b.d) { graphics_flush(); sync_stream(); }
+    if (b.d && (b.texels != texels || b.words != words)) { HIP_OK(hipFree(b.d)); b.d = nullptr; }
+    if (!b.d) HIP_OK(hipMalloc((void**)&b.d, texels * (size_t)words * sizeof(uint32_t)));
+    b.texels = texels;
+    b.words = words;
+    BundleMaps from;
+    memset(&from, 0, sizeof from);
+    for (int k = 0; k < count; k++) {
+        from.map[k] = tex[k] ? (const uint32_t*)tex[k]->d_data : nullptr;
+        b.version[k] = tex[k] ? tex[k]->image_version : 0ull;
+    }
+    rz_bundle_kernel<<<dim3((unsigned)((texels + 255) / 256)), dim3(256), 0, g.stream>>>(b.d, from, texels, words);
+    HIP_OK(hipGetLastError());
+    HIP_OK(hipStreamSynchronize(g.stream));
+    if (g.verbose) fprintf(stderr, "mi355r: bundle of %d maps, %dx%d, %d words per texel\n", present, w, h, words);
+    return b.d;
+}
+
 /* texture_create_packed: the image arrives in a 4-byte device format, straight from the file's bytes */
 extern "C" rz_texture *texture_create_packed(int width, int height, int format, const unsigned int *words) {
     ensure_ready();
@@ -536,6 +579,8 @@ static void drop_derived_handles() {
     for (auto &kv : g.cubes) HIP_OK(hipFree(kv.second));
     for (auto &kv : g.ibls) HIP_OK(hipFree(kv.second));
     for (auto &kv : g.cube_displays) if (kv.second.d) HIP_OK(hipFree(kv.second.d));
+    for (auto &kv : g.bundles) if (kv.second.d) HIP_OK(hipFree(kv.second.d));
+    g.bundles.clear();
     g.cube_displays.clear();
     g.cubes.clear();
     g.ibls.clear();

@@ -2488,6 +2488,14 @@ __global__ void rz_buffers_to_textures_kernel(const CopyJobs jobs) {
     }
 }
 
+/* a material's maps side by side (DrawRec::bundle): word k of texel i = map k's texel i, 0 where there is no map */
+struct BundleMaps { const uint32_t *map[8]; };
+__global__ void rz_bundle_kernel(uint32_t *__restrict__ bundle, const BundleMaps maps, size_t texels, int words) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= texels) return;
+    for (int k = 0; k < words; k++) bundle[i * (size_t)words + k] = maps.map[k] ? maps.map[k][i] : 0u;
+}
+
 /* RGBA8 -> RGB8, four pixels (16 bytes in, 12 out) per thread */
 __global__ void rz_strip_alpha_kernel(const uint32_t *__restrict__ color, uint32_t *__restrict__ rgb, size_t pixels) {
     const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;         /* group of four pixels */

@@ -136,6 +136,10 @@ struct DrawRec {
      * pbr {basecolor|diffuse, metalness|specular, roughness|glossiness,
      *      normal, occlusion, emission} */
     DevTex maps[6];
+    /* the maps' texels side by side, texel i of map k at word i * W + k (W = 4 blinn, 8 pbr; an absent map's word is 0), when
+     * they have one size, one layout and 4-byte formats: a fragment's material texels are then neighbours in memory, one
+     * load of one cache line where the maps' own images are a line each; nullptr: sample the maps */
+    rz_gptr<const uint32_t> bundle;
     rz_gptr<const DevIbl> ibl;
     rz_gptr<const DevTex> skybox;         /* 6 faces (the same six are in maps[] of a skybox draw) */
     int32_t workflow;               /* 0 metal-rough, 1 spec-gloss */

@@ -402,8 +402,17 @@ RZ_DEV f4 fs_blinn(const DrawRec &D, const float *v, bool backface, bool *discar
         return mk4(0, 0, 0, 0);
     }
     /* every texel this fragment can need, in flight together */
-    const MapCell cell = first_cell(D.maps[0], tu, tv);
-    const TexelT<NARROW> t0 = load_like<NARROW>(D.maps[0], cell), t1 = load_like<NARROW>(D.maps[1], cell), t2 = load_like<NARROW>(D.maps[2], cell);
+    const MapCell cell = first_cell(D.maps[0].data ? D.maps[0] : D.maps[1].data ? D.maps[1] : D.maps[2], tu, tv);
+    TexelT<NARROW> t0, t1, t2;
+    bool bundled = false;
+    if constexpr (NARROW) {
+        if (D.bundle) {             /* (uniform) */
+            const uint4 q = *(const uint4 RZ_GLOBAL*)(D.bundle.p + ((size_t)cell.index << 2));
+            t0.word = q.x; t1.word = q.y; t2.word = q.z;
+            bundled = true;
+        }
+    }
+    if (!bundled) { t0 = load_like<NARROW>(D.maps[0], cell); t1 = load_like<NARROW>(D.maps[1], cell); t2 = load_like<NARROW>(D.maps[2], cell); }
     const TexelT<NARROW> tshadow = load_shadow<NARROW>(D, mk3(v[3], v[4], v[5]));
     /* material (:126-169) */
     f3 diffuse = mk3(D.base[0], D.base[1], D.base[2]);
@@ -465,8 +474,21 @@ RZ_DEV Surface pbr_surface(const DrawRec &D, const float *v, bool backface) {
     float tu = v[RZ_PV_TEXCOORD], tv = v[RZ_PV_TEXCOORD + 1];
     /* the six material texels in flight together */
     const MapCell cell = first_cell(D.maps[0].data ? D.maps[0] : D.maps[3], tu, tv);
-    const TexelT<NARROW> t0 = load_like<NARROW>(D.maps[0], cell), t1 = load_like<NARROW>(D.maps[1], cell), t2 = load_like<NARROW>(D.maps[2], cell);
-    const TexelT<NARROW> t3 = load_like<NARROW>(D.maps[3], cell), t4 = load_like<NARROW>(D.maps[4], cell), t5 = load_like<NARROW>(D.maps[5], cell);
+    TexelT<NARROW> t0, t1, t2, t3, t4, t5;
+    bool bundled = false;
+    if constexpr (NARROW) {
+        if (D.bundle) {             /* (uniform) */
+            const uint32_t RZ_GLOBAL *at = D.bundle.p + ((size_t)cell.index << 3);
+            const uint4 lo = *(const uint4 RZ_GLOBAL*)at;
+            const uint2 hi = *(const uint2 RZ_GLOBAL*)(at + 4);
+            t0.word = lo.x; t1.word = lo.y; t2.word = lo.z; t3.word = lo.w; t4.word = hi.x; t5.word = hi.y;
+            bundled = true;
+        }
+    }
+    if (!bundled) {
+        t0 = load_like<NARROW>(D.maps[0], cell); t1 = load_like<NARROW>(D.maps[1], cell); t2 = load_like<NARROW>(D.maps[2], cell);
+        t3 = load_like<NARROW>(D.maps[3], cell); t4 = load_like<NARROW>(D.maps[4], cell); t5 = load_like<NARROW>(D.maps[5], cell);
+    }
     if (D.workflow == 0) {                                      /* metal-rough, :148-182 */
         f3 base = mk3(D.base[0], D.base[1], D.base[2]);
         float metal = D.metalness, rough = D.roughness;
