@@ -19,10 +19,10 @@ pass() {
     name=$1; shift
     timeout -k 10 240 rocprofv3 --pmc "$@" --output-format csv -d "$OUT/$name" -- $BENCH > "$OUT/$name.log" 2>&1 || { echo "pmc pass $name failed"; tail -5 "$OUT/$name.log"; exit 1; }
 }
-pass sq1 SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU
-pass sq2 SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_WAIT_INST_LDS SQ_INST_CYCLES_VMEM
+pass sq1 SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU GRBM_GUI_ACTIVE
+pass sq2 SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_WAIT_INST_LDS SQ_INST_CYCLES_VMEM GRBM_GUI_ACTIVE
 pass fetch FETCH_SIZE GRBM_GUI_ACTIVE
-pass write WRITE_SIZE TCC_HIT_sum TCC_MISS_sum
-pass td TD_TD_BUSY_sum TD_LOAD_WAVEFRONT_sum TA_TA_BUSY_sum
+pass write WRITE_SIZE TCC_HIT_sum TCC_MISS_sum GRBM_GUI_ACTIVE
+pass td TD_TD_BUSY_sum TD_LOAD_WAVEFRONT_sum TA_TA_BUSY_sum GRBM_GUI_ACTIVE
 python3 tools/summarize_profile.py "$OUT" 32 > "$OUT/summary.txt" 2>&1
 grep -v "^    " "$OUT/summary.txt" | head -24

@@ -36,9 +36,27 @@ def median(v):
 
 
 pmc = defaultdict(lambda: defaultdict(list))
+# GRBM_GUI_ACTIVE of each counter pass: the cycles the kernel took IN THAT PASS (counter collection serialises launches
+# and stretches them, each pass differently: a fraction is a pass's counter over that same pass's cycles)
+active = defaultdict(lambda: defaultdict(list))         # pass -> kernel -> GRBM_GUI_ACTIVE
+pass_of = {}                                            # counter -> pass
 for f in glob.glob(os.path.join(out, "*", "**", "*counter_collection.csv"), recursive=True):
+    which = os.path.relpath(f, out).split(os.sep)[0]
     for row in csv.DictReader(open(f)):
+        if row["Counter_Name"] == "GRBM_GUI_ACTIVE":
+            active[which][short(row["Kernel_Name"])].append(float(row["Counter_Value"]))
+            if which != "fetch":
+                continue
         pmc[short(row["Kernel_Name"])][row["Counter_Name"]].append(float(row["Counter_Value"]))
+        pass_of[row["Counter_Name"]] = which
+XCDS = 8
+
+
+def cycles_in_pass(kernel, counter):
+    """average cycles per launch of `kernel` in the pass that collected `counter` (GRBM_GUI_ACTIVE is summed over the
+    eight XCDs), or None when that pass did not collect it"""
+    v = active.get(pass_of.get(counter, ""), {}).get(kernel)
+    return sum(v) / len(v) / XCDS if v else None
 
 def steady(v):
     """average over the launches of the benchmark's ordinary steps: without those that take more than twice
@@ -75,8 +93,9 @@ CLOCK_MHZ = 2400.0
 traffic = {"frames_per_launch": frames, "unit": "bytes per launch; fractions over the kernel's steady average duration in this profile",
            "note": "traffic_frac = (FETCH_SIZE + WRITE_SIZE, KiB -> bytes) / duration / 8 TB/s; traffic_frac_x2 doubles FETCH_SIZE, the gfx950 "
                    "correction for wide coalesced reads (an upper bound for 4- and 16-byte gathers); valu_issue_frac = wave-level VALU "
-                   "instructions x 4 cycles over the cycles of the 1024 SIMDs at 2.4 GHz; td_busy_frac = TD_TD_BUSY_sum over the "
-                   "cycles of the 256 compute units' texture data paths",
+                   "instructions x 4 cycles over the cycles of the 1024 SIMDs; td_busy_frac = TD_TD_BUSY_sum over the "
+                   "cycles of the 256 compute units' texture data paths; cycles = GRBM_GUI_ACTIVE / 8 XCDs of the same counter pass "
+                   "(2.4 GHz x the trace's duration where a pass did not collect it)",
            "kernels": {}}
 for k in stats:
     c = pmc.get(k, {})
@@ -97,14 +116,15 @@ for k in stats:
                 salu = sum(c["SQ_INSTS_SALU"]) / len(c["SQ_INSTS_SALU"]) if "SQ_INSTS_SALU" in c else 0.0
                 entry["valu_insts_per_launch"] = valu
                 entry["salu_insts_per_launch"] = salu
-                entry["valu_issue_frac"] = valu * 4 / (4 * COMPUTE_UNITS * us * CLOCK_MHZ)
+                cyc = cycles_in_pass(k, "SQ_INSTS_VALU") or us * CLOCK_MHZ
+                entry["valu_issue_frac"] = valu * 4 / (4 * COMPUTE_UNITS * cyc)
                 # scalar issue: a compute unit's scalar unit takes one instruction per cycle from its four SIMDs in turn,
                 # i.e. one per SIMD every 4 cycles, like the vector unit; scalar memory instructions go through it too
                 smem = sum(c["SQ_INSTS_SMEM"]) / len(c["SQ_INSTS_SMEM"]) if "SQ_INSTS_SMEM" in c else 0.0
-                entry["salu_issue_frac"] = (salu + smem) * 4 / (4 * COMPUTE_UNITS * us * CLOCK_MHZ)
+                entry["salu_issue_frac"] = (salu + smem) * 4 / (4 * COMPUTE_UNITS * (cycles_in_pass(k, "SQ_INSTS_SALU") or us * CLOCK_MHZ))
             if "TD_TD_BUSY_sum" in c:
                 busy = sum(c["TD_TD_BUSY_sum"]) / len(c["TD_TD_BUSY_sum"])
-                entry["td_busy_frac"] = busy / (COMPUTE_UNITS * us * CLOCK_MHZ)
+                entry["td_busy_frac"] = busy / (COMPUTE_UNITS * (cycles_in_pass(k, "TD_TD_BUSY_sum") or us * CLOCK_MHZ))
             if "SQ_INSTS_VMEM_RD" in c:
                 entry["vmem_rd_insts_per_launch"] = sum(c["SQ_INSTS_VMEM_RD"]) / len(c["SQ_INSTS_VMEM_RD"])
         traffic["kernels"][k] = entry
