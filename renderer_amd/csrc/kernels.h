@@ -1444,7 +1444,7 @@ RZ_DEV void raster_tile(const PassParams &P, const uint32_t pass_index, const ui
                 /* the shaders' discard test (blinn_shader.c:104-113, 220; pbr_shader.c:116-134, 452):
                  * alpha = base alpha * first map's alpha, from the interpolated texcoord */
                 const DrawRec &D = draw_table[RZ_META_DRAW(r.meta)];
-                const int tc = D.family == 0 ? RZ_BV_TEXCOORD : RZ_PV_TEXCOORD;
+                const int tc = RZ_META_FAMILY(r.meta) == 0 ? RZ_BV_TEXCOORD : RZ_PV_TEXCOORD;   /* (from the record: the varyings do not wait for the draw) */
                 const float *v0, *v1, *v2;
                 ref_varyings(ref, vary_table, fan_vary_table, v0, v1, v2);
                 float q0 = r.rw[0] * w0, q1 = r.rw[1] * w1, q2 = r.rw[2] * w2;
@@ -1645,7 +1645,7 @@ RZ_DEV void blend_visibility_tile(const PassParams P, const uint32_t pass_index,
                 /* the shaders' discard test (blinn_shader.c:104-113, 220; pbr_shader.c:116-134, 452):
                  * alpha = base alpha * first map's alpha, from the interpolated texcoord */
                 const DrawRec &D = draw_table[RZ_META_DRAW(r.meta)];
-                const int tc = D.family == 0 ? RZ_BV_TEXCOORD : RZ_PV_TEXCOORD;
+                const int tc = RZ_META_FAMILY(r.meta) == 0 ? RZ_BV_TEXCOORD : RZ_PV_TEXCOORD;   /* (from the record: the varyings do not wait for the draw) */
                 const float *v0, *v1, *v2;
                 ref_varyings(ref, vary_table, fan_vary_table, v0, v1, v2);
                 for (int q = 0; q < PPL; q++) {
@@ -2162,7 +2162,7 @@ __global__ void __launch_bounds__(128) rz_strip_kernel(const PassParams *__restr
                     /* the shaders' discard test (blinn_shader.c:104-113, 220; pbr_shader.c:116-134, 452):
                      * alpha = base alpha * first map's alpha, from the interpolated texcoord */
                     const DrawRec &D = draw_table[RZ_META_DRAW(r.meta)];
-                    const int tc = D.family == 0 ? RZ_BV_TEXCOORD : RZ_PV_TEXCOORD;
+                    const int tc = RZ_META_FAMILY(r.meta) == 0 ? RZ_BV_TEXCOORD : RZ_PV_TEXCOORD;   /* (from the record: the varyings do not wait for the draw) */
                     const float *v0, *v1, *v2;
                     ref_varyings(ref, vary_table, fan_vary_table, v0, v1, v2);
                     for (int q = 0; q < PPL; q++) {
