@@ -127,7 +127,7 @@ struct Lane {
 };
 
 static const int RZ_TEX_NARROW_FORMATS = RZ_TEX_R32F | RZ_TEX_UNORM8 | RZ_TEX_SRGB8 | RZ_TEX_RGBE8;
-static const size_t MAX_BATCH = 64;     /* passes per launch sequence, upper bound */
+static const size_t MAX_BATCH = 256;    /* passes per launch sequence, upper bound */
 static const int MAX_LANES = 8;
 
 struct Context {
@@ -137,7 +137,7 @@ struct Context {
     hipStream_t copy_stream = nullptr;  /* table uploads / control read-back of a flush */
     Lane lanes[MAX_LANES];
     int num_lanes = 1, next_lane = 0;
-    size_t max_batch = 32;                  /* passes per launch sequence */
+    size_t max_batch = 64;                  /* passes per launch sequence (MI355R_BATCH) */
     bool sky_bytes = true;                  /* MI355R_SKY_BYTES=0: skybox fragments fetch the face's texel and convert it themselves */
     bool pack_textures = true;              /* MI355R_PACK=0: keep every image as float4 */
     int micro_min_list = 256;               /* MI355R_MICRO_MIN_LIST: small triangles are rasterised one per lane only in bins with at least this many list entries */

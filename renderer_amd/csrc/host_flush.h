@@ -1,4 +1,4 @@
-/* Host side, part 4 of 6: the flush -- pending draws become passes, passes become batches of up to 32 on the execution
+/* Host side, part 4 of 6: the flush -- pending draws become passes, passes become batches of up to 64 on the execution
  * lanes, each batch one sequence of kernel launches; scratch that ran out, passes that run again, settling a flush. */
 
 /* ------------------------------------------------------------------- flush -- */

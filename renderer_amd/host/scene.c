@@ -58,7 +58,7 @@ typedef struct {                /* renderer/core/scene.h:25-40 */
     float pose_time;
 } model_t;
 
-#define RZS_SHADOW_RING 32
+#define RZS_SHADOW_RING 128          /* at most; a scene takes as many as fit a budget, at least 32 (scene_create) */
 
 struct rzs_scene {              /* renderer/core/scene.h:42-52 */
     rz_vec4 background;
@@ -72,7 +72,7 @@ struct rzs_scene {              /* renderer/core/scene.h:42-52 */
      * each, and with one the library has to finish every frame before the next starts). */
     rz_framebuffer *shadow_buffer, *shadow_buffers[RZS_SHADOW_RING];
     rz_texture *shadow_map, *shadow_maps[RZS_SHADOW_RING];
-    int shadow_turn;
+    int shadow_turn, shadow_ring;
 };
 
 /* ======================= models ========================================= */
@@ -469,9 +469,21 @@ static rzs_scene *scene_from_scn(const char *filename, rz_mat4 root) {
     scene->punctual = punctual;
     if (shadow_w > 0 && shadow_h > 0) {
         int k;
-        for (k = 0; k < RZS_SHADOW_RING; k++) {
+        /* The ring is what bounds a flush: the frame that takes a slot again has to wait for the frame that used it
+         * before, and the library finishes everything recorded so far.  The longer a flush, the more of its batches run
+         * side by side on the library's lanes (a frame's shadow pass, main pass and blended pass depend on each other;
+         * those of different frames do not).  A slot holds a framebuffer and a texture with their host images, 36 bytes
+         * per texel: as many slots as fit in 1 GiB, 32 at least (a 2048 x 2048 map: 151 MB per slot). */
+        const double slot_bytes = 36.0 * (double)shadow_w * (double)shadow_h;
+        scene->shadow_ring = (int)(1073741824.0 / slot_bytes);
+        if (scene->shadow_ring < 32) scene->shadow_ring = 32;
+        if (scene->shadow_ring > RZS_SHADOW_RING) scene->shadow_ring = RZS_SHADOW_RING;
+        for (k = 0; k < scene->shadow_ring; k++) {
             scene->shadow_buffers[k] = framebuffer_create(shadow_w, shadow_h);
             scene->shadow_maps[k] = texture_create(shadow_w, shadow_h);
+            /* on the GPU library a texture's first copy from a framebuffer moves its host image into page-locked memory
+             * and allocates its device image: paid here, not by the first frames that take the slot */
+            if (strncmp(mi355r_backend(), "hip", 3) == 0) texture_from_depthbuffer(scene->shadow_maps[k], scene->shadow_buffers[k]);
         }
         scene->shadow_buffer = scene->shadow_buffers[0];
         scene->shadow_map = scene->shadow_maps[0];
@@ -578,7 +590,7 @@ void rzs_scene_close(rzs_scene *scene) {            /* scene.c:29-48 */
     free(scene->models);
     if (scene->shadow_buffer) {
         int k;
-        for (k = 0; k < RZS_SHADOW_RING; k++) {
+        for (k = 0; k < scene->shadow_ring; k++) {
             framebuffer_release(scene->shadow_buffers[k]);
             texture_release(scene->shadow_maps[k]);
         }
@@ -698,7 +710,7 @@ static void scene_draw(rzs_scene *scene, rz_framebuffer *fb, const rzs_view *vie
     f.camera_view = hm_m4_lookat(eye, target, up);
     f.camera_proj = hm_m4_perspective(RZ_RADIANS(60), aspect, 0.1f, 10000);
     if (scene->shadow_buffer) {
-        const int slot = scene->shadow_turn++ % RZS_SHADOW_RING;
+        const int slot = scene->shadow_turn++ % scene->shadow_ring;
         scene->shadow_buffer = scene->shadow_buffers[slot];
         scene->shadow_map = scene->shadow_maps[slot];
     }
