@@ -113,6 +113,10 @@ template <typename T> struct DevBuf {
  * serialised by the stream, which is what lets them share the scratch. */
 struct Lane {
     hipStream_t stream = nullptr;
+    /* the sky kernel of a batch runs beside the batch's shade kernels: it keeps the vector units busy, they wait for
+     * memory, and neither reads what the other writes (fork after the strips, join before whatever comes next) */
+    hipStream_t side = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;
     DevBuf<float> clip, vary, fan_vary;
     DevBuf<TriRec> tri, fan_tri;
     DevBuf<uint2> bbox;
@@ -141,6 +145,7 @@ struct Context {
     bool sky_bytes = true;                  /* MI355R_SKY_BYTES=0: skybox fragments fetch the face's texel and convert it themselves */
     bool pack_textures = true;              /* MI355R_PACK=0: keep every image as float4 */
     int micro_min_list = 256;               /* MI355R_MICRO_MIN_LIST: small triangles are rasterised one per lane only in bins with at least this many list entries */
+    bool sky_side = true;                   /* MI355R_SKY_SIDE=0: the sky kernel runs in line, on its batch's own stream */
     bool sky_table = true;                  /* MI355R_SKY_TABLE=0: a sky box goes through the bins like any other draw */
     int fill_waves = 0;                     /* MI355R_FILL_WAVES: waves that share a chunk of 64 triangles in rz_bin_fill_kernel (1, 2, 4; unset: by the launch's size) */
     unsigned strip_long = 2048;             /* MI355R_STRIP_LONG: a batch whose framebuffers had a bin list of this many entries in their last frame takes one block per wave,
@@ -298,6 +303,12 @@ extern "C" int mi355r_init(int device) {
         if (env && atoi(env) >= 1) g.max_batch = std::min<size_t>((size_t)atoi(env), MAX_BATCH);
     }
     for (int i = 0; i < g.num_lanes; i++) HIP_OK(hipStreamCreateWithFlags(&g.lanes[i].stream, hipStreamNonBlocking));
+    if (const char *env = getenv("MI355R_SKY_SIDE")) g.sky_side = atoi(env) != 0;
+    for (int i = 0; i < g.num_lanes && g.sky_side; i++) {
+        HIP_OK(hipStreamCreateWithFlags(&g.lanes[i].side, hipStreamNonBlocking));
+        HIP_OK(hipEventCreateWithFlags(&g.lanes[i].fork, hipEventDisableTiming));
+        HIP_OK(hipEventCreateWithFlags(&g.lanes[i].join, hipEventDisableTiming));
+    }
     HIP_OK(hipStreamCreateWithFlags(&g.copy_stream, hipStreamNonBlocking));
     g.stream = g.lanes[0].stream;
     HIP_OK(hipHostMalloc((void**)&g.ring_host, RING_BYTES, hipHostMallocDefault));
