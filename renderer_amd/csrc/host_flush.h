@@ -962,6 +962,7 @@ extern "C" void graphics_flush(void) {
                 memset(&jobs, 0, sizeof jobs);
                 std::vector<hipEvent_t> readers;
                 int max_w = 0, max_h = 0;
+                bool quads = true;                  /* depth buffers with sides of whole 16s into tiled images */
                 for (size_t k = 0; k < count; k++) {
                     const FlushRecord::Copy &w = fr.copies[feeds[at + k]];
                     Tex *t = w.tex;
@@ -971,9 +972,12 @@ extern "C" void graphics_flush(void) {
                     if (t->write_event && t->write_lane != b.lane) readers.push_back(t->write_event);
                     jobs.job[k] = copy_job(t, w.fb, w.depth, fr.control_dev(w.producer));
                     max_w = std::max(max_w, t->pub.width); max_h = std::max(max_h, t->pub.height);
+                    quads = quads && w.depth && (t->flags & RZ_TEX_TILED) && t->pub.width % 16 == 0 && t->pub.height % 16 == 0;
                 }
                 for (hipEvent_t e : readers) HIP_OK(hipStreamWaitEvent(L.stream, e, 0));   /* passes that still sample the old contents */
-                rz_buffers_to_textures_kernel<<<dim3((max_w + 15) / 16, (max_h + 15) / 16, (unsigned)count), dim3(256), 0, L.stream>>>(jobs);
+                const dim3 copy_grid((max_w + 15) / 16, (max_h + 15) / 16, (unsigned)count);
+                if (quads) rz_depth_to_textures_kernel<<<copy_grid, dim3(64), 0, L.stream>>>(jobs);
+                else rz_buffers_to_textures_kernel<<<copy_grid, dim3(256), 0, L.stream>>>(jobs);
                 HIP_OK(hipGetLastError());
                 hipEvent_t written = new_event(L.stream);
                 for (size_t k = 0; k < count; k++) {
