@@ -9,6 +9,9 @@ CONFIG=${2:-C2}
 OUT=gpurun_out/prof_$TAG
 rm -rf "$OUT"; mkdir -p "$OUT"
 export TMPDIR=/tmp
+# one kernel at a time: a batch's sky kernel in line, not beside its shade kernels (counters of kernels that run side by side
+# cannot be told apart, and their durations stretch)
+export MI355R_SKY_SIDE=0
 if [ "$CONFIG" = C2 ]; then
     BENCH="python3 bench.py --steps 3 --warmup 1 --frames 32 --no-cpu --no-other"
 else

@@ -37,18 +37,32 @@ def median(v):
 
 pmc = defaultdict(lambda: defaultdict(list))
 # GRBM_GUI_ACTIVE of each counter pass: the cycles the kernel took IN THAT PASS (counter collection serialises launches
-# and stretches them, each pass differently: a fraction is a pass's counter over that same pass's cycles)
+# and stretches them, each pass differently: a fraction is a pass's counter over that same pass's cycles).  Launches that
+# are not the benchmark's ordinary steps -- the first frame that loads the code, the counting step -- are left out the
+# way steady() leaves them out of the durations: by their cycles against the pass's median.
 active = defaultdict(lambda: defaultdict(list))         # pass -> kernel -> GRBM_GUI_ACTIVE
 pass_of = {}                                            # counter -> pass
 for f in glob.glob(os.path.join(out, "*", "**", "*counter_collection.csv"), recursive=True):
     which = os.path.relpath(f, out).split(os.sep)[0]
+    launches = defaultdict(dict)                        # (kernel, dispatch) -> counter -> value
     for row in csv.DictReader(open(f)):
-        if row["Counter_Name"] == "GRBM_GUI_ACTIVE":
-            active[which][short(row["Kernel_Name"])].append(float(row["Counter_Value"]))
-            if which != "fetch":
+        launches[(short(row["Kernel_Name"]), row["Dispatch_Id"])][row["Counter_Name"]] = float(row["Counter_Value"])
+    cycles = defaultdict(list)
+    for (kernel, _), values in launches.items():
+        if "GRBM_GUI_ACTIVE" in values:
+            cycles[kernel].append(values["GRBM_GUI_ACTIVE"])
+    for (kernel, _), values in launches.items():
+        if "GRBM_GUI_ACTIVE" in values:
+            m = median(cycles[kernel])
+            if not 0.5 * m <= values["GRBM_GUI_ACTIVE"] <= 2 * m:
                 continue
-        pmc[short(row["Kernel_Name"])][row["Counter_Name"]].append(float(row["Counter_Value"]))
-        pass_of[row["Counter_Name"]] = which
+        for counter, value in values.items():
+            if counter == "GRBM_GUI_ACTIVE":
+                active[which][kernel].append(value)
+                if which != "fetch":
+                    continue
+            pmc[kernel][counter].append(value)
+            pass_of[counter] = which
 XCDS = 8
 
 
