@@ -80,6 +80,8 @@ class Pipeline:
         lib.rzs_scene_info.argtypes = [P, C.POINTER(C.c_int)]
         lib.rzs_scene_shadow_buffer.restype = FB
         lib.rzs_scene_shadow_buffer.argtypes = [P]
+        lib.rzs_scene_shadow_ring.restype = C.c_int
+        lib.rzs_scene_shadow_ring.argtypes = [P]
         lib.rzs_evaluate_poses.restype = C.c_int
         lib.rzs_evaluate_poses.argtypes = [C.c_char_p, P, C.c_int, P, P, C.c_int]
         lib.rzs_set_device_poses.argtypes = [C.c_int]

@@ -615,6 +615,9 @@ void rzs_scene_info(rzs_scene *scene, int out[8]) {
 
 rz_framebuffer *rzs_scene_shadow_buffer(rzs_scene *scene) { return scene->shadow_buffer; }
 
+/* how many frames' shadow buffers and maps the scene alternates between (0: it casts no shadows) */
+int rzs_scene_shadow_ring(rzs_scene *scene) { return scene->shadow_buffer ? scene->shadow_ring : 0; }
+
 /* Joint and normal matrices of `count` poses of a .ani skeleton, for tests: through the pipeline's pose
  * source (on_host == 0) or this layer's own per-frame evaluation (rzh_skeleton_update).  Returns the
  * number of joints (also with count == 0), -1 when the pipeline does not take the skeleton. */

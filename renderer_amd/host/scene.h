@@ -61,6 +61,7 @@ int rzs_evaluate_poses(const char *ani, const float *times, int count, float *jo
  * height, [5] blended models, [6] skinned models, [7] node-attached models */
 void rzs_scene_info(rzs_scene *scene, int out[8]);
 rz_framebuffer *rzs_scene_shadow_buffer(rzs_scene *scene);
+int rzs_scene_shadow_ring(rzs_scene *scene);
 
 #ifdef __cplusplus
 }
