@@ -38,7 +38,7 @@ extern "C" void framebuffer_read_device_rgb(rz_framebuffer *p, void *rgb) {
     apply_pending_clear(fb);
     const size_t n = (size_t)fb->pub.width * fb->pub.height;
     hipStream_t st = g.lanes[fb->lane < 0 ? 0 : fb->lane].stream;
-    rz_strip_alpha_kernel<<<dim3((unsigned)((n / 4 + 1 + 255) / 256)), dim3(256), 0, st>>>(fb->d_color, (uint32_t*)rgb, n);
+    rz_strip_alpha_kernel<<<dim3((unsigned)((n / 16 + 1 + 255) / 256)), dim3(256), 0, st>>>(fb->d_color, (uint32_t*)rgb, n);
     HIP_OK(hipGetLastError());
     HIP_OK(hipStreamSynchronize(st));
 }
@@ -171,7 +171,7 @@ extern "C" void framebuffers_read_device_rgb(rz_framebuffer *const *fps, int cou
             apply_pending_clear(fb);
             const size_t n = (size_t)fb->pub.width * fb->pub.height;
             hipStream_t st = g.lanes[fb->lane < 0 ? 0 : fb->lane].stream;
-            rz_strip_alpha_kernel<<<dim3((unsigned)((n / 4 + 1 + 255) / 256)), dim3(256), 0, st>>>(
+            rz_strip_alpha_kernel<<<dim3((unsigned)((n / 16 + 1 + 255) / 256)), dim3(256), 0, st>>>(
                 fb->d_color, (uint32_t*)((char*)rgb + (size_t)i * stride_bytes), n);
             HIP_OK(hipGetLastError());
         }
@@ -203,7 +203,7 @@ static void launch_frames_read(bool again) {
         Fb *fb = r.fbs[i];
         const size_t n = (size_t)fb->pub.width * fb->pub.height;
         const int lane = fb->lane < 0 ? 0 : fb->lane;
-        rz_strip_alpha_kernel<<<dim3((unsigned)((n / 4 + 1 + 255) / 256)), dim3(256), 0, g.lanes[lane].stream>>>(
+        rz_strip_alpha_kernel<<<dim3((unsigned)((n / 16 + 1 + 255) / 256)), dim3(256), 0, g.lanes[lane].stream>>>(
             fb->d_color, (uint32_t*)(r.rgb + i * r.stride), n);
         HIP_OK(hipGetLastError());
         r.used[lane] = true;

@@ -2514,21 +2514,43 @@ __global__ void rz_bundle_kernel(uint32_t *__restrict__ bundle, const BundleMaps
     for (int k = 0; k < words; k++) bundle[i * (size_t)words + k] = maps.map[k] ? maps.map[k][i] : 0u;
 }
 
-/* RGBA8 -> RGB8, four pixels (16 bytes in, 12 out) per thread */
+/* RGBA8 -> RGB8.  A thread takes sixteen pixels, 64 bytes in as four 16-byte loads and 48 out as three 16-byte stores,
+ * when the destination is 16-byte aligned (a frame of a gather buffer is); otherwise, and for the last pixels of a frame
+ * that is no multiple of sixteen, four pixels with 4-byte stores or pixel by pixel.  (Four pixels per thread everywhere:
+ * 14.5 MB of a 1080p frame moved in 5.2 us.) */
+RZ_DEV void strip_alpha_four(uint4 c, uint32_t &o0, uint32_t &o1, uint32_t &o2) {
+    const uint32_t a = c.x & 0xffffffu, b = c.y & 0xffffffu, d = c.z & 0xffffffu, e = c.w & 0xffffffu;
+    o0 = a | (b << 24);
+    o1 = (b >> 8) | (d << 16);
+    o2 = (d >> 16) | (e << 8);
+}
 __global__ void rz_strip_alpha_kernel(const uint32_t *__restrict__ color, uint32_t *__restrict__ rgb, size_t pixels) {
-    const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;         /* group of four pixels */
-    if (q * 4 >= pixels) return;
-    if (q * 4 + 4 <= pixels) {
-        const uint4 c = ((const uint4*)color)[q];
-        const uint32_t a = c.x & 0xffffffu, b = c.y & 0xffffffu, d = c.z & 0xffffffu, e = c.w & 0xffffffu;
-        rgb[q * 3 + 0] = a | (b << 24);
-        rgb[q * 3 + 1] = (b >> 8) | (d << 16);
-        rgb[q * 3 + 2] = (d >> 16) | (e << 8);
-    } else {
-        unsigned char *out = (unsigned char*)rgb;
-        for (size_t p = q * 4; p < pixels; p++) {
-            const uint32_t c = color[p];
-            out[p * 3] = (unsigned char)c; out[p * 3 + 1] = (unsigned char)(c >> 8); out[p * 3 + 2] = (unsigned char)(c >> 16);
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;         /* group of sixteen pixels */
+    if (t * 16 >= pixels) return;
+    const bool aligned = ((uintptr_t)rgb & 15u) == 0;                       /* uniform */
+    if (aligned && t * 16 + 16 <= pixels) {
+        const uint4 *in = (const uint4*)color + t * 4;
+        const uint4 c0 = in[0], c1 = in[1], c2 = in[2], c3 = in[3];
+        uint4 o0, o1, o2;
+        strip_alpha_four(c0, o0.x, o0.y, o0.z);
+        strip_alpha_four(c1, o0.w, o1.x, o1.y);
+        strip_alpha_four(c2, o1.z, o1.w, o2.x);
+        strip_alpha_four(c3, o2.y, o2.z, o2.w);
+        uint4 *out = (uint4*)rgb + t * 3;
+        out[0] = o0; out[1] = o1; out[2] = o2;
+        return;
+    }
+    for (size_t q = t * 4; q < t * 4 + 4 && q * 4 < pixels; q++) {         /* groups of four pixels */
+        if (q * 4 + 4 <= pixels) {
+            uint32_t o0, o1, o2;
+            strip_alpha_four(((const uint4*)color)[q], o0, o1, o2);
+            rgb[q * 3 + 0] = o0; rgb[q * 3 + 1] = o1; rgb[q * 3 + 2] = o2;
+        } else {
+            unsigned char *out = (unsigned char*)rgb;
+            for (size_t p = q * 4; p < pixels; p++) {
+                const uint32_t c = color[p];
+                out[p * 3] = (unsigned char)c; out[p * 3 + 1] = (unsigned char)(c >> 8); out[p * 3 + 2] = (unsigned char)(c >> 16);
+            }
         }
     }
 }

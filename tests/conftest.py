@@ -57,6 +57,14 @@ def oracle():
 def gpu():
     """The product: renderer_amd/libmi355r.so through its C ABI.  No fallback."""
     from renderer_amd.binding import Pipeline, GPU_LIB
+    try:
+        # tests that hand the library device tensors need torch's HIP runtime up BEFORE the library's: brought up
+        # second it finds no device ("No HIP GPUs are available"), whichever test happens to run first
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except ImportError:
+        pass
     pipe = Pipeline(GPU_LIB)
     assert pipe.backend.startswith("hip"), pipe.backend
     return pipe
