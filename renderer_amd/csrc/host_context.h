@@ -145,6 +145,9 @@ struct Context {
     bool sky_bytes = true;                  /* MI355R_SKY_BYTES=0: skybox fragments fetch the face's texel and convert it themselves */
     bool pack_textures = true;              /* MI355R_PACK=0: keep every image as float4 */
     int micro_min_list = 256;               /* MI355R_MICRO_MIN_LIST: small triangles are rasterised one per lane only in bins with at least this many list entries */
+    int crowd_min = 8192;                   /* MI355R_CROWD_MIN: bins with at least this many list entries have their blocks rasterised by several waves each, beside the strips (0: none) */
+    bool crowd_always = false;              /* (set with MI355R_CROWD_MIN: also for framebuffers whose last frame is not known to have had such a bin) */
+    int crowd_split = 4;                    /* MI355R_CROWD_SPLIT: that many (2, 4, 8, 16) */
     bool sky_side = true;                   /* MI355R_SKY_SIDE=0: the sky kernel runs in line, on its batch's own stream */
     bool sky_table = true;                  /* MI355R_SKY_TABLE=0: a sky box goes through the bins like any other draw */
     int fill_waves = 0;                     /* MI355R_FILL_WAVES: waves that share a chunk of 64 triangles in rz_bin_fill_kernel (1, 2, 4; unset: by the launch's size) */
@@ -304,7 +307,9 @@ extern "C" int mi355r_init(int device) {
     }
     for (int i = 0; i < g.num_lanes; i++) HIP_OK(hipStreamCreateWithFlags(&g.lanes[i].stream, hipStreamNonBlocking));
     if (const char *env = getenv("MI355R_SKY_SIDE")) g.sky_side = atoi(env) != 0;
-    for (int i = 0; i < g.num_lanes && g.sky_side; i++) {
+    if (const char *env = getenv("MI355R_CROWD_MIN")) { g.crowd_min = std::max(0, atoi(env)); g.crowd_always = true; }
+    if (const char *env = getenv("MI355R_CROWD_SPLIT")) { const int v = atoi(env); if (v == 2 || v == 4 || v == 8 || v == 16) g.crowd_split = v; }
+    for (int i = 0; i < g.num_lanes && (g.sky_side || g.crowd_min > 0); i++) {
         HIP_OK(hipStreamCreateWithFlags(&g.lanes[i].side, hipStreamNonBlocking));
         HIP_OK(hipEventCreateWithFlags(&g.lanes[i].fork, hipEventDisableTiming));
         HIP_OK(hipEventCreateWithFlags(&g.lanes[i].join, hipEventDisableTiming));

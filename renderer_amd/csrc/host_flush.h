@@ -150,6 +150,7 @@ struct Batch {
     bool has_blend;
     int families;
     bool sky_table = false;         /* one of its passes keeps sky boxes on its table of sky triangles */
+    bool crowd = false;             /* its crowded bins are rz_crowd_kernel's (settled when the batch is put together: its passes' parameters and its launches must agree) */
 };
 
 /* What is kept of a flush until its control blocks have been looked at: enough to run any of its
@@ -173,6 +174,20 @@ struct FlushRecord {
 static std::vector<FlushRecord> g_in_flight;
 
 /* whether a batch of passes with blended draws takes the visibility-first route */
+/* does a batch hand its crowded bins to rz_crowd_kernel?  (asked when its passes' parameters are written and again
+ * when it is launched) */
+/* does a batch hand its crowded bins to rz_crowd_kernel?  Only where a framebuffer's last frame had such a bin (control
+ * word 4): a fork, a launch that finds an empty list and a join cost every other batch 2 %. */
+template <class Plans>
+static bool wants_crowd(const Batch &b, const Plans &plans) {
+    static const bool paranoid = getenv("MI355R_SYNC") != nullptr;
+    if (!(g.crowd_min > 0 && !g.counting && !g.timing && !paranoid && !b.has_blend && g.lanes[b.lane].side != nullptr)) return false;
+    if (g.crowd_always) return true;
+    uint32_t longest = 0;
+    for (size_t i : b.members) longest = std::max(longest, plans[i].fb->longest_list);
+    return longest >= (uint32_t)g.crowd_min;
+}
+
 static bool splits_blend(size_t batch_tiles, size_t passes) {
     if (g.counting || g.split_blend == 0) return false;
     return g.split_blend == 1 || batch_tiles >= 16384 * passes;
@@ -310,6 +325,7 @@ static void prepare_batch(const Batch &b, const FlushRecord &fr, bool reserve_on
         P.scan_list = !b.has_blend ? -1 : splits_blend(tiles, b.members.size()) ? (int)RZ_VISIBILITY_LIST : (int)RZ_ORDERED_LIST;
         P.micro_area = g.micro_area;
         P.micro_min_list = g.micro_min_list;
+        P.crowd_min = b.crowd ? g.crowd_min : 0;
         P.tiles_x = (W + RZ_TILE_W - 1) / RZ_TILE_W;
         P.tiles_y = (H + RZ_TILE_H - 1) / RZ_TILE_H;
         P.tile_listed = L.tile_listed.ptr + tile_off;
@@ -417,6 +433,7 @@ static void launch_batch(const Batch &b, const std::vector<PassPlan> &plans, cha
      * blended fragments pile up and the shade kernels for the rest */
     const int only = b.families == (1 << RZ_FAMILY_BLINN) ? 0 : b.families == (1 << RZ_FAMILY_PBR) ? 1 : -1;
     bool in_strips = false;                         /* the shade lists hold 16x8 blocks */
+    bool crowd_forked = false;
     if (b.has_blend && !splits_blend(batch_tiles, n)) {
         /* over the tiles of the bins that are not empty (listed by rz_bin_scan_kernel) */
         auto kernel = rz_raster_list_kernel<-1, false>;
@@ -459,16 +476,27 @@ static void launch_batch(const Batch &b, const std::vector<PassPlan> &plans, cha
             int uniform_w = plans[b.members[0]].fb->pub.width, uniform_h = plans[b.members[0]].fb->pub.height;
             for (size_t i : b.members)
                 if (plans[i].fb->pub.width != uniform_w || plans[i].fb->pub.height != uniform_h) uniform_w = uniform_h = 0;
+            if (b.crowd) {
+                /* the blocks of crowded bins (listed by the class kernel) beside the strips of the others */
+                HIP_OK(hipEventRecord(L.fork, st));
+                HIP_OK(hipStreamWaitEvent(L.side, L.fork, 0));
+                auto crowd = g.crowd_split == 2 ? rz_crowd_kernel<2> : g.crowd_split == 4 ? rz_crowd_kernel<4> : g.crowd_split == 16 ? rz_crowd_kernel<16> : rz_crowd_kernel<8>;
+                crowd<<<shade_grid, dim3(64u * (unsigned)g.crowd_split), 0, L.side>>>(
+                    passes, L.bin_list.ptr, L.bin_boxes.ptr, L.vary.ptr, L.fan_vary.ptr, db, L.bin_range.ptr, L.queue.ptr, L.queue_counts.ptr, queue_capacity);
+                HIP_OK(hipEventRecord(L.join, L.side));
+                crowd_forked = true;
+            }
             kernel<<<dim3(n, bin_columns * 2, bin_rows * strips_per_bin), dim3(128), 0, st>>>(
                 passes, L.bin_list.ptr, L.bin_boxes.ptr, L.vary.ptr, L.fan_vary.ptr, db, L.bin_range.ptr, L.bin_class.ptr, uniform_w, uniform_h);
         }
         stamp();
+        if (crowd_forked) HIP_OK(hipStreamWaitEvent(st, L.join, 0));
         bool forked = false;
         if (b.sky_table) {
             hipStream_t sky_stream = st;
             /* (not for a launch of a frame or two: there the fork and the join cost more than the overlap gains --
              * helmet, one frame per flush: 0.172 against 0.159 ms per frame) */
-            if (L.side && !g.timing && !paranoid && b.members.size() > 4) {
+            if (L.side && g.sky_side && !g.timing && !paranoid && b.members.size() > 4) {
                 HIP_OK(hipEventRecord(L.fork, st));
                 HIP_OK(hipStreamWaitEvent(L.side, L.fork, 0));
                 sky_stream = L.side;
@@ -863,6 +891,7 @@ extern "C" void graphics_flush(void) {
                     int lane = plans[b.members[0]].fb->lane;
                     if (lane < 0 || lane >= lanes) { lane = g.next_lane % lanes; g.next_lane = (g.next_lane + 1) % lanes; }
                     b.lane = lane;
+                    b.crowd = wants_crowd(b, plans);
                     batches.push_back(std::move(b));
                     b = Batch();
                 };

@@ -691,7 +691,9 @@ RZ_DEV const TriRec *ref_record(uint32_t ref, const TriRec *tri_table, const Tri
  * memory's rate.  A strip whose batch has passes of one size finds its bin's class with two kernel arguments and
  * its own index, before it has read anything else.  For a pass with a table of sky triangles the bin's SkyBin
  * record is written here too. */
-enum { RZ_BIN_STRIP = 0, RZ_BIN_DONE = 1 };
+enum { RZ_BIN_STRIP = 0, RZ_BIN_DONE = 1, RZ_BIN_CROWD = 2 };
+/* a 16x8 block on a work list */
+#define RZ_BLOCK_ITEM(pass, by, bx) (((uint32_t)(pass) << 21) | ((uint32_t)(by) << 10) | (uint32_t)(bx))
 __global__ void __launch_bounds__(64) rz_bin_class_kernel(const PassParams *__restrict__ passes,
         const TriRec *__restrict__ tri_base, const TriRec *__restrict__ fan_base,
         const uint2 *__restrict__ bin_range_base, SkyBin *__restrict__ sky_base, uint32_t *__restrict__ class_base) {
@@ -705,7 +707,20 @@ __global__ void __launch_bounds__(64) rz_bin_class_kernel(const PassParams *__re
     }
     const uint2 range = (bin_range_base + P.bin_off)[blockIdx.x];
     const int bin_x0 = (int)(blockIdx.x % (uint32_t)P.bins_x) * RZ_BIN, bin_y0 = (int)(blockIdx.x / (uint32_t)P.bins_x) * RZ_BIN;
-    if (lane == 0) *bin_class = range.y == 0u ? (uint32_t)RZ_BIN_DONE : (uint32_t)RZ_BIN_STRIP;
+    /* a crowded bin is left to rz_crowd_kernel: its 16x8 blocks go on that kernel's work list, block by lane */
+    const bool crowd = P.crowd_min > 0 && range.y >= (uint32_t)P.crowd_min;
+    if (lane == 0) *bin_class = range.y == 0u ? (uint32_t)RZ_BIN_DONE : crowd ? (uint32_t)RZ_BIN_CROWD : (uint32_t)RZ_BIN_STRIP;
+    if (crowd && lane < (RZ_BIN / 16) * (RZ_BIN / 8)) {
+        const uint32_t block_x = (uint32_t)bin_x0 / 16u + (uint32_t)lane % (RZ_BIN / 16u), block_y = (uint32_t)bin_y0 / 8u + (uint32_t)lane / (RZ_BIN / 16u);
+        if ((int)(block_x * 16u) < P.width && (int)(block_y * 8u) < P.height) {
+            const uint32_t way = RZ_CROWD_LIST * RZ_QUEUE_WAYS + ((block_y * 2u * (uint32_t)P.tiles_x + block_x) & (RZ_QUEUE_WAYS - 1u));
+            const uint32_t at = atomicAdd(&P.queue_counts[way * RZ_QUEUE_PAD], 1u);
+            if (at < P.queue_capacity)
+                P.queue[(size_t)way * P.queue_capacity + at] = RZ_BLOCK_ITEM(blockIdx.y, block_y, block_x);
+            else
+                atomicOr(&P.control[2], (uint32_t)RZ_ERR_QUEUE_OVERFLOW);
+        }
+    }
     if (P.sky_draws == 0) {
         if (range.y != 0u || !(P.clear_color_pending || P.clear_depth_pending)) return;
         const float d = P.clear_depth;
@@ -777,7 +792,6 @@ RZ_DEV uint32_t ref_tag(uint32_t meta) { return RZ_META_BLACK(meta) ? 3u : RZ_ME
 /* What a wave of rz_strip_kernel does with a finished block of 16x8 pixels: depth, the clear colour where no
  * fragment is, black (draw_fragment keeps the buffer's alpha byte, graphics.c:466-468) where a shadow pass's
  * fragment is, and -- for blocks that hold fragments to shade -- the references. */
-#define RZ_BLOCK_ITEM(pass, by, bx) (((uint32_t)(pass) << 21) | ((uint32_t)(by) << 10) | (uint32_t)(bx))
 RZ_DEV void finish_block(const PassParams &P, uint32_t pass_index, int bx0, int by0, int lane,
                          const bool valid[2], const uint32_t pixel[2], const float zcur[2], const uint32_t ref_of[2]) {
     constexpr int PPL = 2;
@@ -817,81 +831,30 @@ RZ_DEV void finish_block(const PassParams &P, uint32_t pass_index, int bx0, int 
     }
 }
 
-/* K4c  visibility for passes without blending: coverage + depth, leaves depth and one fragment reference per
- * pixel.  A wave owns blocks of 16x8 pixels (lane = the pixel at (lane & 7, lane >> 3) and the one 8 to its right:
- * half the waves walk the lists, cull candidates and fetch survivors compared with one pixel per lane), a STRIP of
- * them per wave.
- *
- * With one block per wave a wave spends its time waiting: it lives for some 14 000 cycles and issues 700
- * instructions, the rest is a chain of dependent memory round trips (the pass's parameters, the bin's
- * range, the list's first entries, the surviving entries, the stores), paid by every wave for 128
- * pixels.  Here a wave keeps its 16-pixel column and takes STRIP blocks of 16x8 pixels one above the
- * other inside one bin -- same list, same parameters -- so the chain is paid once per 128 * STRIP
- * pixels; a list of up to 64 entries (any bin that holds only sky) stays in the lanes' registers for
- * the whole strip.  The first group of the next block's candidates is requested before the current
- * block's epilogue, which hides its latency behind the epilogue's arithmetic.
- *
- * How tall a strip should be depends on the lists.  Where they are short the fixed costs of a wave and of
- * starting its workgroup count; with the sky box in the bins (every bin of the frame a list of a dozen entries)
- * tall strips won (helmet at 1080p, longest list 700 entries: 12.9 / 12.5 / 11.7 us per frame with 1 / 2 / 4
- * blocks).  With the sky box on its own table only the bins a model touches have strips at all, a scene of a few
- * thousand triangles has fewer waves than the device holds, and shorter strips finish sooner (helmet 6.4 / 6.6 /
- * 7.0 us; kgirl at 1080p, 32 passes: 43.0 / 43.9 / 40.6 thousand frames per second): two blocks is the default.  A long list makes
- * the blocks themselves expensive: then four times as many waves, each a quarter as long, fill the
- * device better and leave a shorter tail (azura at 800x600, a few bins of 10 000 entries and more: 19.2 /
- * 30.6 / 46.8 us).  The host picks STRIP per batch from the longest list its framebuffers had in their
- * last frame (control word 4, rz_bin_scan_kernel).  Deciding per bin inside one launch -- a workgroup
- * per block, all but the first of a strip leaving at once where the list is short -- gave the long lists
- * their waves but cost the short ones the workgroup starts again (helmet 11.9 -> 14.0 us).
- *
- * The epilogue writes depth and, for blocks that hold blinn or pbr fragments, the references; such a block is
- * appended to its family's work list (16x8 blocks, not 32x8 tiles: the wave that owns the block is the only one
- * to list it).  Skybox fragments are rz_sky_kernel's: it looks at the references of every pixel outside the bins
- * it resolves itself, so in a batch with a sky box the references of all blocks are written. */
 #ifdef RZ_PROBE
 #define RZ_PROBE_WORDS 12
 #define RZ_PROBE_MAX (1 << 19)
 __device__ unsigned long long rz_probe_data[RZ_PROBE_WORDS * RZ_PROBE_MAX];
 __device__ unsigned int rz_probe_count;
 #endif
-template <int STRIP>
-__global__ void __launch_bounds__(128) rz_strip_kernel(const PassParams *__restrict__ passes,
-        const BinEntry *__restrict__ list_base, const uint2 *__restrict__ box_base,
-        const float *__restrict__ vary_base, const float *__restrict__ fan_vary_base,
-        const char *__restrict__ upload_base, const uint2 *__restrict__ bin_range_base,
-        const uint32_t *__restrict__ class_base, int uniform_width, int uniform_height) {
+/* The walk of rz_strip_kernel (see there): STRIP blocks of 16x8 pixels one above the other from (bx0, sy0) down, all in
+ * the bin whose list is given.  SPLIT > 1: the workgroup's waves share ONE block (STRIP == 1) -- wave `part` takes
+ * the list's groups of 64 entries part, part + SPLIT, ... -- and their results meet in `merged`, a key per pixel.  Which
+ * fragment a pixel ends up with does not depend on the order the triangles are taken in (least depth, the latest in
+ * submission order among equals), so any cut of the list gives the same picture. */
+template <int STRIP, int SPLIT>
+RZ_DEV void strip_walk(const PassParams &P, uint32_t pass_index, int probe_bin, const BinEntry *__restrict__ list, const uint2 *__restrict__ boxes, uint32_t count,
+                       const float *__restrict__ vary_table, const float *__restrict__ fan_vary_table, const DrawRec *__restrict__ draw_table,
+                       int bx0, int sy0, int lane, int part, unsigned long long *keys, uint32_t *ring, unsigned long long *merged) {
     constexpr int PPL = 2;
-    static_assert(RZ_BIN % (8 * STRIP) == 0, "a strip lies inside one bin");
-    const TileOrder o = tile_order(RZ_BIN / (8 * STRIP));
-    const uint32_t pass_index = o.pass, tile_column = o.column, strip_row = o.row;
-    const int sy0 = (int)strip_row * 8 * STRIP, tx0 = (int)tile_column * RZ_TILE_W;
-    /* the passes of the batch have one size (uniform_width != 0): what the bin's class says is known before the pass's
-     * parameters are asked for, and most strips of most frames end here */
-    if (uniform_width) {
-        if (tx0 >= uniform_width || sy0 >= uniform_height) return;
-        const uint32_t bins_x = ((uint32_t)uniform_width + RZ_BIN - 1u) / RZ_BIN, bins_y = ((uint32_t)uniform_height + RZ_BIN - 1u) / RZ_BIN;
-        if (class_base[pass_index * (bins_x * bins_y) + (uint32_t)(sy0 / RZ_BIN) * bins_x + (uint32_t)(tx0 / RZ_BIN)] != (uint32_t)RZ_BIN_STRIP) return;
-    }
-    const PassParams P = passes[pass_index];
-    if ((int)tile_column >= P.tiles_x || sy0 >= P.height) return;
-    const BinEntry *list_table = list_base + P.list_off;
-    const float *vary_table = vary_base + (size_t)P.tri_off * 3 * RZ_VARY_STRIDE;
-    const float *fan_vary_table = fan_vary_base + (size_t)P.fan_off * RZ_MAX_POLY * RZ_VARY_STRIDE;
-    const DrawRec *draw_table = (const DrawRec*)(upload_base + P.draws_off);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int bx0 = tx0 + wave * 8 * PPL, bx1 = bx0 + 8 * PPL - 1;
+    static_assert(SPLIT == 1 || STRIP == 1, "waves share one block");
+    const int bx1 = bx0 + 8 * PPL - 1;
     int px[PPL];
     for (int q = 0; q < PPL; q++) px[q] = bx0 + 8 * q + (lane & 7);
-    const int bin = (sy0 / RZ_BIN) * P.bins_x + tx0 / RZ_BIN;
-    const uint2 range = (bin_range_base + P.bin_off)[bin];          /* {first entry, entries} */
-    if (!uniform_width && class_base[P.bin_off + (uint32_t)bin] != (uint32_t)RZ_BIN_STRIP) return;
-    const uint32_t count = range.y;                                 /* (a bin of this class is not empty) */
 #ifdef RZ_PROBE
     const unsigned long long probe_t0 = wall_clock64();
     unsigned long long probe_ordered = 0, probe_ring = 0, probe_groups = 0, probe_hits = 0, probe_survivors = 0, probe_cutoffs = 0, probe_batches = 0, probe_small = 0;
 #endif
-    const BinEntry *list = list_table + range.x;
-    const uint2 *boxes = box_base + P.list_off + range.x;
 
     /* Small triangles.  Which fragment a pixel ends up with does not depend on the order the
      * triangles are taken in: it is the one of least depth, the latest in submission order among
@@ -902,10 +865,6 @@ __global__ void __launch_bounds__(128) rz_strip_kernel(const PassParams *__restr
      * the list position, so that an atomic minimum keeps exactly that fragment.  The keys meet the
      * registers of the one-triangle-per-step path when the list ends.  Triangles with an alpha
      * cutoff and passes that count fragments stay on the ordered path. */
-    __shared__ unsigned long long micro_keys[256];
-    __shared__ uint32_t micro_ring[2][128];
-    unsigned long long *keys = micro_keys + wave * 64 * PPL;
-    uint32_t *ring = micro_ring[wave];
     const int micro_area = (P.counters || count < (uint32_t)P.micro_min_list) ? 0 : P.micro_area;
     const int sx1 = min(bx1, P.width - 1);
 
@@ -919,11 +878,12 @@ __global__ void __launch_bounds__(128) rz_strip_kernel(const PassParams *__restr
     float4 n0 = make_float4(0, 0, 0, 0), n1 = n0;
     uint2 nbox = make_uint2(RZ_BBOX_EMPTY_X, 0u);
     auto request_first_group = [&]() {
-        if ((uint32_t)lane < count) {
+        const uint32_t first = (uint32_t)part * 64u + (uint32_t)lane;
+        if (first < count) {
             if (long_list) {
-                nbox = boxes[lane];
+                nbox = boxes[first];
             } else {
-                const float4 *e = (const float4*)&list[lane];          /* reference + record, 80 bytes */
+                const float4 *e = (const float4*)&list[first];         /* reference + record, 80 bytes */
                 n0 = e[1]; n1 = e[2];
                 nbox = entry_box(e[4]);
             }
@@ -989,13 +949,13 @@ __global__ void __launch_bounds__(128) rz_strip_kernel(const PassParams *__restr
         /* block corners at pixel centres, for the conservative triangle/block test */
         const float cx0 = (float)bx0 + 0.5f, cx1 = (float)bx1 + 0.5f, cy0 = (float)by0 + 0.5f, cy1 = (float)by0 + 7.5f;
 
-        for (uint32_t base = 0; base < count;) {
+        for (uint32_t base = (uint32_t)part * 64u; base < count;) {
             const uint2 cbox = nbox;
             float4 c0 = n0, c1 = n1;
             const bool present = base + lane < count;
             const BinEntry *group = list + base;
             const uint32_t group_at = base;
-            base += 64u;
+            base += 64u * SPLIT;
             if (base + lane < count) {
                 if (long_list) {
                     nbox = boxes[base + lane];
@@ -1130,16 +1090,146 @@ __global__ void __launch_bounds__(128) rz_strip_kernel(const PassParams *__restr
         /* the next block's first candidates: on their way while this block's epilogue runs */
         if (count > 64u && k + 1 < STRIP) request_first_group();
 
-        finish_block(P, pass_index, bx0, by0, lane, valid, pixel, zcur, ref_of);
+        if constexpr (SPLIT > 1) {
+            /* the waves' fragments meet: depth (as an order-preserving integer) above the complement of the list position,
+             * as the small triangles' keys above; the first wave takes what the minimum kept */
+            if (part == 0) for (int q = 0; q < PPL; q++) merged[q * 64 + lane] = ~0ull;
+            __syncthreads();
+            for (int q = 0; q < PPL; q++) {
+                if (ord_of[q] < 0) continue;
+                const uint32_t bits = __float_as_uint(zcur[q] + 0.0f);
+                const uint32_t up = bits ^ ((uint32_t)((int32_t)bits >> 31) | 0x80000000u);
+                atomicMin(&merged[q * 64 + lane], ((unsigned long long)up << 32) | (uint32_t)~(uint32_t)ord_of[q]);
+            }
+            __syncthreads();
+            if (part == 0) {
+                for (int q = 0; q < PPL; q++) {
+                    const unsigned long long key = merged[q * 64 + lane];
+                    if (key == ~0ull) continue;                     /* no fragment: zcur[q] is what the buffer held */
+                    const uint32_t up = (uint32_t)(key >> 32);
+                    const int ord = (int)~(uint32_t)key;
+                    if (ord == ord_of[q]) continue;                 /* this wave's own */
+                    const BinEntry *e = &list[ord];
+                    zcur[q] = __uint_as_float(up ^ ((up >> 31) ? 0x80000000u : 0xffffffffu));
+                    ref_of[q] = e->tri | (ref_tag(e->rec.meta) << 28);
+                }
+                finish_block(P, pass_index, bx0, by0, lane, valid, pixel, zcur, ref_of);
+            }
+        } else {
+            finish_block(P, pass_index, bx0, by0, lane, valid, pixel, zcur, ref_of);
+        }
     }
 #ifdef RZ_PROBE
     if (lane == 0) {
         const unsigned int at = atomicAdd(&rz_probe_count, 1u);
         if (at < RZ_PROBE_MAX) {
             unsigned long long *o = rz_probe_data + (size_t)at * RZ_PROBE_WORDS;
-            o[0] = pass_index; o[1] = (unsigned long long)bin; o[2] = count; o[3] = probe_groups; o[4] = probe_survivors; o[5] = probe_cutoffs;
+            o[0] = pass_index; o[1] = (unsigned long long)probe_bin; o[2] = count; o[3] = probe_groups; o[4] = probe_survivors; o[5] = probe_cutoffs;
             o[6] = probe_batches; o[7] = wall_clock64() - probe_t0; o[8] = probe_ordered; o[9] = probe_ring; o[10] = probe_small; o[11] = probe_t0;
         }
     }
 #endif
+}
+
+/* K4c  visibility for passes without blending: coverage + depth, leaves depth and one fragment reference per
+ * pixel.  A wave owns blocks of 16x8 pixels (lane = the pixel at (lane & 7, lane >> 3) and the one 8 to its right:
+ * half the waves walk the lists, cull candidates and fetch survivors compared with one pixel per lane), a STRIP of
+ * them per wave.
+ *
+ * With one block per wave a wave spends its time waiting: it lives for some 14 000 cycles and issues 700
+ * instructions, the rest is a chain of dependent memory round trips (the pass's parameters, the bin's
+ * range, the list's first entries, the surviving entries, the stores), paid by every wave for 128
+ * pixels.  Here a wave keeps its 16-pixel column and takes STRIP blocks of 16x8 pixels one above the
+ * other inside one bin -- same list, same parameters -- so the chain is paid once per 128 * STRIP
+ * pixels; a list of up to 64 entries (any bin that holds only sky) stays in the lanes' registers for
+ * the whole strip.  The first group of the next block's candidates is requested before the current
+ * block's epilogue, which hides its latency behind the epilogue's arithmetic.
+ *
+ * How tall a strip should be depends on the lists.  Where they are short the fixed costs of a wave and of
+ * starting its workgroup count; with the sky box in the bins (every bin of the frame a list of a dozen entries)
+ * tall strips won (helmet at 1080p, longest list 700 entries: 12.9 / 12.5 / 11.7 us per frame with 1 / 2 / 4
+ * blocks).  With the sky box on its own table only the bins a model touches have strips at all, a scene of a few
+ * thousand triangles has fewer waves than the device holds, and shorter strips finish sooner (helmet 6.4 / 6.6 /
+ * 7.0 us; kgirl at 1080p, 32 passes: 43.0 / 43.9 / 40.6 thousand frames per second): two blocks is the default.  A long list makes
+ * the blocks themselves expensive: then four times as many waves, each a quarter as long, fill the
+ * device better and leave a shorter tail (azura at 800x600, a few bins of 10 000 entries and more: 19.2 /
+ * 30.6 / 46.8 us).  The host picks STRIP per batch from the longest list its framebuffers had in their
+ * last frame (control word 4, rz_bin_scan_kernel).  Deciding per bin inside one launch -- a workgroup
+ * per block, all but the first of a strip leaving at once where the list is short -- gave the long lists
+ * their waves but cost the short ones the workgroup starts again (helmet 11.9 -> 14.0 us).
+ *
+ * The epilogue writes depth and, for blocks that hold blinn or pbr fragments, the references; such a block is
+ * appended to its family's work list (16x8 blocks, not 32x8 tiles: the wave that owns the block is the only one
+ * to list it).  Skybox fragments are rz_sky_kernel's: it looks at the references of every pixel outside the bins
+ * it resolves itself, so in a batch with a sky box the references of all blocks are written. */
+template <int STRIP>
+__global__ void __launch_bounds__(128) rz_strip_kernel(const PassParams *__restrict__ passes,
+        const BinEntry *__restrict__ list_base, const uint2 *__restrict__ box_base,
+        const float *__restrict__ vary_base, const float *__restrict__ fan_vary_base,
+        const char *__restrict__ upload_base, const uint2 *__restrict__ bin_range_base,
+        const uint32_t *__restrict__ class_base, int uniform_width, int uniform_height) {
+    constexpr int PPL = 2;
+    static_assert(RZ_BIN % (8 * STRIP) == 0, "a strip lies inside one bin");
+    const TileOrder o = tile_order(RZ_BIN / (8 * STRIP));
+    const uint32_t pass_index = o.pass, tile_column = o.column, strip_row = o.row;
+    const int sy0 = (int)strip_row * 8 * STRIP, tx0 = (int)tile_column * RZ_TILE_W;
+    /* the passes of the batch have one size (uniform_width != 0): what the bin's class says is known before the pass's
+     * parameters are asked for, and most strips of most frames end here */
+    if (uniform_width) {
+        if (tx0 >= uniform_width || sy0 >= uniform_height) return;
+        const uint32_t bins_x = ((uint32_t)uniform_width + RZ_BIN - 1u) / RZ_BIN, bins_y = ((uint32_t)uniform_height + RZ_BIN - 1u) / RZ_BIN;
+        if (class_base[pass_index * (bins_x * bins_y) + (uint32_t)(sy0 / RZ_BIN) * bins_x + (uint32_t)(tx0 / RZ_BIN)] != (uint32_t)RZ_BIN_STRIP) return;
+    }
+    const PassParams P = passes[pass_index];
+    if ((int)tile_column >= P.tiles_x || sy0 >= P.height) return;
+    const BinEntry *list_table = list_base + P.list_off;
+    const float *vary_table = vary_base + (size_t)P.tri_off * 3 * RZ_VARY_STRIDE;
+    const float *fan_vary_table = fan_vary_base + (size_t)P.fan_off * RZ_MAX_POLY * RZ_VARY_STRIDE;
+    const DrawRec *draw_table = (const DrawRec*)(upload_base + P.draws_off);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int bin = (sy0 / RZ_BIN) * P.bins_x + tx0 / RZ_BIN;
+    const uint2 range = (bin_range_base + P.bin_off)[bin];          /* {first entry, entries} */
+    if (!uniform_width && class_base[P.bin_off + (uint32_t)bin] != (uint32_t)RZ_BIN_STRIP) return;
+    __shared__ unsigned long long micro_keys[256];
+    __shared__ uint32_t micro_ring[2][128];
+    strip_walk<STRIP, 1>(P, pass_index, bin, list_table + range.x, box_base + P.list_off + range.x, range.y /* (a bin of this class is not empty) */,
+                         vary_table, fan_vary_table, draw_table, tx0 + wave * 16, sy0, lane, 0, micro_keys + wave * 128, micro_ring[wave], nullptr);
+}
+
+/* Crowded bins.  A launch of rz_strip_kernel is as long as its longest wave, and a bin that holds the better part of a
+ * mesh -- a head of hair in a few bins of 10 000 entries and more -- keeps 32 waves busy for the whole launch while the
+ * rest of the device drains.  rz_bin_class_kernel puts the 16x8 blocks of such bins on a work list of their own, and here
+ * the SPLIT waves of a workgroup share a block's list between them; the launch runs beside the strips, on the lane's side
+ * stream. */
+template <int SPLIT>
+__global__ void __launch_bounds__(64 * SPLIT) rz_crowd_kernel(const PassParams *__restrict__ passes,
+        const BinEntry *__restrict__ list_base, const uint2 *__restrict__ box_base,
+        const float *__restrict__ vary_base, const float *__restrict__ fan_vary_base,
+        const char *__restrict__ upload_base, const uint2 *__restrict__ bin_range_base,
+        const uint32_t *__restrict__ queue_base, const uint32_t *__restrict__ queue_counts, uint32_t queue_capacity) {
+    __shared__ unsigned long long micro_keys[SPLIT][128];
+    __shared__ uint32_t micro_ring[SPLIT][128];
+    __shared__ unsigned long long merged[128];
+    const int lane = threadIdx.x & 63, wave = (int)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t my_count = min(queue_counts[(RZ_CROWD_LIST * RZ_QUEUE_WAYS + (uint32_t)lane) * RZ_QUEUE_PAD], queue_capacity);
+    /* The list's parts are dealt by a block's place on the screen, and crowded bins are a few places: most parts are
+     * empty, a few long.  The workgroups therefore stride over the parts laid end to end (lane = part: a prefix over the
+     * lanes says where each starts), not over every part in step -- striding part by part, one workgroup in eight did all
+     * the work. */
+    uint32_t total;
+    const uint32_t before = wave_exclusive_scan(my_count, &total);
+    for (uint32_t j = blockIdx.x; j < total; j += gridDim.x) {
+        const int way = 63 - __clzll((long long)__ballot(before <= j));      /* the last part that starts at or before j (uniform) */
+        const uint32_t index = j - (uint32_t)__builtin_amdgcn_readlane((int)before, way);
+        const uint32_t item = queue_base[(size_t)(RZ_CROWD_LIST * RZ_QUEUE_WAYS + (uint32_t)way) * queue_capacity + index];
+        const uint32_t pass_index = item >> 21;
+        const PassParams P = passes[pass_index];
+        const int bx0 = (int)(item & 1023u) * 16, by0 = (int)((item >> 10) & 2047u) * 8;
+        const int bin = (by0 / RZ_BIN) * P.bins_x + bx0 / RZ_BIN;
+        const uint2 range = (bin_range_base + P.bin_off)[bin];
+        strip_walk<1, SPLIT>(P, pass_index, bin, list_base + P.list_off + range.x, box_base + P.list_off + range.x, range.y,
+                             vary_base + (size_t)P.tri_off * 3 * RZ_VARY_STRIDE, fan_vary_base + (size_t)P.fan_off * RZ_MAX_POLY * RZ_VARY_STRIDE,
+                             (const DrawRec*)(upload_base + P.draws_off), bx0, by0, lane, wave, micro_keys[wave], micro_ring[wave], merged);
+        __syncthreads();            /* (the first wave has read `merged` before any wave sets it up again) */
+    }
 }

@@ -58,7 +58,8 @@ enum { RZ_PV_WORLD = 0, RZ_PV_NORMAL = 3, RZ_PV_TANGENT = 6, RZ_PV_BITANGENT = 9
 #define RZ_VISIBILITY_LIST 3u       /* the fourth: tiles of such a pass that rz_blend_visibility_kernel has to look at */
 #define RZ_SKY_LIST 4u              /* the fifth: blocks with skybox fragments that came through the bins (a sky box that is not on the
                                      * pass's table: more than 12 triangles, not drawn last, fragments being counted) */
-#define RZ_LISTS 5u
+#define RZ_CROWD_LIST 5u            /* the sixth: the blocks of crowded bins, rz_crowd_kernel's */
+#define RZ_LISTS 6u
 /* the table of a pass's sky boxes: up to RZ_SKY_DRAWS draws of up to RZ_SKY_FACES triangles, RZ_MAX_FAN entries each -- the
  * triangle's index, RZ_REF_FAN | its fan records', or RZ_REF_NONE --, in submission order */
 #define RZ_SKY_DRAWS 4
@@ -215,7 +216,7 @@ struct PassParams {
      * used, [2] error bits, [3] triangles queued for clipping */
     rz_gptr<uint32_t> control;
     rz_gptr<unsigned long long> counters;   /* nullptr unless counting is enabled */
-    int32_t reserved_;
+    int32_t crowd_min;              /* bins with at least this many list entries are rz_crowd_kernel's (0: none are) */
     int32_t micro_area;             /* triangles whose box covers at most this many pixels of a wave's block
                                      * are rasterised one per lane; 0 = none */
     int32_t micro_min_list;         /* ... in bins whose list has at least this many entries */

@@ -140,7 +140,7 @@ sys.exit(0 if bad == 0 else 1)
 @pytest.mark.gpu
 @pytest.mark.parametrize("env", [{"MI355R_PACK": "0"}, {"MI355R_LANES": "1", "MI355R_BATCH": "1"},
                                  {"MI355R_MICRO_AREA": "0"}, {"MI355R_MICRO_MIN_LIST": "0"}, {"MI355R_RECORD_COPIES": "0"},
-                                 {"MI355R_STRIP": "4"}, {"MI355R_SKY_TABLE": "0"}, {"MI355R_FILL_WAVES": "4"}, {"MI355R_BUNDLE": "0"}, {"MI355R_SKY_SIDE": "0"}, {"MI355R_SKY_BYTES": "0"}, {"MI355R_STRIP": "2"},
+                                 {"MI355R_STRIP": "4"}, {"MI355R_SKY_TABLE": "0"}, {"MI355R_FILL_WAVES": "4"}, {"MI355R_BUNDLE": "0"}, {"MI355R_SKY_SIDE": "0"}, {"MI355R_CROWD_MIN": "200"}, {"MI355R_CROWD_MIN": "300", "MI355R_CROWD_SPLIT": "2"}, {"MI355R_CROWD_MIN": "0"}, {"MI355R_SKY_BYTES": "0"}, {"MI355R_STRIP": "2"},
                                  {"MI355R_STRIP_LONG": "1"}, {"MI355R_STRIP_LONG": "600"}, {"MI355R_STRIP": "1", "MI355R_MICRO_MIN_LIST": "0"},
                                  {"MI355R_SPLIT_BLEND": "0"}, {"MI355R_SPLIT_BLEND": "1"},
                                  {"MI355R_MICRO_MIN_LIST": "0", "MI355R_MICRO_AREA": "128"}],
