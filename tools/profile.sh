@@ -12,6 +12,8 @@ export TMPDIR=/tmp
 # one kernel at a time: a batch's sky kernel in line, not beside its shade kernels (counters of kernels that run side by side
 # cannot be told apart, and their durations stretch)
 export MI355R_SKY_SIDE=0
+# ... and crowded bins in their strips, not in rz_crowd_kernel beside them (azura: 3 % slower than the default)
+export MI355R_CROWD_MIN=0
 if [ "$CONFIG" = C2 ]; then
     BENCH="python3 bench.py --steps 3 --warmup 1 --frames 32 --no-cpu --no-other"
 else
