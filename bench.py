@@ -103,7 +103,7 @@ def committed_counters(label, symbol):
     return json.load(open(path)).get("kernels", {}).get(symbol, {})
 
 
-RASTER_KERNELS = ("rz_strip_kernel", "rz_raster_list_kernel", "rz_blend_visibility_kernel")
+RASTER_KERNELS = ("rz_strip_kernel", "rz_strip_team_kernel", "rz_raster_list_kernel", "rz_blend_visibility_kernel")
 
 
 def raster_symbol(label, last_launched):

@@ -149,6 +149,8 @@ struct Context {
     bool crowd_always = false;              /* (set with MI355R_CROWD_MIN: also for framebuffers whose last frame is not known to have had such a bin) */
     int crowd_split = 4;                    /* MI355R_CROWD_SPLIT: that many (2, 4, 8, 16) */
     bool sky_side = true;                   /* MI355R_SKY_SIDE=0: the sky kernel runs in line, on its batch's own stream */
+    bool strip_team = true;                 /* MI355R_STRIP_TEAM=0: a launch of at most two passes takes the plain strips, not two waves per block (rz_strip_team_kernel) */
+    bool sky_with_strips = true;            /* MI355R_SKY_WITH_STRIPS=0: ... and that launch leaves the sky of empty bins to rz_sky_kernel */
     bool sky_table = true;                  /* MI355R_SKY_TABLE=0: a sky box goes through the bins like any other draw */
     int fill_waves = 0;                     /* MI355R_FILL_WAVES: waves that share a chunk of 64 triangles in rz_bin_fill_kernel (1, 2, 4; unset: by the launch's size) */
     unsigned strip_long = 2048;             /* MI355R_STRIP_LONG: a batch whose framebuffers had a bin list of this many entries in their last frame takes one block per wave,
@@ -307,6 +309,8 @@ extern "C" int mi355r_init(int device) {
     }
     for (int i = 0; i < g.num_lanes; i++) HIP_OK(hipStreamCreateWithFlags(&g.lanes[i].stream, hipStreamNonBlocking));
     if (const char *env = getenv("MI355R_SKY_SIDE")) g.sky_side = atoi(env) != 0;
+    if (const char *env = getenv("MI355R_STRIP_TEAM")) g.strip_team = atoi(env) != 0;
+    if (const char *env = getenv("MI355R_SKY_WITH_STRIPS")) g.sky_with_strips = atoi(env) != 0;
     if (const char *env = getenv("MI355R_CROWD_MIN")) { g.crowd_min = std::max(0, atoi(env)); g.crowd_always = true; }
     if (const char *env = getenv("MI355R_CROWD_SPLIT")) { const int v = atoi(env); if (v == 2 || v == 4 || v == 8 || v == 16) g.crowd_split = v; }
     for (int i = 0; i < g.num_lanes && (g.sky_side || g.crowd_min > 0); i++) {

@@ -434,6 +434,7 @@ static void launch_batch(const Batch &b, const std::vector<PassPlan> &plans, cha
     const int only = b.families == (1 << RZ_FAMILY_BLINN) ? 0 : b.families == (1 << RZ_FAMILY_PBR) ? 1 : -1;
     bool in_strips = false;                         /* the shade lists hold 16x8 blocks */
     bool crowd_forked = false;
+    bool sky_with_strips = false;                   /* the strips' launch takes the sky of empty bins along */
     if (b.has_blend && !splits_blend(batch_tiles, n)) {
         /* over the tiles of the bins that are not empty (listed by rz_bin_scan_kernel) */
         auto kernel = rz_raster_list_kernel<-1, false>;
@@ -472,6 +473,10 @@ static void launch_batch(const Batch &b, const std::vector<PassPlan> &plans, cha
                                                                              L.sky_bins.ptr, L.bin_class.ptr);
             if (g.verbose) fprintf(stderr, "mi355r: batch of %u passes, longest bin list last time %u entries, strips of %d\n", n, longest, strip);
             snprintf(g.last_raster_kernel, sizeof g.last_raster_kernel, "rz_strip_kernel<%d>", strip);
+            /* a launch of a frame or two: a team of waves per block, the sky of empty bins in the same launch
+             * (fragment counts follow the order the triangles are taken in: no teams while they are kept) */
+            const bool team = strip == 1 && b.members.size() <= 2 && !g.counting && g.strip_team;
+            sky_with_strips = team && b.sky_table && g.sky_with_strips && !g.timing;
             /* passes of one size: a strip then finds its bin's class without reading its pass's parameters */
             int uniform_w = plans[b.members[0]].fb->pub.width, uniform_h = plans[b.members[0]].fb->pub.height;
             for (size_t i : b.members)
@@ -486,8 +491,16 @@ static void launch_batch(const Batch &b, const std::vector<PassPlan> &plans, cha
                 HIP_OK(hipEventRecord(L.join, L.side));
                 crowd_forked = true;
             }
-            kernel<<<dim3(n, bin_columns * 2, bin_rows * strips_per_bin), dim3(128), 0, st>>>(
-                passes, L.bin_list.ptr, L.bin_boxes.ptr, L.vary.ptr, L.fan_vary.ptr, db, L.bin_range.ptr, L.bin_class.ptr, uniform_w, uniform_h);
+            if (team) {
+                snprintf(g.last_raster_kernel, sizeof g.last_raster_kernel, "rz_strip_team_kernel<2>");
+                SkyTables sky;
+                sky.tri_base = L.tri.ptr; sky.fan_base = L.fan_tri.ptr; sky.sky_base = sky_with_strips ? L.sky_bins.ptr : nullptr;
+                rz_strip_team_kernel<2><<<dim3(n, bin_columns * 2, bin_rows * strips_per_bin), dim3(256), 0, st>>>(
+                    passes, L.bin_list.ptr, L.bin_boxes.ptr, L.vary.ptr, L.fan_vary.ptr, db, L.bin_range.ptr, L.bin_class.ptr, uniform_w, uniform_h, sky);
+            } else {
+                kernel<<<dim3(n, bin_columns * 2, bin_rows * strips_per_bin), dim3(128), 0, st>>>(
+                    passes, L.bin_list.ptr, L.bin_boxes.ptr, L.vary.ptr, L.fan_vary.ptr, db, L.bin_range.ptr, L.bin_class.ptr, uniform_w, uniform_h);
+            }
         }
         stamp();
         if (crowd_forked) HIP_OK(hipStreamWaitEvent(st, L.join, 0));
@@ -502,7 +515,8 @@ static void launch_batch(const Batch &b, const std::vector<PassPlan> &plans, cha
                 sky_stream = L.side;
                 forked = true;
             }
-            rz_sky_kernel<2><<<tiles, dim3(128), 0, sky_stream>>>(passes, L.tri.ptr, L.fan_tri.ptr, L.vary.ptr, L.fan_vary.ptr, db, L.sky_bins.ptr);
+            rz_sky_kernel<2><<<tiles, dim3(128), 0, sky_stream>>>(passes, L.tri.ptr, L.fan_tri.ptr, L.vary.ptr, L.fan_vary.ptr, db, L.sky_bins.ptr,
+                                                                  sky_with_strips ? (int)RZ_SKY_STALE_ONLY : (int)RZ_SKY_ALL);
             if (forked) HIP_OK(hipEventRecord(L.join, L.side));
         }
         if (b.families & (1 << RZ_FAMILY_SKYBOX)) {     /* skybox fragments that came through the bins */

@@ -1162,23 +1162,45 @@ RZ_DEV void strip_walk(const PassParams &P, uint32_t pass_index, int probe_bin, 
  * appended to its family's work list (16x8 blocks, not 32x8 tiles: the wave that owns the block is the only one
  * to list it).  Skybox fragments are rz_sky_kernel's: it looks at the references of every pixel outside the bins
  * it resolves itself, so in a batch with a sky box the references of all blocks are written. */
-template <int STRIP>
-__global__ void __launch_bounds__(128) rz_strip_kernel(const PassParams *__restrict__ passes,
+template <int PPL>
+RZ_DEV void sky_tile(const PassParams &P, int tile_x, int tile_y, int wave, int lane, int which,
+        const TriRec *__restrict__ tri_base, const TriRec *__restrict__ fan_base,
+        const float *__restrict__ vary_base, const float *__restrict__ fan_vary_base,
+        const char *__restrict__ upload_base, const SkyBin *__restrict__ sky_base);
+/* (for a workgroup of rz_strip_team_kernel whose bin is empty: what the sky of its tile is read from, see sky_tile) */
+struct SkyTables { const TriRec *tri_base, *fan_base; const SkyBin *sky_base; };
+
+/* a workgroup of the strip kernels: two strips side by side (a 32-pixel tile column), SPLIT waves to each */
+template <int STRIP, int SPLIT, bool SKY>
+RZ_DEV void strips_of_workgroup(const PassParams *__restrict__ passes,
         const BinEntry *__restrict__ list_base, const uint2 *__restrict__ box_base,
         const float *__restrict__ vary_base, const float *__restrict__ fan_vary_base,
         const char *__restrict__ upload_base, const uint2 *__restrict__ bin_range_base,
-        const uint32_t *__restrict__ class_base, int uniform_width, int uniform_height) {
-    constexpr int PPL = 2;
+        const uint32_t *__restrict__ class_base, int uniform_width, int uniform_height, SkyTables sky) {
     static_assert(RZ_BIN % (8 * STRIP) == 0, "a strip lies inside one bin");
+    static_assert(!SKY || STRIP == 1, "a workgroup's strips cover one tile");
     const TileOrder o = tile_order(RZ_BIN / (8 * STRIP));
     const uint32_t pass_index = o.pass, tile_column = o.column, strip_row = o.row;
     const int sy0 = (int)strip_row * 8 * STRIP, tx0 = (int)tile_column * RZ_TILE_W;
+    const int lane = threadIdx.x & 63, wave = (int)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    /* an empty bin's tile: its sky, by the workgroup's first two waves */
+    auto sky_of_tile = [&](const PassParams &P) {
+        if constexpr (SKY) {
+            if (sky.sky_base && wave < 2 && P.sky_draws != 0 && (int)tile_column < P.tiles_x && (int)strip_row < P.tiles_y)
+                sky_tile<2>(P, (int)tile_column, (int)strip_row, wave, lane, 1 /* RZ_SKY_FRESH_ONLY */,
+                            sky.tri_base, sky.fan_base, vary_base, fan_vary_base, upload_base, sky.sky_base);
+        }
+    };
     /* the passes of the batch have one size (uniform_width != 0): what the bin's class says is known before the pass's
      * parameters are asked for, and most strips of most frames end here */
     if (uniform_width) {
         if (tx0 >= uniform_width || sy0 >= uniform_height) return;
         const uint32_t bins_x = ((uint32_t)uniform_width + RZ_BIN - 1u) / RZ_BIN, bins_y = ((uint32_t)uniform_height + RZ_BIN - 1u) / RZ_BIN;
-        if (class_base[pass_index * (bins_x * bins_y) + (uint32_t)(sy0 / RZ_BIN) * bins_x + (uint32_t)(tx0 / RZ_BIN)] != (uint32_t)RZ_BIN_STRIP) return;
+        const uint32_t bin_class = class_base[pass_index * (bins_x * bins_y) + (uint32_t)(sy0 / RZ_BIN) * bins_x + (uint32_t)(tx0 / RZ_BIN)];
+        if (bin_class != (uint32_t)RZ_BIN_STRIP) {
+            if (SKY && sky.sky_base && wave < 2 && bin_class == (uint32_t)RZ_BIN_DONE) sky_of_tile(passes[pass_index]);
+            return;
+        }
     }
     const PassParams P = passes[pass_index];
     if ((int)tile_column >= P.tiles_x || sy0 >= P.height) return;
@@ -1186,14 +1208,50 @@ __global__ void __launch_bounds__(128) rz_strip_kernel(const PassParams *__restr
     const float *vary_table = vary_base + (size_t)P.tri_off * 3 * RZ_VARY_STRIDE;
     const float *fan_vary_table = fan_vary_base + (size_t)P.fan_off * RZ_MAX_POLY * RZ_VARY_STRIDE;
     const DrawRec *draw_table = (const DrawRec*)(upload_base + P.draws_off);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int side = wave & 1, part = wave >> 1;
     const int bin = (sy0 / RZ_BIN) * P.bins_x + tx0 / RZ_BIN;
     const uint2 range = (bin_range_base + P.bin_off)[bin];          /* {first entry, entries} */
-    if (!uniform_width && class_base[P.bin_off + (uint32_t)bin] != (uint32_t)RZ_BIN_STRIP) return;
-    __shared__ unsigned long long micro_keys[256];
-    __shared__ uint32_t micro_ring[2][128];
-    strip_walk<STRIP, 1>(P, pass_index, bin, list_table + range.x, box_base + P.list_off + range.x, range.y /* (a bin of this class is not empty) */,
-                         vary_table, fan_vary_table, draw_table, tx0 + wave * 16, sy0, lane, 0, micro_keys + wave * 128, micro_ring[wave], nullptr);
+    if (!uniform_width) {
+        const uint32_t bin_class = class_base[P.bin_off + (uint32_t)bin];
+        if (bin_class != (uint32_t)RZ_BIN_STRIP) {
+            if (bin_class == (uint32_t)RZ_BIN_DONE) sky_of_tile(P);
+            return;
+        }
+    }
+    __shared__ unsigned long long micro_keys[2 * SPLIT][128];
+    __shared__ uint32_t micro_ring[2 * SPLIT][128];
+    __shared__ unsigned long long merged[SPLIT > 1 ? 2 : 1][128];
+    strip_walk<STRIP, SPLIT>(P, pass_index, bin, list_table + range.x, box_base + P.list_off + range.x, range.y /* (a bin of this class is not empty) */,
+                             vary_table, fan_vary_table, draw_table, tx0 + side * 16, sy0, lane, part, micro_keys[wave], micro_ring[wave],
+                             SPLIT > 1 ? merged[side] : nullptr);
+}
+template <int STRIP>
+__global__ void __launch_bounds__(128) rz_strip_kernel(const PassParams *__restrict__ passes,
+        const BinEntry *__restrict__ list_base, const uint2 *__restrict__ box_base,
+        const float *__restrict__ vary_base, const float *__restrict__ fan_vary_base,
+        const char *__restrict__ upload_base, const uint2 *__restrict__ bin_range_base,
+        const uint32_t *__restrict__ class_base, int uniform_width, int uniform_height) {
+    strips_of_workgroup<STRIP, 1, false>(passes, list_base, box_base, vary_base, fan_vary_base, upload_base, bin_range_base, class_base,
+                                         uniform_width, uniform_height, SkyTables());
+}
+/* A launch of a frame or two (a viewer's frame-at-a-time loop) is as long as its longest wave, and a wave alone on its
+ * SIMD issues an instruction every few cycles at best: some 900 cycles for each candidate that survives culling, whether
+ * its record comes through scalar loads or out of the lanes' registers (helmet at 1080p, one frame: 2 500 waves on 1 024
+ * SIMDs, the longest with 70 survivors and 37 us; whole entries loaded a group ahead and handed round with readlane: 33.9
+ * -> 32.9 us, not kept).  So the waves are made shorter: a TEAM of SPLIT waves per block of one strip each, sharing the
+ * list's groups as in rz_crowd_kernel (33.4 -> 25.6 us with two; four and more waves per block no longer fit the device
+ * at once and take longer again, 31 us and up; sharing a group's survivors instead of the groups: the same 25.9).
+ * Such a launch has wave slots to spare, and a workgroup whose bin is empty spends its first two waves on its tile's
+ * sky (`sky` with tables; sky_tile): nothing there waits for the strips, and rz_sky_kernel behind it is left with the
+ * bins that have lists (sky in all: 17.7 -> 14.1 us). */
+template <int SPLIT>
+__global__ void __launch_bounds__(128 * SPLIT) rz_strip_team_kernel(const PassParams *__restrict__ passes,
+        const BinEntry *__restrict__ list_base, const uint2 *__restrict__ box_base,
+        const float *__restrict__ vary_base, const float *__restrict__ fan_vary_base,
+        const char *__restrict__ upload_base, const uint2 *__restrict__ bin_range_base,
+        const uint32_t *__restrict__ class_base, int uniform_width, int uniform_height, SkyTables sky) {
+    strips_of_workgroup<1, SPLIT, true>(passes, list_base, box_base, vary_base, fan_vary_base, upload_base, bin_range_base, class_base,
+                                        uniform_width, uniform_height, sky);
 }
 
 /* Crowded bins.  A launch of rz_strip_kernel is as long as its longest wave, and a bin that holds the better part of a

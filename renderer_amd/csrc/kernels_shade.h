@@ -36,23 +36,25 @@ RZ_DEV void shade_pixel(const PassParams &P, const TriRec *__restrict__ tri_base
  * and varyings, the draw's face descriptors, all through scalar loads -- is paid once per 128 pixels.
  * Visibility among the table's triangles as in rz_strip_kernel (graphics.c:512-532), in table order, starting from
  * the depth the pass's other triangles left -- or, in a bin whose list is empty, from the pending clear, which
- * this kernel then carries out for the pixels no sky triangle covers. */
+ * this kernel then carries out for the pixels no sky triangle covers.
+ *
+ * sky_tile is a wave's part of it: tile (tile_x, tile_y) of pass P, wave 0 or 1 of the tile.  `which` leaves bins out:
+ * RZ_SKY_STALE_ONLY those whose list is empty -- nothing in them waits for the strips, and in a launch of a frame or two
+ * the strips' kernel takes them along (rz_strip_team_kernel) instead of leaving them for a launch behind it. */
+enum { RZ_SKY_ALL = 0, RZ_SKY_FRESH_ONLY = 1, RZ_SKY_STALE_ONLY = 2 };
 template <int PPL>
-__global__ void __launch_bounds__(256 / PPL) rz_sky_kernel(const PassParams *__restrict__ passes,
+RZ_DEV void sky_tile(const PassParams &P, int tile_x, int tile_y, int wave, int lane, int which,
         const TriRec *__restrict__ tri_base, const TriRec *__restrict__ fan_base,
         const float *__restrict__ vary_base, const float *__restrict__ fan_vary_base,
         const char *__restrict__ upload_base, const SkyBin *__restrict__ sky_base) {
     static_assert(PPL == 2, "a wave's region is 32x4 pixels");
-    const PassParams P = passes[blockIdx.z];
-    if ((int)blockIdx.x >= P.tiles_x || (int)blockIdx.y >= P.tiles_y || P.sky_draws == 0) return;
     const uint32_t failed = P.control[2];             /* looked at below, in the same round trip as the bin's record */
-    const int lane = threadIdx.x & 63, wave = (int)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const TriRec *tri_table = tri_base + P.tri_off;
     const TriRec *fan_table = fan_base + (size_t)P.fan_off * RZ_MAX_FAN;
     const float *vary_table = vary_base + (size_t)P.tri_off * 3 * RZ_VARY_STRIDE;
     const float *fan_vary_table = fan_vary_base + (size_t)P.fan_off * RZ_MAX_POLY * RZ_VARY_STRIDE;
     const DrawRec *draw_table = (const DrawRec*)(upload_base + P.draws_off);
-    const int tx0 = (int)blockIdx.x * RZ_TILE_W, ry0 = (int)blockIdx.y * RZ_TILE_H + wave * 2 * PPL;
+    const int tx0 = tile_x * RZ_TILE_W, ry0 = tile_y * RZ_TILE_H + wave * 2 * PPL;
     const int px = tx0 + (lane & 31);
     int py[PPL];
     uint32_t pixel[PPL];
@@ -67,6 +69,7 @@ __global__ void __launch_bounds__(256 / PPL) rz_sky_kernel(const PassParams *__r
     uint32_t refs[RZ_SKY_BIN_MAX];
     for (uint32_t e = 0; e < RZ_SKY_BIN_MAX; e++) refs[e] = bin.ref[e];
     if (failed != 0u) return;                         /* the pass did not run */
+    if ((which == RZ_SKY_FRESH_ONLY && !fresh) || (which == RZ_SKY_STALE_ONLY && fresh)) return;
     const bool overflow = sky_count == RZ_SKY_BIN_OVERFLOW;
     const uint32_t entries = overflow ? 0u : (sky_word >> ((region & 3u) * 8u)) & 0xffu;
     /* in a bin whose list is empty nothing has consumed the pass's clears; elsewhere rz_strip_kernel has */
@@ -183,6 +186,17 @@ __global__ void __launch_bounds__(256 / PPL) rz_sky_kernel(const PassParams *__r
             }
         }
     }
+}
+
+template <int PPL>
+__global__ void __launch_bounds__(256 / PPL) rz_sky_kernel(const PassParams *__restrict__ passes,
+        const TriRec *__restrict__ tri_base, const TriRec *__restrict__ fan_base,
+        const float *__restrict__ vary_base, const float *__restrict__ fan_vary_base,
+        const char *__restrict__ upload_base, const SkyBin *__restrict__ sky_base, int which) {
+    const PassParams P = passes[blockIdx.z];
+    if ((int)blockIdx.x >= P.tiles_x || (int)blockIdx.y >= P.tiles_y || P.sky_draws == 0) return;
+    sky_tile<PPL>(P, (int)blockIdx.x, (int)blockIdx.y, (int)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), (int)(threadIdx.x & 63u), which,
+                  tri_base, fan_base, vary_base, fan_vary_base, upload_base, sky_base);
 }
 
 /* over the family's work list: a fixed number of workgroups strides over it, so no wave is spent on

@@ -1,4 +1,4 @@
-"""Per-wave probe of rz_strip_kernel<1> (library built with -DRZ_PROBE): /tmp/probe.py <C1|C5|...>"""
+"""Per-wave probe of the strip kernel (library built with -DRZ_PROBE, named by MI355R_LIB): tools/probe_strip.py <C1|C5|...> [frames per flush]"""
 import ctypes as C, json, os, sys
 import numpy as np
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
@@ -10,7 +10,7 @@ only = sys.argv[1]
 gpu = Pipeline(GPU_LIB)
 for label, name, like, (w, h), _ in CONFIGS:
     if not label.startswith(only): continue
-    frames = 32
+    frames = int(sys.argv[2]) if len(sys.argv) > 2 else 32
     scene = gpu.open_scene(name, like)
     fbs = [gpu.framebuffer(w, h) for _ in range(frames)]
     views = [gpu.orbit_view(i, 240) for i in range(frames)]
