@@ -515,8 +515,8 @@ static void launch_batch(const Batch &b, const std::vector<PassPlan> &plans, cha
                 sky_stream = L.side;
                 forked = true;
             }
-            rz_sky_kernel<2><<<tiles, dim3(128), 0, sky_stream>>>(passes, L.tri.ptr, L.fan_tri.ptr, L.vary.ptr, L.fan_vary.ptr, db, L.sky_bins.ptr,
-                                                                  sky_with_strips ? (int)RZ_SKY_STALE_ONLY : (int)RZ_SKY_ALL);
+            auto sky_kernel = sky_with_strips ? rz_sky_stale_kernel<2> : rz_sky_kernel<2>;
+            sky_kernel<<<tiles, dim3(128), 0, sky_stream>>>(passes, L.tri.ptr, L.fan_tri.ptr, L.vary.ptr, L.fan_vary.ptr, db, L.sky_bins.ptr);
             if (forked) HIP_OK(hipEventRecord(L.join, L.side));
         }
         if (b.families & (1 << RZ_FAMILY_SKYBOX)) {     /* skybox fragments that came through the bins */

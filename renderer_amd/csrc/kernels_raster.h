@@ -1162,8 +1162,8 @@ RZ_DEV void strip_walk(const PassParams &P, uint32_t pass_index, int probe_bin, 
  * appended to its family's work list (16x8 blocks, not 32x8 tiles: the wave that owns the block is the only one
  * to list it).  Skybox fragments are rz_sky_kernel's: it looks at the references of every pixel outside the bins
  * it resolves itself, so in a batch with a sky box the references of all blocks are written. */
-template <int PPL>
-RZ_DEV void sky_tile(const PassParams &P, int tile_x, int tile_y, int wave, int lane, int which,
+template <int PPL, int WHICH>
+RZ_DEV void sky_tile(const PassParams &P, int tile_x, int tile_y, int wave, int lane,
         const TriRec *__restrict__ tri_base, const TriRec *__restrict__ fan_base,
         const float *__restrict__ vary_base, const float *__restrict__ fan_vary_base,
         const char *__restrict__ upload_base, const SkyBin *__restrict__ sky_base);
@@ -1187,7 +1187,7 @@ RZ_DEV void strips_of_workgroup(const PassParams *__restrict__ passes,
     auto sky_of_tile = [&](const PassParams &P) {
         if constexpr (SKY) {
             if (sky.sky_base && wave < 2 && P.sky_draws != 0 && (int)tile_column < P.tiles_x && (int)strip_row < P.tiles_y)
-                sky_tile<2>(P, (int)tile_column, (int)strip_row, wave, lane, 1 /* RZ_SKY_FRESH_ONLY */,
+                sky_tile<2, 1 /* RZ_SKY_FRESH_ONLY */>(P, (int)tile_column, (int)strip_row, wave, lane,
                             sky.tri_base, sky.fan_base, vary_base, fan_vary_base, upload_base, sky.sky_base);
         }
     };

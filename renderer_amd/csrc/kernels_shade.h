@@ -38,12 +38,12 @@ RZ_DEV void shade_pixel(const PassParams &P, const TriRec *__restrict__ tri_base
  * the depth the pass's other triangles left -- or, in a bin whose list is empty, from the pending clear, which
  * this kernel then carries out for the pixels no sky triangle covers.
  *
- * sky_tile is a wave's part of it: tile (tile_x, tile_y) of pass P, wave 0 or 1 of the tile.  `which` leaves bins out:
+ * sky_tile is a wave's part of it: tile (tile_x, tile_y) of pass P, wave 0 or 1 of the tile.  WHICH leaves bins out:
  * RZ_SKY_STALE_ONLY those whose list is empty -- nothing in them waits for the strips, and in a launch of a frame or two
  * the strips' kernel takes them along (rz_strip_team_kernel) instead of leaving them for a launch behind it. */
 enum { RZ_SKY_ALL = 0, RZ_SKY_FRESH_ONLY = 1, RZ_SKY_STALE_ONLY = 2 };
-template <int PPL>
-RZ_DEV void sky_tile(const PassParams &P, int tile_x, int tile_y, int wave, int lane, int which,
+template <int PPL, int WHICH>
+RZ_DEV void sky_tile(const PassParams &P, int tile_x, int tile_y, int wave, int lane,
         const TriRec *__restrict__ tri_base, const TriRec *__restrict__ fan_base,
         const float *__restrict__ vary_base, const float *__restrict__ fan_vary_base,
         const char *__restrict__ upload_base, const SkyBin *__restrict__ sky_base) {
@@ -69,7 +69,7 @@ RZ_DEV void sky_tile(const PassParams &P, int tile_x, int tile_y, int wave, int 
     uint32_t refs[RZ_SKY_BIN_MAX];
     for (uint32_t e = 0; e < RZ_SKY_BIN_MAX; e++) refs[e] = bin.ref[e];
     if (failed != 0u) return;                         /* the pass did not run */
-    if ((which == RZ_SKY_FRESH_ONLY && !fresh) || (which == RZ_SKY_STALE_ONLY && fresh)) return;
+    if ((WHICH == RZ_SKY_FRESH_ONLY && !fresh) || (WHICH == RZ_SKY_STALE_ONLY && fresh)) return;
     const bool overflow = sky_count == RZ_SKY_BIN_OVERFLOW;
     const uint32_t entries = overflow ? 0u : (sky_word >> ((region & 3u) * 8u)) & 0xffu;
     /* in a bin whose list is empty nothing has consumed the pass's clears; elsewhere rz_strip_kernel has */
@@ -192,11 +192,22 @@ template <int PPL>
 __global__ void __launch_bounds__(256 / PPL) rz_sky_kernel(const PassParams *__restrict__ passes,
         const TriRec *__restrict__ tri_base, const TriRec *__restrict__ fan_base,
         const float *__restrict__ vary_base, const float *__restrict__ fan_vary_base,
-        const char *__restrict__ upload_base, const SkyBin *__restrict__ sky_base, int which) {
+        const char *__restrict__ upload_base, const SkyBin *__restrict__ sky_base) {
     const PassParams P = passes[blockIdx.z];
     if ((int)blockIdx.x >= P.tiles_x || (int)blockIdx.y >= P.tiles_y || P.sky_draws == 0) return;
-    sky_tile<PPL>(P, (int)blockIdx.x, (int)blockIdx.y, (int)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), (int)(threadIdx.x & 63u), which,
-                  tri_base, fan_base, vary_base, fan_vary_base, upload_base, sky_base);
+    sky_tile<PPL, RZ_SKY_ALL>(P, (int)blockIdx.x, (int)blockIdx.y, (int)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), (int)(threadIdx.x & 63u),
+                              tri_base, fan_base, vary_base, fan_vary_base, upload_base, sky_base);
+}
+/* ... behind a launch of rz_strip_team_kernel that took the empty bins' sky along */
+template <int PPL>
+__global__ void __launch_bounds__(256 / PPL) rz_sky_stale_kernel(const PassParams *__restrict__ passes,
+        const TriRec *__restrict__ tri_base, const TriRec *__restrict__ fan_base,
+        const float *__restrict__ vary_base, const float *__restrict__ fan_vary_base,
+        const char *__restrict__ upload_base, const SkyBin *__restrict__ sky_base) {
+    const PassParams P = passes[blockIdx.z];
+    if ((int)blockIdx.x >= P.tiles_x || (int)blockIdx.y >= P.tiles_y || P.sky_draws == 0) return;
+    sky_tile<PPL, RZ_SKY_STALE_ONLY>(P, (int)blockIdx.x, (int)blockIdx.y, (int)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), (int)(threadIdx.x & 63u),
+                                     tri_base, fan_base, vary_base, fan_vary_base, upload_base, sky_base);
 }
 
 /* over the family's work list: a fixed number of workgroups strides over it, so no wave is spent on
