@@ -262,7 +262,7 @@ static void prepare_batch(const Batch &b, const FlushRecord &fr, bool reserve_on
     const size_t queue_capacity = (2 * tiles + RZ_QUEUE_WAYS - 1) / RZ_QUEUE_WAYS + b.members.size();    /* every pass's share rounded up */
     reserve(L.tile_listed, tiles, st);
     reserve(L.queue, RZ_LISTS * RZ_QUEUE_WAYS * queue_capacity, st);    /* blinn, pbr, RZ_ORDERED_LIST, RZ_VISIBILITY_LIST */
-    reserve(L.queue_counts, RZ_LISTS * RZ_QUEUE_WAYS * RZ_QUEUE_PAD, st);
+    reserve(L.queue_counts, (RZ_BATCH_CONTESTED + 1u) * RZ_QUEUE_PAD, st);
     reserve(L.bin_list, lists, st);
     reserve(L.bin_boxes, lists, st);
     if (!b.has_blend || splits_blend(tiles, b.members.size())) reserve(L.ref, pixels, st);
@@ -404,7 +404,7 @@ static void launch_batch(const Batch &b, const std::vector<PassPlan> &plans, cha
         }
         if (L.bin_range.cap < bins || L.bin_class.cap < bins || L.sky_bins.cap < bins || L.sky_table.cap < b.members.size() * RZ_SKY_TABLE) fatal("per-bin scratch of lane %d is smaller than the batch it is about to run", b.lane);
         const bool uses_ref = !(b.has_blend && !splits_blend(batch_tiles, n));
-        if (L.queue_counts.cap < RZ_LISTS * RZ_QUEUE_WAYS * RZ_QUEUE_PAD || L.queue.cap < RZ_LISTS * RZ_QUEUE_WAYS * (size_t)queue_capacity ||
+        if (L.queue_counts.cap < (RZ_BATCH_CONTESTED + 1u) * RZ_QUEUE_PAD || L.queue.cap < RZ_LISTS * RZ_QUEUE_WAYS * (size_t)queue_capacity ||
             L.tile_listed.cap < batch_tiles || L.bin_boxes.cap < L.bin_list.cap || (uses_ref && (!L.ref.ptr || L.ref.cap < pixels)) || L.tri.cap < tris || L.bbox.cap < tris)
             fatal("scratch of lane %d is smaller than the batch it is about to run", b.lane);
     }
@@ -515,7 +515,9 @@ static void launch_batch(const Batch &b, const std::vector<PassPlan> &plans, cha
                 sky_stream = L.side;
                 forked = true;
             }
-            auto sky_kernel = sky_with_strips ? rz_sky_stale_kernel<2> : rz_sky_kernel<2>;
+            /* beside the shade kernels the sky keeps its hands off the bins of passes where it may hide a fragment they
+             * shade (whichever wrote last would show); those bins follow behind the join */
+            auto sky_kernel = sky_with_strips ? rz_sky_stale_kernel<2> : forked ? rz_sky_side_kernel<2> : rz_sky_kernel<2>;
             sky_kernel<<<tiles, dim3(128), 0, sky_stream>>>(passes, L.tri.ptr, L.fan_tri.ptr, L.vary.ptr, L.fan_vary.ptr, db, L.sky_bins.ptr);
             if (forked) HIP_OK(hipEventRecord(L.join, L.side));
         }
@@ -539,7 +541,10 @@ static void launch_batch(const Batch &b, const std::vector<PassPlan> &plans, cha
                                                      L.queue.ptr, L.queue_counts.ptr, queue_capacity);
         }
         stamp();
-        if (forked) HIP_OK(hipStreamWaitEvent(st, L.join, 0));
+        if (forked) {
+            HIP_OK(hipStreamWaitEvent(st, L.join, 0));
+            rz_sky_late_kernel<2><<<shade_grid, dim3(128), 0, st>>>(passes, n, L.tri.ptr, L.fan_tri.ptr, L.vary.ptr, L.fan_vary.ptr, db, L.sky_bins.ptr, L.queue_counts.ptr);
+        }
     }
     HIP_OK(hipGetLastError());
     if (g.timing) g.timing_passes.push_back(n);

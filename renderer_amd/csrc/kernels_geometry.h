@@ -36,7 +36,7 @@ __global__ void __launch_bounds__(256) rz_begin_kernel(const PassParams *__restr
     /* the pass's device-written scalars start at zero -- unless another pass of the flush ran out of
      * scratch and this one may depend on it: then it is marked to be left out and run again later */
     if (gv < 8u) P.control[gv] = (gv == 2u && P.level > 0 && *P.flush_flag != 0u) ? (uint32_t)RZ_ERR_SKIPPED : 0u;
-    if (blockIdx.y == 0 && gv < RZ_LISTS * RZ_QUEUE_WAYS) P.queue_counts[gv * RZ_QUEUE_PAD] = 0;    /* ... and the batch's work-list lengths */
+    if (blockIdx.y == 0 && gv <= RZ_BATCH_CONTESTED) P.queue_counts[gv * RZ_QUEUE_PAD] = 0;    /* ... and the batch's work-list lengths and its flag word */
     for (uint32_t t = gv; t < (uint32_t)(P.tiles_x * P.tiles_y); t += gridDim.x * 256u) P.tile_listed[t] = 0;
     if (P.sky_draws && gv < (uint32_t)RZ_SKY_TABLE) P.sky_table[gv] = 0xffffffffu;      /* RZ_REF_NONE: no sky triangle yet */
     {   /* ... and the pass's (chunk, bin) matrix, which rz_bin_count_kernel adds into */

@@ -796,6 +796,15 @@ RZ_DEV void finish_block(const PassParams &P, uint32_t pass_index, int bx0, int 
                          const bool valid[2], const uint32_t pixel[2], const float zcur[2], const uint32_t ref_of[2]) {
     constexpr int PPL = 2;
     bool listed = false;
+    if (P.sky_draws != 0) {
+        /* a fragment the pass's sky box may hide: said for the pass and for the batch (rz_sky_side_kernel, rz_sky_late_kernel) */
+        bool far_one = false;
+        for (int q = 0; q < PPL; q++) far_one |= ref_of[q] != RZ_REF_NONE && !(zcur[q] < RZ_SKY_NEAR);
+        if (__any(far_one) && lane == 0) {
+            atomicOr(&P.control[5], 1u);
+            atomicOr(&P.queue_counts[RZ_BATCH_CONTESTED * RZ_QUEUE_PAD], 1u);
+        }
+    }
     for (int q = 0; q < PPL; q++) {
         if (valid[q] && (ref_of[q] != RZ_REF_NONE || P.clear_depth_pending)) P.depth[pixel[q]] = zcur[q];  /* else: what was there */
         listed |= ((ref_of[q] >> 28) & 3u) < 3u;                /* RZ_REF_NONE reads as family 3 */
@@ -1162,7 +1171,7 @@ RZ_DEV void strip_walk(const PassParams &P, uint32_t pass_index, int probe_bin, 
  * appended to its family's work list (16x8 blocks, not 32x8 tiles: the wave that owns the block is the only one
  * to list it).  Skybox fragments are rz_sky_kernel's: it looks at the references of every pixel outside the bins
  * it resolves itself, so in a batch with a sky box the references of all blocks are written. */
-template <int PPL, int WHICH>
+template <int PPL, int WHICH, bool DEFERS = false>
 RZ_DEV void sky_tile(const PassParams &P, int tile_x, int tile_y, int wave, int lane,
         const TriRec *__restrict__ tri_base, const TriRec *__restrict__ fan_base,
         const float *__restrict__ vary_base, const float *__restrict__ fan_vary_base,
@@ -1187,7 +1196,7 @@ RZ_DEV void strips_of_workgroup(const PassParams *__restrict__ passes,
     auto sky_of_tile = [&](const PassParams &P) {
         if constexpr (SKY) {
             if (sky.sky_base && wave < 2 && P.sky_draws != 0 && (int)tile_column < P.tiles_x && (int)strip_row < P.tiles_y)
-                sky_tile<2, 1 /* RZ_SKY_FRESH_ONLY */>(P, (int)tile_column, (int)strip_row, wave, lane,
+                sky_tile<2, 1 /* RZ_SKY_FRESH_ONLY */, false>(P, (int)tile_column, (int)strip_row, wave, lane,
                             sky.tri_base, sky.fan_base, vary_base, fan_vary_base, upload_base, sky.sky_base);
         }
     };

@@ -40,15 +40,20 @@ RZ_DEV void shade_pixel(const PassParams &P, const TriRec *__restrict__ tri_base
  *
  * sky_tile is a wave's part of it: tile (tile_x, tile_y) of pass P, wave 0 or 1 of the tile.  WHICH leaves bins out:
  * RZ_SKY_STALE_ONLY those whose list is empty -- nothing in them waits for the strips, and in a launch of a frame or two
- * the strips' kernel takes them along (rz_strip_team_kernel) instead of leaving them for a launch behind it. */
+ * the strips' kernel takes them along (rz_strip_team_kernel) instead of leaving them for a launch behind it.
+ * DEFERS: beside the shade kernels (rz_sky_side_kernel).  There the sky must not take a pixel that holds a fragment
+ * for them -- colour and reference would go to whoever wrote last -- and it can only where a fragment lies behind the
+ * sky's depth (RZ_SKY_NEAR; the strips flag such a pass, control word 5): the bins with lists of a flagged pass are left
+ * to rz_sky_late_kernel, which runs when the shade kernels are through. */
 enum { RZ_SKY_ALL = 0, RZ_SKY_FRESH_ONLY = 1, RZ_SKY_STALE_ONLY = 2 };
-template <int PPL, int WHICH>
+template <int PPL, int WHICH, bool DEFERS>
 RZ_DEV void sky_tile(const PassParams &P, int tile_x, int tile_y, int wave, int lane,
         const TriRec *__restrict__ tri_base, const TriRec *__restrict__ fan_base,
         const float *__restrict__ vary_base, const float *__restrict__ fan_vary_base,
         const char *__restrict__ upload_base, const SkyBin *__restrict__ sky_base) {
     static_assert(PPL == 2, "a wave's region is 32x4 pixels");
     const uint32_t failed = P.control[2];             /* looked at below, in the same round trip as the bin's record */
+    const uint32_t contested = DEFERS ? P.control[5] : 0u;
     const TriRec *tri_table = tri_base + P.tri_off;
     const TriRec *fan_table = fan_base + (size_t)P.fan_off * RZ_MAX_FAN;
     const float *vary_table = vary_base + (size_t)P.tri_off * 3 * RZ_VARY_STRIDE;
@@ -70,6 +75,7 @@ RZ_DEV void sky_tile(const PassParams &P, int tile_x, int tile_y, int wave, int 
     for (uint32_t e = 0; e < RZ_SKY_BIN_MAX; e++) refs[e] = bin.ref[e];
     if (failed != 0u) return;                         /* the pass did not run */
     if ((WHICH == RZ_SKY_FRESH_ONLY && !fresh) || (WHICH == RZ_SKY_STALE_ONLY && fresh)) return;
+    if (DEFERS && contested != 0u && !fresh) return;  /* rz_sky_late_kernel's */
     const bool overflow = sky_count == RZ_SKY_BIN_OVERFLOW;
     const uint32_t entries = overflow ? 0u : (sky_word >> ((region & 3u) * 8u)) & 0xffu;
     /* in a bin whose list is empty nothing has consumed the pass's clears; elsewhere rz_strip_kernel has */
@@ -195,8 +201,37 @@ __global__ void __launch_bounds__(256 / PPL) rz_sky_kernel(const PassParams *__r
         const char *__restrict__ upload_base, const SkyBin *__restrict__ sky_base) {
     const PassParams P = passes[blockIdx.z];
     if ((int)blockIdx.x >= P.tiles_x || (int)blockIdx.y >= P.tiles_y || P.sky_draws == 0) return;
-    sky_tile<PPL, RZ_SKY_ALL>(P, (int)blockIdx.x, (int)blockIdx.y, (int)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), (int)(threadIdx.x & 63u),
+    sky_tile<PPL, RZ_SKY_ALL, false>(P, (int)blockIdx.x, (int)blockIdx.y, (int)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), (int)(threadIdx.x & 63u),
                               tri_base, fan_base, vary_base, fan_vary_base, upload_base, sky_base);
+}
+/* ... beside the shade kernels, on the lane's side stream */
+template <int PPL>
+__global__ void __launch_bounds__(256 / PPL) rz_sky_side_kernel(const PassParams *__restrict__ passes,
+        const TriRec *__restrict__ tri_base, const TriRec *__restrict__ fan_base,
+        const float *__restrict__ vary_base, const float *__restrict__ fan_vary_base,
+        const char *__restrict__ upload_base, const SkyBin *__restrict__ sky_base) {
+    const PassParams P = passes[blockIdx.z];
+    if ((int)blockIdx.x >= P.tiles_x || (int)blockIdx.y >= P.tiles_y || P.sky_draws == 0) return;
+    sky_tile<PPL, RZ_SKY_ALL, true>(P, (int)blockIdx.x, (int)blockIdx.y, (int)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), (int)(threadIdx.x & 63u),
+                                    tri_base, fan_base, vary_base, fan_vary_base, upload_base, sky_base);
+}
+/* ... and what that one left: the bins with lists of the passes flagged as holding fragments the sky may hide.  Hardly
+ * ever any (geometry between the sky's depth and the far plane): the batch's flag word says so to every workgroup in one
+ * load; otherwise the workgroups stride over the flagged passes' tiles. */
+template <int PPL>
+__global__ void __launch_bounds__(256 / PPL) rz_sky_late_kernel(const PassParams *__restrict__ passes, uint32_t num_passes,
+        const TriRec *__restrict__ tri_base, const TriRec *__restrict__ fan_base,
+        const float *__restrict__ vary_base, const float *__restrict__ fan_vary_base,
+        const char *__restrict__ upload_base, const SkyBin *__restrict__ sky_base, const uint32_t *__restrict__ queue_counts) {
+    if (queue_counts[RZ_BATCH_CONTESTED * RZ_QUEUE_PAD] == 0u) return;
+    const int wave = (int)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = (int)(threadIdx.x & 63u);
+    for (uint32_t p = 0; p < num_passes; p++) {
+        const PassParams P = passes[p];
+        if (P.sky_draws == 0 || P.control[5] == 0u) continue;
+        for (uint32_t tile = blockIdx.x; tile < (uint32_t)(P.tiles_x * P.tiles_y); tile += gridDim.x)
+            sky_tile<PPL, RZ_SKY_STALE_ONLY, false>(P, (int)(tile % (uint32_t)P.tiles_x), (int)(tile / (uint32_t)P.tiles_x), wave, lane,
+                                                    tri_base, fan_base, vary_base, fan_vary_base, upload_base, sky_base);
+    }
 }
 /* ... behind a launch of rz_strip_team_kernel that took the empty bins' sky along */
 template <int PPL>
@@ -206,7 +241,7 @@ __global__ void __launch_bounds__(256 / PPL) rz_sky_stale_kernel(const PassParam
         const char *__restrict__ upload_base, const SkyBin *__restrict__ sky_base) {
     const PassParams P = passes[blockIdx.z];
     if ((int)blockIdx.x >= P.tiles_x || (int)blockIdx.y >= P.tiles_y || P.sky_draws == 0) return;
-    sky_tile<PPL, RZ_SKY_STALE_ONLY>(P, (int)blockIdx.x, (int)blockIdx.y, (int)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), (int)(threadIdx.x & 63u),
+    sky_tile<PPL, RZ_SKY_STALE_ONLY, false>(P, (int)blockIdx.x, (int)blockIdx.y, (int)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), (int)(threadIdx.x & 63u),
                                      tri_base, fan_base, vary_base, fan_vary_base, upload_base, sky_base);
 }
 

@@ -60,6 +60,13 @@ enum { RZ_PV_WORLD = 0, RZ_PV_NORMAL = 3, RZ_PV_TANGENT = 6, RZ_PV_BITANGENT = 9
                                      * pass's table: more than 12 triangles, not drawn last, fragments being counted) */
 #define RZ_CROWD_LIST 5u            /* the sixth: the blocks of crowded bins, rz_crowd_kernel's */
 #define RZ_LISTS 6u
+/* behind the lists' lengths in queue_counts, one word per batch: set when a pass of the batch has a fragment that a sky
+ * box on its table may hide (see RZ_SKY_NEAR) */
+#define RZ_BATCH_CONTESTED (RZ_LISTS * RZ_QUEUE_WAYS)
+/* A sky box lies at z = w * (1 - EPSILON) (skybox_shader.c:15), short of the far plane: depth 0.999995 give or take
+ * rounding, wherever it is seen from.  Drawn last it hides what lies behind it (graphics.c:523), and a fragment nearer
+ * than this can not be hidden by it. */
+#define RZ_SKY_NEAR 0.9999f
 /* the table of a pass's sky boxes: up to RZ_SKY_DRAWS draws of up to RZ_SKY_FACES triangles, RZ_MAX_FAN entries each -- the
  * triangle's index, RZ_REF_FAN | its fan records', or RZ_REF_NONE --, in submission order */
 #define RZ_SKY_DRAWS 4

@@ -392,6 +392,84 @@ def test_skybox_of_caller_made_faces_replaced_between_frames(gpu, oracle, eight_
     assert all(int((f[1] < 0.9).sum()) > 1000 for f in results[0])                  # the triangle in front is there
 
 
+@pytest.mark.parametrize("frames", [2, 12], ids=["two_frames", "twelve_frames"])
+def test_triangles_that_reach_behind_the_sky(gpu, oracle, frames):
+    """Opaque triangles whose depth runs from well in front of the sky box to beyond it (the sky's vertex shader
+    puts it at z = w * (1 - EPSILON), skybox_shader.c:15, short of the far plane), then the sky box: drawn last, the
+    sky takes every pixel where its depth is not greater (graphics.c:523), so the far part of each triangle is
+    hidden behind it.  Several framebuffers in one flush: the library shades the sky and the triangles'
+    fragments in different kernels, side by side when the flush is large enough, and a pixel both of them
+    have a fragment for must end up with the sky's."""
+    size = (448, 320)
+    rng = np.random.default_rng(5)
+    images = [rng.integers(0, 256, (32, 32, 4)).astype(np.float32) / np.float32(255) for _ in range(6)]
+    views = [(0.5 * i, 0.2 * np.sin(i)) for i in range(frames)]
+    results = []
+    for pipe in (gpu, oracle):
+        lib = pipe.lib
+        declare(lib)
+        P = C.c_void_p
+        lib.texture_create.restype = C.POINTER(HostTexture)
+        lib.texture_create.argtypes = [C.c_int, C.c_int]
+        lib.texture_release.argtypes = [C.POINTER(HostTexture)]
+        lib.texture_invalidate.argtypes = [C.POINTER(HostTexture)]
+        cube = Cubemap()
+        for i in range(6):
+            cube.faces[i] = lib.texture_create(32, 32)
+            np.ctypeslib.as_array(cube.faces[i].contents.buffer, (32, 32, 4))[...] = images[i]
+            lib.texture_invalidate(cube.faces[i])
+        sky = lib.program_create(fn(lib, "skybox_vertex_shader"), fn(lib, "skybox_fragment_shader"), 12, 12, 72, 1, 0)
+        su = SkyboxUniforms.from_address(lib.program_get_uniforms(sky))
+        su.skybox = C.cast(C.pointer(cube), P)
+        front = lib.program_create(fn(lib, "blinn_vertex_shader"), fn(lib, "blinn_fragment_shader"), 64, 44, 344, 1, 0)
+        bu = BlinnUniforms.from_address(lib.program_get_uniforms(front))
+        bu.light_dir[:] = [0.0, 0.0, -1.0]
+        bu.camera_pos[:] = [0.0, 0.0, 2.0]
+        bu.model_matrix[:] = IDENTITY4[:]
+        bu.normal_matrix[:] = IDENTITY3[:]
+        bu.light_vp_matrix[:] = IDENTITY4[:]
+        bu.camera_vp_matrix[:] = IDENTITY4[:]
+        bu.ambient_intensity = 1.0
+        bu.punctual_intensity = 0.0
+        bu.shininess = 4.0
+        fbs = [pipe.framebuffer(*size) for _ in views]
+        for k, (fb, (yaw, pitch)) in enumerate(zip(fbs, views)):
+            lib.framebuffer_clear_color(fb, Vec4(0.0, 0.0, 0.0, 1.0))
+            lib.framebuffer_clear_depth(fb, 1.0)
+            # clip space = position (identity matrices): z = 0.99999 is where the sky lies
+            for t, (z_near, z_far) in enumerate([(0.2, 1.0), (0.9999, 1.0), (0.99998, 0.999995)]):
+                bu.basecolor[:] = [0.9 - 0.3 * t, 0.3 + 0.2 * t, 0.1 + 0.4 * t, 1.0]
+                corners = [(-0.9 + 0.1 * k / frames, -0.8 + 0.5 * t, z_near), (0.9, -0.7 + 0.5 * t, z_far), (-0.2, 0.1 + 0.4 * t, z_far)]
+                for j, (x, y, z) in enumerate(corners):
+                    a = BlinnAttribs.from_address(lib.program_get_attribs(front, j))
+                    a.position[:] = [x, y, z]
+                    a.texcoord[:] = [0.5, 0.5]
+                    a.normal[:] = [0.0, 0.0, 1.0]
+                    a.joint[:] = [0, 0, 0, 0]
+                    a.weight[:] = [0, 0, 0, 0]
+                lib.graphics_draw_triangle(C.cast(fb, P), front)
+            su.vp_matrix[:] = [float(x) for x in look_from_inside(size[0] / size[1], yaw, pitch).reshape(-1)]
+            for quad in CUBE_FACES:
+                for tri in ((quad[0], quad[1], quad[2]), (quad[0], quad[2], quad[3])):
+                    for j in range(3):
+                        (C.c_float * 3).from_address(lib.program_get_attribs(sky, j))[:] = [float(x) for x in CUBE_CORNERS[tri[j]]]
+                    lib.graphics_draw_triangle(C.cast(fb, P), sky)
+        out = [pipe.read(fb) for fb in fbs]
+        for fb in fbs:
+            pipe.release(fb)
+        lib.program_release(sky)
+        lib.program_release(front)
+        for i in range(6):
+            lib.texture_release(cube.faces[i])
+        results.append(out)
+    for got, want in zip(*results):
+        assert same(got, want)
+    sky_depth = np.float32((1.0 - 1e-5 + 1.0) * 0.5)
+    for colour, depth in results[1]:
+        assert int((depth < 0.99).sum()) > 1000                     # the near parts of the triangles are there
+        assert float(depth.max()) <= float(sky_depth) + 1e-6        # nothing shows from behind the sky
+
+
 @pytest.mark.parametrize("blend", [0, 1], ids=["opaque", "second_blended"])
 def test_two_sky_boxes_in_one_pass(gpu, oracle, blend):
     """A sky box from inside, then triangles of a SECOND sky program (another cube map) over parts of it, all
