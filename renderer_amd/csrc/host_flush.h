@@ -475,7 +475,7 @@ static void launch_batch(const Batch &b, const std::vector<PassPlan> &plans, cha
             snprintf(g.last_raster_kernel, sizeof g.last_raster_kernel, "rz_strip_kernel<%d>", strip);
             /* a launch of a frame or two: a team of waves per block, the sky of empty bins in the same launch
              * (fragment counts follow the order the triangles are taken in: no teams while they are kept) */
-            const bool team = strip == 1 && b.members.size() <= 2 && !g.counting && g.strip_team;
+            const bool team = strip == 1 && b.members.size() <= 2 && !g.counting && g.strip_team && !b.crowd;
             sky_with_strips = team && b.sky_table && g.sky_with_strips && !g.timing;
             /* passes of one size: a strip then finds its bin's class without reading its pass's parameters */
             int uniform_w = plans[b.members[0]].fb->pub.width, uniform_h = plans[b.members[0]].fb->pub.height;
@@ -505,7 +505,7 @@ static void launch_batch(const Batch &b, const std::vector<PassPlan> &plans, cha
         stamp();
         if (crowd_forked) HIP_OK(hipStreamWaitEvent(st, L.join, 0));
         bool forked = false;
-        if (b.sky_table) {
+        if (b.sky_table && !sky_with_strips) {
             hipStream_t sky_stream = st;
             /* (not for a launch of a frame or two: there the fork and the join cost more than the overlap gains --
              * helmet, one frame per flush: 0.172 against 0.159 ms per frame) */
@@ -517,7 +517,7 @@ static void launch_batch(const Batch &b, const std::vector<PassPlan> &plans, cha
             }
             /* beside the shade kernels the sky keeps its hands off the bins of passes where it may hide a fragment they
              * shade (whichever wrote last would show); those bins follow behind the join */
-            auto sky_kernel = sky_with_strips ? rz_sky_stale_kernel<2> : forked ? rz_sky_side_kernel<2> : rz_sky_kernel<2>;
+            auto sky_kernel = forked ? rz_sky_side_kernel<2> : rz_sky_kernel<2>;
             sky_kernel<<<tiles, dim3(128), 0, sky_stream>>>(passes, L.tri.ptr, L.fan_tri.ptr, L.vary.ptr, L.fan_vary.ptr, db, L.sky_bins.ptr);
             if (forked) HIP_OK(hipEventRecord(L.join, L.side));
         }

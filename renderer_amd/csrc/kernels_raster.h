@@ -422,6 +422,9 @@ RZ_DEV uint32_t outwards(uint32_t turn, uint32_t count) {      /* 0, 1, 2, .. ->
 RZ_DEV TileOrder tile_order(uint32_t rows_per_bin) {
     TileOrder o;
     o.pass = blockIdx.x;
+#ifdef RZ_ORDER_PLAIN
+    o.column = blockIdx.y; o.row = blockIdx.z; return o;
+#endif
     o.column = outwards(blockIdx.y / 2u, gridDim.y / 2u) * 2u + (blockIdx.y & 1u);
     o.row = outwards(blockIdx.z / rows_per_bin, gridDim.z / rows_per_bin) * rows_per_bin + blockIdx.z % rows_per_bin;
     return o;
@@ -1171,15 +1174,18 @@ RZ_DEV void strip_walk(const PassParams &P, uint32_t pass_index, int probe_bin, 
  * appended to its family's work list (16x8 blocks, not 32x8 tiles: the wave that owns the block is the only one
  * to list it).  Skybox fragments are rz_sky_kernel's: it looks at the references of every pixel outside the bins
  * it resolves itself, so in a batch with a sky box the references of all blocks are written. */
-template <int PPL, int WHICH, bool DEFERS = false>
-RZ_DEV void sky_tile(const PassParams &P, int tile_x, int tile_y, int wave, int lane,
+/* (for a workgroup of rz_strip_team_kernel: what the sky of its tile is read from, see sky_tile) */
+struct SkyTables { const TriRec *tri_base, *fan_base; const SkyBin *sky_base; };
+template <int PPL, bool DEFERS>
+RZ_DEV void sky_tile(const PassParams &P, int tile_x, int tile_y, int wave, int lane, int WHICH,
         const TriRec *__restrict__ tri_base, const TriRec *__restrict__ fan_base,
         const float *__restrict__ vary_base, const float *__restrict__ fan_vary_base,
         const char *__restrict__ upload_base, const SkyBin *__restrict__ sky_base);
-/* (for a workgroup of rz_strip_team_kernel whose bin is empty: what the sky of its tile is read from, see sky_tile) */
-struct SkyTables { const TriRec *tri_base, *fan_base; const SkyBin *sky_base; };
 
-/* a workgroup of the strip kernels: two strips side by side (a 32-pixel tile column), SPLIT waves to each */
+/* a workgroup of the strip kernels: two strips side by side (a 32-pixel tile column), SPLIT waves to each.  SKY: the
+ * tile's sky too (rz_strip_team_kernel) -- at once where the bin is empty, behind the strips where it has a list; both
+ * ways lead to ONE copy of the sky's code at the end (inlined twice it tripled the kernel and spilled its scalar
+ * registers; as a function the kernel calls it took 118 vector registers by the calling convention's numbering). */
 template <int STRIP, int SPLIT, bool SKY>
 RZ_DEV void strips_of_workgroup(const PassParams *__restrict__ passes,
         const BinEntry *__restrict__ list_base, const uint2 *__restrict__ box_base,
@@ -1192,14 +1198,9 @@ RZ_DEV void strips_of_workgroup(const PassParams *__restrict__ passes,
     const uint32_t pass_index = o.pass, tile_column = o.column, strip_row = o.row;
     const int sy0 = (int)strip_row * 8 * STRIP, tx0 = (int)tile_column * RZ_TILE_W;
     const int lane = threadIdx.x & 63, wave = (int)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    /* an empty bin's tile: its sky, by the workgroup's first two waves */
-    auto sky_of_tile = [&](const PassParams &P) {
-        if constexpr (SKY) {
-            if (sky.sky_base && wave < 2 && P.sky_draws != 0 && (int)tile_column < P.tiles_x && (int)strip_row < P.tiles_y)
-                sky_tile<2, 1 /* RZ_SKY_FRESH_ONLY */, false>(P, (int)tile_column, (int)strip_row, wave, lane,
-                            sky.tri_base, sky.fan_base, vary_base, fan_vary_base, upload_base, sky.sky_base);
-        }
-    };
+    const bool with_sky = SKY && sky.sky_base != nullptr;
+    bool strips = true;                     /* uniform over the workgroup */
+    int sky_which = -1, sky_half = 0;       /* uniform over the wave: what this wave does of the tile's sky, and for which four rows */
     /* the passes of the batch have one size (uniform_width != 0): what the bin's class says is known before the pass's
      * parameters are asked for, and most strips of most frames end here */
     if (uniform_width) {
@@ -1207,32 +1208,50 @@ RZ_DEV void strips_of_workgroup(const PassParams *__restrict__ passes,
         const uint32_t bins_x = ((uint32_t)uniform_width + RZ_BIN - 1u) / RZ_BIN, bins_y = ((uint32_t)uniform_height + RZ_BIN - 1u) / RZ_BIN;
         const uint32_t bin_class = class_base[pass_index * (bins_x * bins_y) + (uint32_t)(sy0 / RZ_BIN) * bins_x + (uint32_t)(tx0 / RZ_BIN)];
         if (bin_class != (uint32_t)RZ_BIN_STRIP) {
-            if (SKY && sky.sky_base && wave < 2 && bin_class == (uint32_t)RZ_BIN_DONE) sky_of_tile(passes[pass_index]);
-            return;
+            if (!(with_sky && bin_class == (uint32_t)RZ_BIN_DONE && wave < 2)) return;
+            strips = false;
         }
     }
     const PassParams P = passes[pass_index];
     if ((int)tile_column >= P.tiles_x || sy0 >= P.height) return;
-    const BinEntry *list_table = list_base + P.list_off;
-    const float *vary_table = vary_base + (size_t)P.tri_off * 3 * RZ_VARY_STRIDE;
-    const float *fan_vary_table = fan_vary_base + (size_t)P.fan_off * RZ_MAX_POLY * RZ_VARY_STRIDE;
-    const DrawRec *draw_table = (const DrawRec*)(upload_base + P.draws_off);
-    const int side = wave & 1, part = wave >> 1;
-    const int bin = (sy0 / RZ_BIN) * P.bins_x + tx0 / RZ_BIN;
-    const uint2 range = (bin_range_base + P.bin_off)[bin];          /* {first entry, entries} */
-    if (!uniform_width) {
-        const uint32_t bin_class = class_base[P.bin_off + (uint32_t)bin];
+    if (strips && !uniform_width) {
+        const uint32_t bin_class = class_base[P.bin_off + (uint32_t)((sy0 / RZ_BIN) * P.bins_x + tx0 / RZ_BIN)];
         if (bin_class != (uint32_t)RZ_BIN_STRIP) {
-            if (bin_class == (uint32_t)RZ_BIN_DONE) sky_of_tile(P);
-            return;
+            if (!(with_sky && bin_class == (uint32_t)RZ_BIN_DONE && wave < 2)) return;
+            strips = false;
         }
     }
-    __shared__ unsigned long long micro_keys[2 * SPLIT][128];
-    __shared__ uint32_t micro_ring[2 * SPLIT][128];
-    __shared__ unsigned long long merged[SPLIT > 1 ? 2 : 1][128];
-    strip_walk<STRIP, SPLIT>(P, pass_index, bin, list_table + range.x, box_base + P.list_off + range.x, range.y /* (a bin of this class is not empty) */,
-                             vary_table, fan_vary_table, draw_table, tx0 + side * 16, sy0, lane, part, micro_keys[wave], micro_ring[wave],
-                             SPLIT > 1 ? merged[side] : nullptr);
+    if (strips) {
+        const BinEntry *list_table = list_base + P.list_off;
+        const float *vary_table = vary_base + (size_t)P.tri_off * 3 * RZ_VARY_STRIDE;
+        const float *fan_vary_table = fan_vary_base + (size_t)P.fan_off * RZ_MAX_POLY * RZ_VARY_STRIDE;
+        const DrawRec *draw_table = (const DrawRec*)(upload_base + P.draws_off);
+        const int side = wave & 1, part = wave >> 1;
+        const int bin = (sy0 / RZ_BIN) * P.bins_x + tx0 / RZ_BIN;
+        const uint2 range = (bin_range_base + P.bin_off)[bin];          /* {first entry, entries} */
+        __shared__ unsigned long long micro_keys[2 * SPLIT][128];
+        __shared__ uint32_t micro_ring[2 * SPLIT][128];
+        __shared__ unsigned long long merged[SPLIT > 1 ? 2 : 1][128];
+        strip_walk<STRIP, SPLIT>(P, pass_index, bin, list_table + range.x, box_base + P.list_off + range.x, range.y /* (a bin of this class is not empty) */,
+                                 vary_table, fan_vary_table, draw_table, tx0 + side * 16, sy0, lane, part, micro_keys[wave], micro_ring[wave],
+                                 SPLIT > 1 ? merged[side] : nullptr);
+        if constexpr (SKY && SPLIT > 1) {
+            /* the tile's own sky, once its two blocks are finished: by the waves that did not finish them (the tile's
+             * upper four rows one, the lower four the other), against the depth the others have just written */
+            if (with_sky && P.sky_draws != 0) {     /* uniform over the workgroup */
+                __syncthreads();
+                if (part == 1) { sky_which = 2 /* RZ_SKY_STALE_ONLY */; sky_half = side; }
+            }
+        }
+    } else {
+        /* an empty bin's tile: its sky, by the workgroup's first two waves -- nothing there waits for the strips */
+        sky_which = 1 /* RZ_SKY_FRESH_ONLY */; sky_half = wave;
+    }
+    if constexpr (SKY) {
+        if (sky_which >= 0 && P.sky_draws != 0)
+            sky_tile<2, false>(P, (int)tile_column, (int)strip_row, sky_half, lane, sky_which,
+                               sky.tri_base, sky.fan_base, vary_base, fan_vary_base, upload_base, sky.sky_base);
+    }
 }
 template <int STRIP>
 __global__ void __launch_bounds__(128) rz_strip_kernel(const PassParams *__restrict__ passes,
@@ -1251,8 +1270,9 @@ __global__ void __launch_bounds__(128) rz_strip_kernel(const PassParams *__restr
  * list's groups as in rz_crowd_kernel (33.4 -> 25.6 us with two; four and more waves per block no longer fit the device
  * at once and take longer again, 31 us and up; sharing a group's survivors instead of the groups: the same 25.9).
  * Such a launch has wave slots to spare, and a workgroup whose bin is empty spends its first two waves on its tile's
- * sky (`sky` with tables; sky_tile): nothing there waits for the strips, and rz_sky_kernel behind it is left with the
- * bins that have lists (sky in all: 17.7 -> 14.1 us). */
+ * sky (`sky` with tables; sky_tile): nothing there waits for the strips.  The sky of a tile whose bin has a list follows
+ * when the tile's two blocks are finished, by the waves that did not finish them: no sky kernel behind such a launch
+ * (strips and sky of a helmet frame 33.4 + 17.7 -> 34 us). */
 template <int SPLIT>
 __global__ void __launch_bounds__(128 * SPLIT) rz_strip_team_kernel(const PassParams *__restrict__ passes,
         const BinEntry *__restrict__ list_base, const uint2 *__restrict__ box_base,

@@ -38,16 +38,17 @@ RZ_DEV void shade_pixel(const PassParams &P, const TriRec *__restrict__ tri_base
  * the depth the pass's other triangles left -- or, in a bin whose list is empty, from the pending clear, which
  * this kernel then carries out for the pixels no sky triangle covers.
  *
- * sky_tile is a wave's part of it: tile (tile_x, tile_y) of pass P, wave 0 or 1 of the tile.  WHICH leaves bins out:
- * RZ_SKY_STALE_ONLY those whose list is empty -- nothing in them waits for the strips, and in a launch of a frame or two
- * the strips' kernel takes them along (rz_strip_team_kernel) instead of leaving them for a launch behind it.
+ * sky_tile is a wave's part of it: tile (tile_x, tile_y) of pass P, wave 0 or 1 of the tile.  WHICH leaves bins out
+ * (a constant wherever the function is inlined): RZ_SKY_FRESH_ONLY those with lists, RZ_SKY_STALE_ONLY those without --
+ * nothing in a bin without a list waits for the strips, and in a launch of a frame or two the strips' kernel takes the
+ * sky along in those two parts (rz_strip_team_kernel) instead of leaving it for a launch behind it.
  * DEFERS: beside the shade kernels (rz_sky_side_kernel).  There the sky must not take a pixel that holds a fragment
  * for them -- colour and reference would go to whoever wrote last -- and it can only where a fragment lies behind the
  * sky's depth (RZ_SKY_NEAR; the strips flag such a pass, control word 5): the bins with lists of a flagged pass are left
  * to rz_sky_late_kernel, which runs when the shade kernels are through. */
 enum { RZ_SKY_ALL = 0, RZ_SKY_FRESH_ONLY = 1, RZ_SKY_STALE_ONLY = 2 };
-template <int PPL, int WHICH, bool DEFERS>
-RZ_DEV void sky_tile(const PassParams &P, int tile_x, int tile_y, int wave, int lane,
+template <int PPL, bool DEFERS>
+RZ_DEV void sky_tile(const PassParams &P, int tile_x, int tile_y, int wave, int lane, int WHICH,
         const TriRec *__restrict__ tri_base, const TriRec *__restrict__ fan_base,
         const float *__restrict__ vary_base, const float *__restrict__ fan_vary_base,
         const char *__restrict__ upload_base, const SkyBin *__restrict__ sky_base) {
@@ -201,7 +202,7 @@ __global__ void __launch_bounds__(256 / PPL) rz_sky_kernel(const PassParams *__r
         const char *__restrict__ upload_base, const SkyBin *__restrict__ sky_base) {
     const PassParams P = passes[blockIdx.z];
     if ((int)blockIdx.x >= P.tiles_x || (int)blockIdx.y >= P.tiles_y || P.sky_draws == 0) return;
-    sky_tile<PPL, RZ_SKY_ALL, false>(P, (int)blockIdx.x, (int)blockIdx.y, (int)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), (int)(threadIdx.x & 63u),
+    sky_tile<PPL, false>(P, (int)blockIdx.x, (int)blockIdx.y, (int)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), (int)(threadIdx.x & 63u), RZ_SKY_ALL,
                               tri_base, fan_base, vary_base, fan_vary_base, upload_base, sky_base);
 }
 /* ... beside the shade kernels, on the lane's side stream */
@@ -212,7 +213,7 @@ __global__ void __launch_bounds__(256 / PPL) rz_sky_side_kernel(const PassParams
         const char *__restrict__ upload_base, const SkyBin *__restrict__ sky_base) {
     const PassParams P = passes[blockIdx.z];
     if ((int)blockIdx.x >= P.tiles_x || (int)blockIdx.y >= P.tiles_y || P.sky_draws == 0) return;
-    sky_tile<PPL, RZ_SKY_ALL, true>(P, (int)blockIdx.x, (int)blockIdx.y, (int)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), (int)(threadIdx.x & 63u),
+    sky_tile<PPL, true>(P, (int)blockIdx.x, (int)blockIdx.y, (int)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), (int)(threadIdx.x & 63u), RZ_SKY_ALL,
                                     tri_base, fan_base, vary_base, fan_vary_base, upload_base, sky_base);
 }
 /* ... and what that one left: the bins with lists of the passes flagged as holding fragments the sky may hide.  Hardly
@@ -229,22 +230,10 @@ __global__ void __launch_bounds__(256 / PPL) rz_sky_late_kernel(const PassParams
         const PassParams P = passes[p];
         if (P.sky_draws == 0 || P.control[5] == 0u) continue;
         for (uint32_t tile = blockIdx.x; tile < (uint32_t)(P.tiles_x * P.tiles_y); tile += gridDim.x)
-            sky_tile<PPL, RZ_SKY_STALE_ONLY, false>(P, (int)(tile % (uint32_t)P.tiles_x), (int)(tile / (uint32_t)P.tiles_x), wave, lane,
+            sky_tile<PPL, false>(P, (int)(tile % (uint32_t)P.tiles_x), (int)(tile / (uint32_t)P.tiles_x), wave, lane, RZ_SKY_STALE_ONLY,
                                                     tri_base, fan_base, vary_base, fan_vary_base, upload_base, sky_base);
     }
 }
-/* ... behind a launch of rz_strip_team_kernel that took the empty bins' sky along */
-template <int PPL>
-__global__ void __launch_bounds__(256 / PPL) rz_sky_stale_kernel(const PassParams *__restrict__ passes,
-        const TriRec *__restrict__ tri_base, const TriRec *__restrict__ fan_base,
-        const float *__restrict__ vary_base, const float *__restrict__ fan_vary_base,
-        const char *__restrict__ upload_base, const SkyBin *__restrict__ sky_base) {
-    const PassParams P = passes[blockIdx.z];
-    if ((int)blockIdx.x >= P.tiles_x || (int)blockIdx.y >= P.tiles_y || P.sky_draws == 0) return;
-    sky_tile<PPL, RZ_SKY_STALE_ONLY, false>(P, (int)blockIdx.x, (int)blockIdx.y, (int)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), (int)(threadIdx.x & 63u),
-                                     tri_base, fan_base, vary_base, fan_vary_base, upload_base, sky_base);
-}
-
 /* over the family's work list: a fixed number of workgroups strides over it, so no wave is spent on
  * pixels without work.  The list holds 32x8 tiles (one per workgroup and turn, a wave takes two rows
  * of 32 pixels) or, with BLOCKS, the 16x8 blocks rz_strip_kernel lists (two per workgroup and turn,
