@@ -422,9 +422,6 @@ RZ_DEV uint32_t outwards(uint32_t turn, uint32_t count) {      /* 0, 1, 2, .. ->
 RZ_DEV TileOrder tile_order(uint32_t rows_per_bin) {
     TileOrder o;
     o.pass = blockIdx.x;
-#ifdef RZ_ORDER_PLAIN
-    o.column = blockIdx.y; o.row = blockIdx.z; return o;
-#endif
     o.column = outwards(blockIdx.y / 2u, gridDim.y / 2u) * 2u + (blockIdx.y & 1u);
     o.row = outwards(blockIdx.z / rows_per_bin, gridDim.z / rows_per_bin) * rows_per_bin + blockIdx.z % rows_per_bin;
     return o;
