@@ -470,6 +470,88 @@ def test_triangles_that_reach_behind_the_sky(gpu, oracle, frames):
         assert float(depth.max()) <= float(sky_depth) + 1e-6        # nothing shows from behind the sky
 
 
+@pytest.mark.parametrize("frames", [2, 12], ids=["two_frames", "twelve_frames"])
+def test_sky_over_unusual_clears(gpu, oracle, frames):
+    """A triangle and the sky box into framebuffers that start differently: colour and depth cleared, depth cleared
+    to 0.5 (nothing behind it shows, the sky least of all), colour cleared only, nothing cleared, and a second
+    pass on top of a first without any clear between them.  Who carries a pending clear out where -- the bins'
+    kernel, the strips, the sky -- differs from bin to bin and with the number of frames in the flush; the
+    pictures must not."""
+    size = (416, 288)
+    rng = np.random.default_rng(15)
+    images = [rng.integers(0, 256, (16, 16, 4)).astype(np.float32) / np.float32(255) for _ in range(6)]
+    results = []
+    for pipe in (gpu, oracle):
+        lib = pipe.lib
+        declare(lib)
+        P = C.c_void_p
+        lib.texture_create.restype = C.POINTER(HostTexture)
+        lib.texture_create.argtypes = [C.c_int, C.c_int]
+        lib.texture_release.argtypes = [C.POINTER(HostTexture)]
+        lib.texture_invalidate.argtypes = [C.POINTER(HostTexture)]
+        cube = Cubemap()
+        for i in range(6):
+            cube.faces[i] = lib.texture_create(16, 16)
+            np.ctypeslib.as_array(cube.faces[i].contents.buffer, (16, 16, 4))[...] = images[i]
+            lib.texture_invalidate(cube.faces[i])
+        sky = lib.program_create(fn(lib, "skybox_vertex_shader"), fn(lib, "skybox_fragment_shader"), 12, 12, 72, 1, 0)
+        su = SkyboxUniforms.from_address(lib.program_get_uniforms(sky))
+        su.skybox = C.cast(C.pointer(cube), P)
+        front = lib.program_create(fn(lib, "blinn_vertex_shader"), fn(lib, "blinn_fragment_shader"), 64, 44, 344, 1, 0)
+        bu = BlinnUniforms.from_address(lib.program_get_uniforms(front))
+        bu.light_dir[:] = [0.0, 0.0, -1.0]
+        bu.camera_pos[:] = [0.0, 0.0, 2.0]
+        bu.model_matrix[:] = IDENTITY4[:]
+        bu.normal_matrix[:] = IDENTITY3[:]
+        bu.light_vp_matrix[:] = IDENTITY4[:]
+        bu.camera_vp_matrix[:] = IDENTITY4[:]
+        bu.ambient_intensity = 1.0
+        bu.punctual_intensity = 0.0
+        bu.shininess = 4.0
+        fbs = [pipe.framebuffer(*size) for _ in range(frames)]
+
+        def one_pass(fb, k, shift):
+            bu.basecolor[:] = [0.2 + 0.05 * (k % 7), 0.8 - 0.1 * shift, 0.3, 1.0]
+            for j, (x, y, z) in enumerate([(-0.8 + shift, -0.7, 0.1), (0.6 + shift, -0.5, 0.7), (-0.1 + shift, 0.8, 1.0)]):
+                a = BlinnAttribs.from_address(lib.program_get_attribs(front, j))
+                a.position[:] = [x, y, z]
+                a.texcoord[:] = [0.5, 0.5]
+                a.normal[:] = [0.0, 0.0, 1.0]
+                a.joint[:] = [0, 0, 0, 0]
+                a.weight[:] = [0, 0, 0, 0]
+            lib.graphics_draw_triangle(C.cast(fb, P), front)
+            su.vp_matrix[:] = [float(x) for x in look_from_inside(size[0] / size[1], 0.7 * k, 0.3 * np.cos(k)).reshape(-1)]
+            for quad in CUBE_FACES:
+                for tri in ((quad[0], quad[1], quad[2]), (quad[0], quad[2], quad[3])):
+                    for j in range(3):
+                        (C.c_float * 3).from_address(lib.program_get_attribs(sky, j))[:] = [float(x) for x in CUBE_CORNERS[tri[j]]]
+                    lib.graphics_draw_triangle(C.cast(fb, P), sky)
+
+        for k, fb in enumerate(fbs):
+            kind = k % 5
+            if kind in (0, 4):
+                lib.framebuffer_clear_color(fb, Vec4(0.3, 0.1, 0.6, 1.0))
+                lib.framebuffer_clear_depth(fb, 1.0)
+            elif kind == 1:
+                lib.framebuffer_clear_depth(fb, 0.5)
+            elif kind == 2:
+                lib.framebuffer_clear_color(fb, Vec4(0.9, 0.9, 0.1, 0.5))
+            one_pass(fb, k, 0.0)
+            if kind == 4:
+                one_pass(fb, k + 3, 0.25)           # a second pass on top: no clear
+        out = [pipe.read(fb) for fb in fbs]
+        for fb in fbs:
+            pipe.release(fb)
+        lib.program_release(sky)
+        lib.program_release(front)
+        for i in range(6):
+            lib.texture_release(cube.faces[i])
+        results.append(out)
+    for got, want in zip(*results):
+        assert same(got, want)
+    assert float(results[1][1][1].max()) <= 0.5                     # behind a depth of 0.5 nothing shows
+
+
 @pytest.mark.parametrize("blend", [0, 1], ids=["opaque", "second_blended"])
 def test_two_sky_boxes_in_one_pass(gpu, oracle, blend):
     """A sky box from inside, then triangles of a SECOND sky program (another cube map) over parts of it, all
