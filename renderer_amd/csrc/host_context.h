@@ -152,7 +152,7 @@ struct Context {
     bool strip_team = true;                 /* MI355R_STRIP_TEAM=0: a launch of at most two passes takes the plain strips, not two waves per block (rz_strip_team_kernel) */
     bool sky_with_strips = true;            /* MI355R_SKY_WITH_STRIPS=0: ... and that launch leaves the sky of empty bins to rz_sky_kernel */
     bool sky_table = true;                  /* MI355R_SKY_TABLE=0: a sky box goes through the bins like any other draw */
-    int fill_waves = 0;                     /* MI355R_FILL_WAVES: waves that share a chunk of 64 triangles in rz_bin_fill_kernel (1, 2, 4; unset: by the launch's size) */
+    int fill_waves = 0;                     /* MI355R_FILL_WAVES: waves that share a chunk of 64 triangles in rz_bin_fill_kernel (1, 2, 4, 8; unset: by the launch's size) */
     unsigned strip_long = 2048;             /* MI355R_STRIP_LONG: a batch whose framebuffers had a bin list of this many entries in their last frame takes one block per wave,
                                              * of half as many two; 0, or MI355R_STRIP set = always `strip` */
     int strip = 2;                          /* MI355R_STRIP: 16x8 blocks a wave of rz_strip_kernel takes (8, 4, 2, 1) */
@@ -286,7 +286,7 @@ extern "C" int mi355r_init(int device) {
         env = getenv("MI355R_SKY_TABLE");
         if (env) g.sky_table = atoi(env) != 0;
         env = getenv("MI355R_FILL_WAVES");
-        if (env) { const int v = atoi(env); if (v == 1 || v == 2 || v == 4) g.fill_waves = v; }
+        if (env) { const int v = atoi(env); if (v == 1 || v == 2 || v == 4 || v == 8) g.fill_waves = v; }
         env = getenv("MI355R_STRIP_LONG");
         if (env) g.strip_long = (unsigned)atoi(env);
         env = getenv("MI355R_SPLIT_BLEND");

@@ -420,9 +420,10 @@ static void launch_batch(const Batch &b, const std::vector<PassPlan> &plans, cha
         /* a chunk whose triangles lie far apart walks its bins in rounds of 64: with few chunks in the launch (a frame
          * or two) the rounds are shared out over four waves, with many one wave per chunk keeps more chunks in flight */
         const dim3 grid((unsigned)((max_T + 63) / 64 * n));
-        const int waves = g.fill_waves ? g.fill_waves : grid.x < 4096u ? 4 : 1;
+        const int waves = g.fill_waves ? g.fill_waves : grid.x < 1024u ? 8 : grid.x < 4096u ? 4 : 1;
         if (waves == 1) rz_bin_fill_kernel<1><<<grid, dim3(64), 0, st>>>(passes, n);
         else if (waves == 2) rz_bin_fill_kernel<2><<<grid, dim3(128), 0, st>>>(passes, n);
+        else if (waves == 8) rz_bin_fill_kernel<8><<<grid, dim3(512), 0, st>>>(passes, n);
         else rz_bin_fill_kernel<4><<<grid, dim3(256), 0, st>>>(passes, n);
     }
     stamp();

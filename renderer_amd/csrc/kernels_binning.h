@@ -262,7 +262,7 @@ __global__ void __launch_bounds__(64 * WAVES) rz_bin_fill_kernel(const PassParam
     if (turn >= chunks) return;                                 /* uniform over the workgroup */
     const uint32_t chunk = chunks - 1u - turn;
     if (P.control[2] != 0u) return;                             /* out of scratch, or left out: the pass is run again later */
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = (int)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t t = chunk * 64u + lane;
     const int bins = P.bins_x * P.bins_y;
     BinRect r;
@@ -308,8 +308,9 @@ __global__ void __launch_bounds__(64 * WAVES) rz_bin_fill_kernel(const PassParam
         /* The chunk's triangles lie in a few bins (a dense mesh: most chunks).  Lanes stay
          * triangles and the few bins are taken one after the other: the triangles that touch the
          * bin find their places behind the chunk's start in its list by a prefix over the lanes
-         * (ascending lane = submission order, as below) and write their entries side by side. */
-        if (wave != 0) return;
+         * (ascending lane = submission order, as below) and write their entries side by side.  Every wave of the
+         * workgroup holds the chunk: wave w takes bins w, w + WAVES, ... (a lone wave issues an instruction every few
+         * cycles; in a launch of a frame or two the chunk's turns, not the device, set the kernel's length). */
         /* lane i asks for bin i's start and whether its list is kept, all bins in one memory round trip
          * (asked for bin after bin inside the loop they were one dependent round trip each) */
         uint32_t my_start = 0u, my_kept = 0u;
@@ -318,7 +319,7 @@ __global__ void __launch_bounds__(64 * WAVES) rz_bin_fill_kernel(const PassParam
             my_start = row[b];
             my_kept = P.bin_range[b].y;         /* zero: the list is empty or overflowed, nothing is kept */
         }
-        for (int i = 0; i < ubins; i++) {
+        for (int i = wave; i < ubins; i += WAVES) {
             const int bx = ux0 + i % uw, by = uy0 + i / uw;
             const bool touch = r.entries != 0 && bx >= r.bx0 && bx <= r.bx1 && by >= r.by0 && by <= r.by1;
             const unsigned long long touching = __ballot(touch);
@@ -343,20 +344,23 @@ __global__ void __launch_bounds__(64 * WAVES) rz_bin_fill_kernel(const PassParam
          * ascending bin index, the wave takes the lowest bin any lane is at, the lanes at that bin find their places
          * with a prefix over the lanes as above and move on.  One turn per DISTINCT bin the chunk touches, where the
          * rounds below make 64 turns per 64 bins of the rectangle.  The starts of a lane's bins are asked for up front,
-         * in one memory round trip. */
-        if (wave != 0) return;
+         * in one memory round trip.  Of the workgroup's waves, each of which holds the chunk, wave w takes the bins whose
+         * index is w modulo WAVES: a lane's walk leaves out the bins of the other waves, and those whose lists are not
+         * kept (empty or overflowed). */
         uint32_t start[9];
+        uint32_t slots = 0;             /* bit q: place q of this lane's box is a bin for this wave to fill */
 #pragma unroll
         for (int q = 0; q < 9; q++) {
             const bool in_box = r.entries != 0 && q % 3 < w && q / 3 < h;
             const int b = in_box ? (r.by0 + q / 3) * P.bins_x + r.bx0 + q % 3 : 0;     /* (every lane loads: nothing waits on a branch) */
             const uint32_t first = row[b], kept = P.bin_range[b].y;
-            start[q] = in_box && kept != 0u ? first : 0xffffffffu;      /* not mine, or a list that is not kept (empty or overflowed) */
+            start[q] = first;
+            if (in_box && kept != 0u && (b & (WAVES - 1)) == wave) slots |= 1u << q;
         }
-        int px = 0, py = 0;
-        bool more = r.entries != 0;
         for (;;) {
-            const int mine = more ? (r.by0 + py) * P.bins_x + r.bx0 + px : 0x7fffffff;
+            /* places ascend with the bin's index (row by row): the lowest place left is the lane's next bin */
+            const int place = slots ? __builtin_ctz(slots) : 0, row_of = (place * 11) >> 5, col_of = place - 3 * row_of;
+            const int mine = slots ? (r.by0 + row_of) * P.bins_x + r.bx0 + col_of : 0x7fffffff;
             const int b = wave_min_i(mine);
             if (b == 0x7fffffff) break;
             const bool touch = mine == b;
@@ -369,13 +373,11 @@ __global__ void __launch_bounds__(64 * WAVES) rz_bin_fill_kernel(const PassParam
                 before = wave_exclusive_scan(touch ? r.entries : 0u, &total);
             }
             if (touch) {
-                const int at_slot = py * 3 + px;
                 uint32_t at = start[0];
 #pragma unroll
-                for (int q = 1; q < 9; q++) if (at_slot == q) at = start[q];
-                if (at != 0xffffffffu) fill_entries(P, at + before, ref, r.entries, r0, r1, r2, r3, slot, s_fan, fan_tri);
-                if (++px == w) { px = 0; py++; }
-                more = py < h;
+                for (int q = 1; q < 9; q++) if (place == q) at = start[q];
+                fill_entries(P, at + before, ref, r.entries, r0, r1, r2, r3, slot, s_fan, fan_tri);
+                slots &= slots - 1u;
             }
         }
         return;
