@@ -249,7 +249,7 @@ static void prepare_batch(const Batch &b, const FlushRecord &fr, bool reserve_on
     reserve(L.vary, tris * 3 * RZ_VARY_STRIDE, st);
     reserve(L.tri, tris, st);
     reserve(L.bbox, tris, st);
-    reserve(L.clip_list, tris, st);
+    reserve(L.clip_list, 2 * tris, st);                 /* (triangle, draw) */
     reserve(L.fan_tri, fans * RZ_MAX_FAN, st);
     reserve(L.fan_vary, fans * RZ_MAX_POLY * RZ_VARY_STRIDE, st);
     reserve(L.bin_range, bins, st);
@@ -307,7 +307,7 @@ static void prepare_batch(const Batch &b, const FlushRecord &fr, bool reserve_on
         P.vary = L.vary.ptr + tri_off * 3 * RZ_VARY_STRIDE;
         P.tri = L.tri.ptr + tri_off;
         P.bbox = L.bbox.ptr + tri_off;
-        P.clip_list = L.clip_list.ptr + tri_off;
+        P.clip_list = L.clip_list.ptr + 2 * tri_off;
         P.fan_tri = L.fan_tri.ptr + fan_off * RZ_MAX_FAN;
         P.fan_vary = L.fan_vary.ptr + fan_off * RZ_MAX_POLY * RZ_VARY_STRIDE;
         P.fan_capacity = (int)std::min<size_t>(fan_cap[k], 0x7fffffff);

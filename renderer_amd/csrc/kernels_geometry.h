@@ -214,7 +214,7 @@ __global__ void __launch_bounds__(256) rz_vertex_kernel(const PassParams *__rest
         } else {
             /* needs the clipper: queued for rz_clip_kernel, which fills tri/bbox */
             P.bbox[t] = empty;
-            P.clip_list[atomicAdd(&P.control[3], 1u)] = t;
+            P.clip_list.as<uint2>()[atomicAdd(&P.control[3], 1u)] = make_uint2(t, (uint32_t)dt);    /* (with its draw: the clipper need not search for it) */
             fate = 2;
         }
         s_fate[threadIdx.x] = fate;
@@ -496,8 +496,9 @@ __global__ void __launch_bounds__(64) rz_clip_kernel(const PassParams *__restric
     const int lane = threadIdx.x;
     const uint32_t queued = P.control[3];
     for (uint32_t item = blockIdx.x; item < queued; item += gridDim.x) {
-        const uint32_t t = P.clip_list[item];
-        const int d = find_draw(P.first_tri, P.num_draws, t);
+        const uint2 queued_item = P.clip_list.as<const uint2>()[item];
+        const uint32_t t = queued_item.x;
+        const int d = (int)queued_item.y;
         const DrawRec &D = P.draws[d];
         const int nv = D.num_varyings;
         const bool double_sided = (D.flags & RZ_DRAW_DOUBLE_SIDED) != 0;
@@ -528,6 +529,7 @@ __global__ void __launch_bounds__(64) rz_clip_kernel(const PassParams *__restric
             float r = 0;
             if (a_in != b_in) r = plane_crossing(a, b, plane);
             const uint32_t cross = (uint32_t)__ballot(lane < n && a_in != b_in), inside = (uint32_t)__ballot(lane < n && b_in);
+            if (cross == 0u && inside == (1u << n) - 1u) continue;     /* every corner inside: the plane leaves the polygon as it is (uniform) */
             float last = vals[0];
 #pragma unroll
             for (int i = 1; i < RZ_MAX_POLY; i++) if (i == n - 1) last = vals[i];

@@ -209,7 +209,7 @@ struct PassParams {
     rz_gptr<TriRec> fan_tri;                /* fan_capacity * RZ_MAX_FAN */
     rz_gptr<float> fan_vary;                /* fan_capacity * RZ_MAX_POLY * RZ_VARY_STRIDE */
     int32_t fan_capacity;
-    rz_gptr<uint32_t> clip_list;            /* triangles queued for the clipper (count in control[3]) */
+    rz_gptr<uint32_t> clip_list;            /* triangles queued for the clipper, each with its draw: pairs of words (count in control[3]) */
     /* binning */
     int32_t bins_x, bins_y;
     rz_gptr<uint32_t> bin_counts;           /* [chunks of 64 triangles][bins]: entries, then first entry */
