@@ -144,7 +144,16 @@ __global__ void __launch_bounds__(64 * RZ_SCAN_SEGMENTS) rz_bin_scan_kernel(cons
     const uint32_t c0 = min((uint32_t)segment * per, chunks), c1 = min(c0 + per, chunks);
     uint32_t *col = P.bin_counts + bin;
     uint32_t sum = 0;
-    if (bin < bins) {
+    /* a segment of at most 16 chunks (a frame or two per launch) is kept in registers between the two passes over it:
+     * read again it was two more memory round trips in a kernel that is nothing but round trips */
+    const bool few = per <= 16u;                    /* uniform */
+    uint32_t kept[16];
+    if (few) {
+#pragma unroll
+        for (int u = 0; u < 16; u++) kept[u] = (bin < bins && c0 + u < c1) ? col[(size_t)(c0 + u) * bins] : 0u;
+#pragma unroll
+        for (int u = 0; u < 16; u++) sum += kept[u];
+    } else if (bin < bins) {
         for (uint32_t c = c0; c < c1; c += 8u) {
             uint32_t v[8];
 #pragma unroll
@@ -198,6 +207,14 @@ __global__ void __launch_bounds__(64 * RZ_SCAN_SEGMENTS) rz_bin_scan_kernel(cons
     const uint32_t start = s_part[0][threadIdx.x & 63];
     if (bin >= bins || start == 0xffffffffu) return;    /* empty or overflowed bin: its entries are never written */
     uint32_t run = start + before;
+    if (few) {
+#pragma unroll
+        for (int u = 0; u < 16; u++) {
+            if (c0 + u < c1) col[(size_t)(c0 + u) * bins] = run;    /* count -> first entry of the chunk */
+            run += kept[u];
+        }
+        return;
+    }
     for (uint32_t c = c0; c < c1; c += 8u) {
         uint32_t v[8];
 #pragma unroll

@@ -39,9 +39,18 @@ __global__ void __launch_bounds__(256) rz_begin_kernel(const PassParams *__restr
     if (blockIdx.y == 0 && gv <= RZ_BATCH_CONTESTED) P.queue_counts[gv * RZ_QUEUE_PAD] = 0;    /* ... and the batch's work-list lengths and its flag word */
     for (uint32_t t = gv; t < (uint32_t)(P.tiles_x * P.tiles_y); t += gridDim.x * 256u) P.tile_listed[t] = 0;
     if (P.sky_draws && gv < (uint32_t)RZ_SKY_TABLE) P.sky_table[gv] = 0xffffffffu;      /* RZ_REF_NONE: no sky triangle yet */
-    {   /* ... and the pass's (chunk, bin) matrix, which rz_bin_count_kernel adds into */
+    {   /* ... and the pass's (chunk, bin) matrix, which rz_bin_count_kernel adds into (four words per store: the
+         * matrix of a batch's pass starts at a multiple of four words when every pass before it has a multiple of four
+         * cells, else word by word) */
         const uint32_t cells = (((uint32_t)P.num_tris + 63u) / 64u) * (uint32_t)(P.bins_x * P.bins_y);
-        for (uint32_t t = gv; t < cells; t += gridDim.x * 256u) P.bin_counts[t] = 0;
+        uint32_t RZ_GLOBAL *counts = P.bin_counts;
+        if ((((size_t)counts) & 15u) == 0u) {
+            const uint32_t quads = cells / 4u;
+            for (uint32_t t = gv; t < quads; t += gridDim.x * 256u) ((uint4 RZ_GLOBAL*)counts)[t] = make_uint4(0u, 0u, 0u, 0u);
+            if (gv < (cells & 3u)) counts[quads * 4u + gv] = 0;
+        } else {
+            for (uint32_t t = gv; t < cells; t += gridDim.x * 256u) counts[t] = 0;
+        }
     }
 }
 
