@@ -544,7 +544,8 @@ static void launch_batch(const Batch &b, const std::vector<PassPlan> &plans, cha
         stamp();
         if (forked) {
             HIP_OK(hipStreamWaitEvent(st, L.join, 0));
-            rz_sky_late_kernel<2><<<shade_grid, dim3(128), 0, st>>>(passes, n, L.tri.ptr, L.fan_tri.ptr, L.vary.ptr, L.fan_vary.ptr, db, L.sky_bins.ptr, L.queue_counts.ptr);
+            /* (hardly ever more than a look at the batch's flag word: a small grid) */
+            rz_sky_late_kernel<2><<<dim3(std::min(shade_grid.x, 512u)), dim3(128), 0, st>>>(passes, n, L.tri.ptr, L.fan_tri.ptr, L.vary.ptr, L.fan_vary.ptr, db, L.sky_bins.ptr, L.queue_counts.ptr);
         }
     }
     HIP_OK(hipGetLastError());

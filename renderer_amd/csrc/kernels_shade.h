@@ -76,9 +76,9 @@ RZ_DEV void sky_tile(const PassParams &P, int tile_x, int tile_y, int wave, int 
     for (uint32_t e = 0; e < RZ_SKY_BIN_MAX; e++) refs[e] = bin.ref[e];
     if (failed != 0u) return;                         /* the pass did not run */
     if ((WHICH == RZ_SKY_FRESH_ONLY && !fresh) || (WHICH == RZ_SKY_STALE_ONLY && fresh)) return;
-    if (DEFERS && contested != 0u && !fresh) return;  /* rz_sky_late_kernel's */
-    const bool overflow = sky_count == RZ_SKY_BIN_OVERFLOW;
-    const uint32_t entries = overflow ? 0u : (sky_word >> ((region & 3u) * 8u)) & 0xffu;
+    const bool left = DEFERS && contested != 0u && !fresh;      /* rz_sky_late_kernel's: nothing to do here, as if no entry touched the region */
+    const bool overflow = !left && sky_count == RZ_SKY_BIN_OVERFLOW;
+    const uint32_t entries = overflow || left ? 0u : (sky_word >> ((region & 3u) * 8u)) & 0xffu;
     /* in a bin whose list is empty nothing has consumed the pass's clears; elsewhere rz_strip_kernel has */
     const bool clear_depth = fresh && P.clear_depth_pending, clear_color = fresh && P.clear_color_pending;
     if (!overflow && entries == 0u && !clear_depth && !clear_color) return;     /* uniform */
