@@ -416,27 +416,37 @@ static void launch_batch(const Batch &b, const std::vector<PassPlan> &plans, cha
     stamp();
     rz_bin_count_kernel<<<tgrid, dim3(256), 0, st>>>(passes);
     rz_bin_scan_kernel<<<dim3((unsigned)((max_bins + 63) / 64), n), dim3(64 * RZ_SCAN_SEGMENTS), 0, st>>>(passes);
+    /* a pass with blended draws: either everything in the ordered kernel (visibility and shading
+     * together, fragment stacks), or visibility first, the ordered kernel for the tiles where
+     * blended fragments pile up and the shade kernels for the rest */
+    const bool ordered_only = b.has_blend && !splits_blend(batch_tiles, n);
     {
         /* a chunk whose triangles lie far apart walks its bins in rounds of 64: with few chunks in the launch (a frame
          * or two) the rounds are shared out over four waves, with many one wave per chunk keeps more chunks in flight */
-        const dim3 grid((unsigned)((max_T + 63) / 64 * n));
-        const int waves = g.fill_waves ? g.fill_waves : grid.x < 1024u ? 8 : grid.x < 4096u ? 4 : 1;
-        if (waves == 1) rz_bin_fill_kernel<1><<<grid, dim3(64), 0, st>>>(passes, n);
-        else if (waves == 2) rz_bin_fill_kernel<2><<<grid, dim3(128), 0, st>>>(passes, n);
-        else if (waves == 8) rz_bin_fill_kernel<8><<<grid, dim3(512), 0, st>>>(passes, n);
-        else rz_bin_fill_kernel<4><<<grid, dim3(256), 0, st>>>(passes, n);
+        const unsigned fill_blocks = (unsigned)((max_T + 63) / 64 * n);
+        const int waves = g.fill_waves ? g.fill_waves : fill_blocks < 1024u ? 8 : fill_blocks < 4096u ? 4 : 1;
+        /* the strips' passes: what a strip has to do with its bin is worked out by the same launch, a wave per bin in
+         * workgroups behind those that fill (empty bins are finished there; a pass with a table of sky triangles gets
+         * its bins' records for rz_sky_kernel) */
+        ClassTables classes;
+        classes.tri_base = L.tri.ptr; classes.fan_base = L.fan_tri.ptr; classes.bin_range_base = L.bin_range.ptr;
+        classes.sky_base = L.sky_bins.ptr; classes.class_base = L.bin_class.ptr;
+        classes.max_bins = (uint32_t)max_bins; classes.fill_blocks = fill_blocks;
+        const unsigned class_blocks = b.has_blend ? 0u : (unsigned)((max_bins * n + (size_t)waves - 1) / (size_t)waves);
+        const dim3 grid(fill_blocks + class_blocks);
+        if (waves == 1) rz_bin_fill_kernel<1><<<grid, dim3(64), 0, st>>>(passes, n, classes);
+        else if (waves == 2) rz_bin_fill_kernel<2><<<grid, dim3(128), 0, st>>>(passes, n, classes);
+        else if (waves == 8) rz_bin_fill_kernel<8><<<grid, dim3(512), 0, st>>>(passes, n, classes);
+        else rz_bin_fill_kernel<4><<<grid, dim3(256), 0, st>>>(passes, n, classes);
     }
     stamp();
     bool narrow = true;
     for (size_t i : b.members) narrow = narrow && plans[i].narrow_texels;
-    /* a pass with blended draws: either everything in the ordered kernel (visibility and shading
-     * together, fragment stacks), or visibility first, the ordered kernel for the tiles where
-     * blended fragments pile up and the shade kernels for the rest */
     const int only = b.families == (1 << RZ_FAMILY_BLINN) ? 0 : b.families == (1 << RZ_FAMILY_PBR) ? 1 : -1;
     bool in_strips = false;                         /* the shade lists hold 16x8 blocks */
     bool crowd_forked = false;
     bool sky_with_strips = false;                   /* the strips' launch takes the sky of empty bins along */
-    if (b.has_blend && !splits_blend(batch_tiles, n)) {
+    if (ordered_only) {
         /* over the tiles of the bins that are not empty (listed by rz_bin_scan_kernel) */
         auto kernel = rz_raster_list_kernel<-1, false>;
         if (only == 0) kernel = narrow ? rz_raster_list_kernel<0, true> : rz_raster_list_kernel<0, false>;
@@ -469,9 +479,6 @@ static void launch_batch(const Batch &b, const std::vector<PassPlan> &plans, cha
             const int strip = !g.strip_long ? g.strip : std::min(few, longest >= g.strip_long ? 1 : longest >= g.strip_long / 2 ? std::min(g.strip, 2) : g.strip);
             const unsigned strips_per_bin = RZ_BIN / (8u * strip);
             auto kernel = strip == 8 ? rz_strip_kernel<8> : strip == 4 ? rz_strip_kernel<4> : strip == 2 ? rz_strip_kernel<2> : rz_strip_kernel<1>;
-            /* empty bins are finished by the kernel that says so; a pass with a table of sky triangles gets its bins' records for rz_sky_kernel */
-            rz_bin_class_kernel<<<dim3((unsigned)max_bins, n), dim3(64), 0, st>>>(passes, L.tri.ptr, L.fan_tri.ptr, L.bin_range.ptr,
-                                                                             L.sky_bins.ptr, L.bin_class.ptr);
             if (g.verbose) fprintf(stderr, "mi355r: batch of %u passes, longest bin list last time %u entries, strips of %d\n", n, longest, strip);
             snprintf(g.last_raster_kernel, sizeof g.last_raster_kernel, "rz_strip_kernel<%d>", strip);
             /* a launch of a frame or two: a team of waves per block, the sky of empty bins in the same launch

@@ -268,8 +268,31 @@ RZ_DEV void fill_entries(const PassParams &P, uint32_t at, uint32_t ref, uint32_
  * that touch its bin.  No lane waits on another and the only dependent loads
  * are the per-bin start offsets.  Every entry carries a copy of the
  * triangle's record. */
+/* what the bins' classes are worked out from and written to (bin_class_of, kernels_raster.h): the workgroups of
+ * rz_bin_fill_kernel's launch from number fill_blocks on take the batch's bins, a wave each */
+struct SkyBin;
+struct ClassTables {
+    const TriRec *tri_base, *fan_base;
+    const uint2 *bin_range_base;
+    SkyBin *sky_base;
+    uint32_t *class_base;
+    uint32_t max_bins, fill_blocks;
+};
+#define RZ_CLASS_SELECTED 8u
+RZ_DEV void bin_class_of(const PassParams *__restrict__ passes, uint32_t pass_index, uint32_t bin_index, int lane, uint32_t *s_sel,
+                         const ClassTables &tables);
+
 template <int WAVES>
-__global__ void __launch_bounds__(64 * WAVES) rz_bin_fill_kernel(const PassParams *__restrict__ passes, uint32_t num_passes) {
+__global__ void __launch_bounds__(64 * WAVES) rz_bin_fill_kernel(const PassParams *__restrict__ passes, uint32_t num_passes, const ClassTables classes) {
+    if (blockIdx.x >= classes.fill_blocks) {                    /* uniform over the workgroup */
+        __shared__ uint32_t s_selected[WAVES][RZ_CLASS_SELECTED];
+        const uint32_t wave_of_group = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+        const uint32_t item = (blockIdx.x - classes.fill_blocks) * (uint32_t)WAVES + wave_of_group;
+        const uint32_t pass_index = item / classes.max_bins;
+        if (pass_index < num_passes)
+            bin_class_of(passes, pass_index, item - pass_index * classes.max_bins, (int)(threadIdx.x & 63u), s_selected[wave_of_group], classes);
+        return;
+    }
     /* Workgroups start in index order: the pass is the fastest part of the index and a pass's chunks are taken
      * from its last one down.  The chunks that run longest are those of triangles over many bins, i.e. the sky
      * box, which a frame draws last (test_helper.c:497-503): they start first in every pass instead of making

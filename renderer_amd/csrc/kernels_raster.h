@@ -694,19 +694,24 @@ RZ_DEV const TriRec *ref_record(uint32_t ref, const TriRec *tri_table, const Tri
 enum { RZ_BIN_STRIP = 0, RZ_BIN_DONE = 1, RZ_BIN_CROWD = 2 };
 /* a 16x8 block on a work list */
 #define RZ_BLOCK_ITEM(pass, by, bx) (((uint32_t)(pass) << 21) | ((uint32_t)(by) << 10) | (uint32_t)(bx))
-__global__ void __launch_bounds__(64) rz_bin_class_kernel(const PassParams *__restrict__ passes,
-        const TriRec *__restrict__ tri_base, const TriRec *__restrict__ fan_base,
-        const uint2 *__restrict__ bin_range_base, SkyBin *__restrict__ sky_base, uint32_t *__restrict__ class_base) {
-    const PassParams &P = passes[blockIdx.y];
-    if ((int)blockIdx.x >= P.bins_x * P.bins_y) return;
-    const int lane = threadIdx.x & 63;
-    uint32_t *bin_class = class_base + P.bin_off + blockIdx.x;
+static_assert(RZ_SKY_BIN_MAX == RZ_CLASS_SELECTED, "a wave's list of selected table entries");
+/* (a wave's part of rz_bin_fill_kernel's launch: the workgroups behind those that fill -- neither reads what the other
+ * writes, and in a launch of a frame or two each is as long as its chain of round trips, which now run side by side) */
+RZ_DEV void bin_class_of(const PassParams *__restrict__ passes, uint32_t pass_index, uint32_t bin_index, int lane, uint32_t *s_sel,
+                         const ClassTables &tables) {
+    const TriRec *__restrict__ tri_base = tables.tri_base, *__restrict__ fan_base = tables.fan_base;
+    const uint2 *__restrict__ bin_range_base = tables.bin_range_base;
+    SkyBin *__restrict__ sky_base = tables.sky_base;
+    uint32_t *__restrict__ class_base = tables.class_base;
+    const PassParams &P = passes[pass_index];
+    if ((int)bin_index >= P.bins_x * P.bins_y) return;
+    uint32_t *bin_class = class_base + P.bin_off + bin_index;
     if (P.control[2] != 0u) {                                   /* out of scratch, or left out: the pass is run again later */
         if (lane == 0) *bin_class = RZ_BIN_DONE;
         return;
     }
-    const uint2 range = (bin_range_base + P.bin_off)[blockIdx.x];
-    const int bin_x0 = (int)(blockIdx.x % (uint32_t)P.bins_x) * RZ_BIN, bin_y0 = (int)(blockIdx.x / (uint32_t)P.bins_x) * RZ_BIN;
+    const uint2 range = (bin_range_base + P.bin_off)[bin_index];
+    const int bin_x0 = (int)(bin_index % (uint32_t)P.bins_x) * RZ_BIN, bin_y0 = (int)(bin_index / (uint32_t)P.bins_x) * RZ_BIN;
     /* a crowded bin is left to rz_crowd_kernel: its 16x8 blocks go on that kernel's work list, block by lane */
     const bool crowd = P.crowd_min > 0 && range.y >= (uint32_t)P.crowd_min;
     if (lane == 0) *bin_class = range.y == 0u ? (uint32_t)RZ_BIN_DONE : crowd ? (uint32_t)RZ_BIN_CROWD : (uint32_t)RZ_BIN_STRIP;
@@ -716,7 +721,7 @@ __global__ void __launch_bounds__(64) rz_bin_class_kernel(const PassParams *__re
             const uint32_t way = RZ_CROWD_LIST * RZ_QUEUE_WAYS + ((block_y * 2u * (uint32_t)P.tiles_x + block_x) & (RZ_QUEUE_WAYS - 1u));
             const uint32_t at = atomicAdd(&P.queue_counts[way * RZ_QUEUE_PAD], 1u);
             if (at < P.queue_capacity)
-                P.queue[(size_t)way * P.queue_capacity + at] = RZ_BLOCK_ITEM(blockIdx.y, block_y, block_x);
+                P.queue[(size_t)way * P.queue_capacity + at] = RZ_BLOCK_ITEM(pass_index, block_y, block_x);
             else
                 atomicOr(&P.control[2], (uint32_t)RZ_ERR_QUEUE_OVERFLOW);
         }
@@ -749,7 +754,6 @@ __global__ void __launch_bounds__(64) rz_bin_class_kernel(const PassParams *__re
     /* ---- the bin's record for rz_sky_kernel: the table entries whose box meets the bin, in table order ... */
     const TriRec *tri_table = tri_base + P.tri_off;
     const TriRec *fan_table = fan_base + (size_t)P.fan_off * RZ_MAX_FAN;
-    __shared__ uint32_t s_sel[RZ_SKY_BIN_MAX];
     uint32_t count = 0;                                         /* wave-uniform */
     const int table_entries = P.sky_draws * RZ_SKY_FACES * RZ_MAX_FAN;
     for (int first = 0; first < table_entries && count <= RZ_SKY_BIN_MAX; first += 64) {
@@ -778,7 +782,7 @@ __global__ void __launch_bounds__(64) rz_bin_class_kernel(const PassParams *__re
                              !block_outside(c0, c1, (float)rx0 + 0.5f, (float)(rx0 + RZ_TILE_W - 1) + 0.5f, (float)ry0 + 0.5f, (float)ry0 + 3.5f);
             mine |= (hit ? 1u : 0u) << e;
         }
-    SkyBin *rec = sky_base + P.bin_off + blockIdx.x;
+    SkyBin *rec = sky_base + P.bin_off + bin_index;
     if (lane < 32) rec->entries_of_region[lane] = (uint8_t)mine;
     if (lane >= 32 && lane < 32 + (int)RZ_SKY_BIN_MAX) rec->ref[lane - 32] = (uint32_t)(lane - 32) < count ? s_sel[lane - 32] : RZ_REF_NONE;
     if (lane == 40) rec->count = overflow ? RZ_SKY_BIN_OVERFLOW : count;
