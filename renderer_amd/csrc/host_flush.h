@@ -33,6 +33,7 @@ struct PassPlan {
     size_t first, last;             /* range in g.pending (while the flush is being put together) */
     size_t T;                       /* triangles */
     size_t off_draws, off_first;    /* offsets from the region start */
+    size_t off_sky_table;           /* ... of the pass's table of sky triangles (sky_draws > 0) */
     std::vector<size_t> side_at, verts_at;
     bool has_blend, samples_gpu_texture;
     bool narrow_texels;             /* every blinn / pbr draw samples 4-byte images only */
@@ -72,6 +73,8 @@ static void plan_pass(PassPlan &pl, size_t &total) {
     for (size_t i = pl.first; i < pl.sky_first; i++)
         if (pl.has_blend || !(g.pending[i].rec.flags & RZ_DRAW_SHADOW_PASS)) pl.families |= 1 << g.pending[i].rec.family;
     total = (total + 255) & ~(size_t)255;
+    pl.off_sky_table = total;
+    if (pl.sky_draws > 0) total += sizeof(uint32_t) * RZ_SKY_TABLE;
     pl.off_draws = total;
     total += sizeof(DrawRec) * D;
     pl.off_first = total;
@@ -150,6 +153,7 @@ struct Batch {
     bool has_blend;
     int families;
     bool sky_table = false;         /* one of its passes keeps sky boxes on its table of sky triangles */
+    bool fast_start = false;        /* no pass of it waits for another pass of the flush, none is run again: no rz_begin_kernel */
     bool crowd = false;             /* its crowded bins are rz_crowd_kernel's (settled when the batch is put together: its passes' parameters and its launches must agree) */
 };
 
@@ -254,7 +258,6 @@ static void prepare_batch(const Batch &b, const FlushRecord &fr, bool reserve_on
     reserve(L.fan_vary, fans * RZ_MAX_POLY * RZ_VARY_STRIDE, st);
     reserve(L.bin_range, bins, st);
     reserve(L.sky_bins, bins, st);
-    reserve(L.sky_table, b.members.size() * RZ_SKY_TABLE, st);
     reserve(L.bin_class, bins, st);
     reserve(L.bin_counts, matrix, st);
     /* tiles are dealt to the parts of a list by their index: a part holds at most its even share */
@@ -320,7 +323,12 @@ static void prepare_batch(const Batch &b, const FlushRecord &fr, bool reserve_on
         P.bin_capacity = (uint32_t)list_cap[k];
         P.ref = L.ref.ptr ? L.ref.ptr + ref_off : nullptr;
         P.sky_draws = pl.sky_draws;
-        P.sky_table = L.sky_table.ptr + k * RZ_SKY_TABLE;
+        /* the table of sky triangles lives in the flush's upload region, where the host has marked every entry as
+         * empty: the vertex kernel finds it ready (a batch run again: rz_begin_kernel marks it anew) */
+        if (mode == PREPARE_FIRST) {
+            P.sky_table = pl.sky_draws > 0 ? (uint32_t*)(db + pl.off_sky_table) : nullptr;
+            if (pl.sky_draws > 0) memset(hb + pl.off_sky_table, 0xff, sizeof(uint32_t) * RZ_SKY_TABLE);
+        }
         P.counters = g.counting ? g.d_counters : nullptr;
         P.scan_list = !b.has_blend ? -1 : splits_blend(tiles, b.members.size()) ? (int)RZ_VISIBILITY_LIST : (int)RZ_ORDERED_LIST;
         P.micro_area = g.micro_area;
@@ -402,15 +410,24 @@ static void launch_batch(const Batch &b, const std::vector<PassPlan> &plans, cha
             tris += plans[i].T;
             bins += (size_t)((plans[i].fb->pub.width + RZ_BIN - 1) / RZ_BIN) * ((plans[i].fb->pub.height + RZ_BIN - 1) / RZ_BIN);
         }
-        if (L.bin_range.cap < bins || L.bin_class.cap < bins || L.sky_bins.cap < bins || L.sky_table.cap < b.members.size() * RZ_SKY_TABLE) fatal("per-bin scratch of lane %d is smaller than the batch it is about to run", b.lane);
+        if (L.bin_range.cap < bins || L.bin_class.cap < bins || L.sky_bins.cap < bins) fatal("per-bin scratch of lane %d is smaller than the batch it is about to run", b.lane);
         const bool uses_ref = !(b.has_blend && !splits_blend(batch_tiles, n));
         if (L.queue_counts.cap < (RZ_BATCH_CONTESTED + 1u) * RZ_QUEUE_PAD || L.queue.cap < RZ_LISTS * RZ_QUEUE_WAYS * (size_t)queue_capacity ||
             L.tile_listed.cap < batch_tiles || L.bin_boxes.cap < L.bin_list.cap || (uses_ref && (!L.ref.ptr || L.ref.cap < pixels)) || L.tri.cap < tris || L.bbox.cap < tris)
             fatal("scratch of lane %d is smaller than the batch it is about to run", b.lane);
     }
     stamp();
-    rz_begin_kernel<<<dim3(64, n), dim3(256), 0, st>>>(passes);
-    rz_vertex_kernel<<<vgrid, dim3(256), 0, st>>>(passes);      /* with the triangles' set-up */
+    /* What the batch's kernels count in or add into starts at zero.  A batch whose passes depend on no other pass of
+     * their flush has its control blocks and sky tables from the upload, ready, and the rest -- lane scratch that nothing
+     * before the bin count looks at -- is zeroed by workgroups behind those of the vertex kernel, in its launch: one
+     * kernel less in the chain of a frame drawn and waited for.  Any other batch (passes that may have to be left out,
+     * passes run again) starts with rz_begin_kernel. */
+    if (b.fast_start) {
+        rz_vertex_kernel<<<dim3(vgrid.x + RZ_BEGIN_BLOCKS, n), dim3(256), 0, st>>>(passes, vgrid.x);
+    } else {
+        rz_begin_kernel<<<dim3(RZ_BEGIN_BLOCKS, n), dim3(256), 0, st>>>(passes);
+        rz_vertex_kernel<<<vgrid, dim3(256), 0, st>>>(passes, vgrid.x);      /* with the triangles' set-up */
+    }
     stamp();
     rz_clip_kernel<<<dim3(256, n), dim3(64), 0, st>>>(passes);
     stamp();
@@ -920,6 +937,7 @@ extern "C" void graphics_flush(void) {
                     if (lane < 0 || lane >= lanes) { lane = g.next_lane % lanes; g.next_lane = (g.next_lane + 1) % lanes; }
                     b.lane = lane;
                     b.crowd = wants_crowd(b, plans);
+                    b.fast_start = l == 0 && g.fast_start;
                     batches.push_back(std::move(b));
                     b = Batch();
                 };
@@ -939,7 +957,7 @@ extern "C" void graphics_flush(void) {
 
     fr.at = ring_alloc(total);
     char *hb = g.ring_host + fr.at, *db = g.ring_dev + fr.at;
-    memset(hb + fr.flag_at, 0, 256);
+    memset(hb, 0, fr.flag_at + 256);            /* the passes' control blocks and the flush's word */
     g_attach_jobs_at = fr.attach_jobs_at;
     g_attach_jobs_filled = 0;
     for (auto &pl : plans) fill_pass(pl, hb, db);
@@ -949,7 +967,7 @@ extern "C" void graphics_flush(void) {
     for (auto &b : batches) prepare_batch(b, fr, true, PREPARE_FIRST);
     for (auto &b : batches) prepare_batch(b, fr, false, PREPARE_FIRST);
     prof.mark(3);
-    HIP_OK(hipMemcpyAsync(db + fr.flag_at, hb + fr.flag_at, total - fr.flag_at, hipMemcpyHostToDevice, g.copy_stream));
+    HIP_OK(hipMemcpyAsync(db, hb, total, hipMemcpyHostToDevice, g.copy_stream));    /* (control blocks included: zero) */
     prof.mark(4);
     /* Now the flush before this one: everything above went on while the GPU was still busy with it, and
      * nothing has been launched yet.  If some of its passes had to run again the lanes' scratch may
@@ -959,7 +977,7 @@ extern "C" void graphics_flush(void) {
         HIP_OK(hipStreamSynchronize(g.copy_stream));
         for (auto &b : batches) prepare_batch(b, fr, true, PREPARE_REWRITE);
         for (auto &b : batches) prepare_batch(b, fr, false, PREPARE_REWRITE);
-        HIP_OK(hipMemcpyAsync(db + fr.flag_at, hb + fr.flag_at, total - fr.flag_at, hipMemcpyHostToDevice, g.copy_stream));
+        HIP_OK(hipMemcpyAsync(db, hb, total, hipMemcpyHostToDevice, g.copy_stream));
     }
     /* the flush's poses, and the model matrices of draws attached to a joint, behind the upload */
     if (fr.pose_jobs) {

@@ -29,16 +29,14 @@ RZ_DEV void mat_mul(const float *a, const float *b, float *c) {
     }
 }
 
-/* first kernel of a batch: what the passes' kernels count in or add into starts at zero */
-__global__ void __launch_bounds__(256) rz_begin_kernel(const PassParams *__restrict__ passes) {
-    const PassParams &P = passes[blockIdx.y];
-    const uint32_t gv = blockIdx.x * 256u + threadIdx.x;
-    /* the pass's device-written scalars start at zero -- unless another pass of the flush ran out of
-     * scratch and this one may depend on it: then it is marked to be left out and run again later */
-    if (gv < 8u) P.control[gv] = (gv == 2u && P.level > 0 && *P.flush_flag != 0u) ? (uint32_t)RZ_ERR_SKIPPED : 0u;
-    if (blockIdx.y == 0 && gv <= RZ_BATCH_CONTESTED) P.queue_counts[gv * RZ_QUEUE_PAD] = 0;    /* ... and the batch's work-list lengths and its flag word */
-    for (uint32_t t = gv; t < (uint32_t)(P.tiles_x * P.tiles_y); t += gridDim.x * 256u) P.tile_listed[t] = 0;
-    if (P.sky_draws && gv < (uint32_t)RZ_SKY_TABLE) P.sky_table[gv] = 0xffffffffu;      /* RZ_REF_NONE: no sky triangle yet */
+/* What the passes' kernels count in or add into starts at zero.  zero_lane_scratch: the part nothing before the bin
+ * count looks at (block `block` of RZ_BEGIN_BLOCKS of pass `pass`); rz_begin_kernel: that and what the vertex kernel
+ * itself adds into -- the pass's control block and its table of sky triangles. */
+#define RZ_BEGIN_BLOCKS 64u
+RZ_DEV void zero_lane_scratch(const PassParams &P, uint32_t pass, uint32_t block) {
+    const uint32_t gv = block * 256u + threadIdx.x, stride = RZ_BEGIN_BLOCKS * 256u;
+    if (pass == 0 && gv <= RZ_BATCH_CONTESTED) P.queue_counts[gv * RZ_QUEUE_PAD] = 0;    /* the batch's work-list lengths and its flag word */
+    for (uint32_t t = gv; t < (uint32_t)(P.tiles_x * P.tiles_y); t += stride) P.tile_listed[t] = 0;
     {   /* ... and the pass's (chunk, bin) matrix, which rz_bin_count_kernel adds into (four words per store: the
          * matrix of a batch's pass starts at a multiple of four words when every pass before it has a multiple of four
          * cells, else word by word) */
@@ -46,12 +44,21 @@ __global__ void __launch_bounds__(256) rz_begin_kernel(const PassParams *__restr
         uint32_t RZ_GLOBAL *counts = P.bin_counts;
         if ((((size_t)counts) & 15u) == 0u) {
             const uint32_t quads = cells / 4u;
-            for (uint32_t t = gv; t < quads; t += gridDim.x * 256u) ((uint4 RZ_GLOBAL*)counts)[t] = make_uint4(0u, 0u, 0u, 0u);
+            for (uint32_t t = gv; t < quads; t += stride) ((uint4 RZ_GLOBAL*)counts)[t] = make_uint4(0u, 0u, 0u, 0u);
             if (gv < (cells & 3u)) counts[quads * 4u + gv] = 0;
         } else {
-            for (uint32_t t = gv; t < cells; t += gridDim.x * 256u) counts[t] = 0;
+            for (uint32_t t = gv; t < cells; t += stride) counts[t] = 0;
         }
     }
+}
+__global__ void __launch_bounds__(256) rz_begin_kernel(const PassParams *__restrict__ passes) {
+    const PassParams &P = passes[blockIdx.y];
+    const uint32_t gv = blockIdx.x * 256u + threadIdx.x;
+    /* the pass's device-written scalars start at zero -- unless another pass of the flush ran out of
+     * scratch and this one may depend on it: then it is marked to be left out and run again later */
+    if (gv < 8u) P.control[gv] = (gv == 2u && P.level > 0 && *P.flush_flag != 0u) ? (uint32_t)RZ_ERR_SKIPPED : 0u;
+    if (P.sky_draws && gv < (uint32_t)RZ_SKY_TABLE) P.sky_table[gv] = 0xffffffffu;      /* RZ_REF_NONE: no sky triangle yet */
+    zero_lane_scratch(P, blockIdx.y, blockIdx.x);
 }
 
 RZ_DEV bool make_tri(const f4 c[3], int width, int height, bool double_sided, uint32_t draw,
@@ -90,8 +97,12 @@ RZ_DEV uint32_t draw_vary_groups(const DrawRec &D) {
  * other, so that a draw's record -- four matrices, flags, pointers -- comes through scalar loads once per wave; read
  * per lane those 60 words were three times the vertex itself and the kernel waited on the vector memory path. */
 #define RZ_VS_TRIS 85
-__global__ void __launch_bounds__(256) rz_vertex_kernel(const PassParams *__restrict__ passes) {
+__global__ void __launch_bounds__(256) rz_vertex_kernel(const PassParams *__restrict__ passes, uint32_t vertex_blocks) {
     const PassParams &P = passes[blockIdx.y];
+    if (blockIdx.x >= vertex_blocks) {              /* (a batch without rz_begin_kernel: the workgroups behind the vertices') */
+        zero_lane_scratch(P, blockIdx.y, blockIdx.x - vertex_blocks);
+        return;
+    }
     __shared__ float4 s_clip[256];
     __shared__ int s_fate[RZ_VS_TRIS + 1];          /* 0 culled, 1 alive, 2 for the clipper */
     __shared__ int s_draw[RZ_VS_TRIS + 1];
