@@ -147,7 +147,7 @@ struct Context {
     int crowd_min = 8192;                   /* MI355R_CROWD_MIN: bins with at least this many list entries have their blocks rasterised by several waves each, beside the strips (0: none) */
     bool crowd_always = false;              /* (set with MI355R_CROWD_MIN: also for framebuffers whose last frame is not known to have had such a bin) */
     int crowd_split = 4;                    /* MI355R_CROWD_SPLIT: that many (2, 4, 8, 16) */
-    bool fast_start = true;                 /* MI355R_FAST_START=0: every batch starts with rz_begin_kernel */
+    int fast_start = 1;                     /* MI355R_FAST_START=0: every batch starts with rz_begin_kernel; 2: none that need not (default: those of up to four passes) */
     bool sky_side = true;                   /* MI355R_SKY_SIDE=0: the sky kernel runs in line, on its batch's own stream */
     bool strip_team = true;                 /* MI355R_STRIP_TEAM=0: a launch of at most two passes takes the plain strips, not two waves per block (rz_strip_team_kernel) */
     bool sky_with_strips = true;            /* MI355R_SKY_WITH_STRIPS=0: ... and that launch leaves the sky of empty bins to rz_sky_kernel */
@@ -309,7 +309,7 @@ extern "C" int mi355r_init(int device) {
     }
     for (int i = 0; i < g.num_lanes; i++) HIP_OK(hipStreamCreateWithFlags(&g.lanes[i].stream, hipStreamNonBlocking));
     if (const char *env = getenv("MI355R_SKY_SIDE")) g.sky_side = atoi(env) != 0;
-    if (const char *env = getenv("MI355R_FAST_START")) g.fast_start = atoi(env) != 0;
+    if (const char *env = getenv("MI355R_FAST_START")) g.fast_start = std::max(0, std::min(atoi(env), 2));
     if (const char *env = getenv("MI355R_STRIP_TEAM")) g.strip_team = atoi(env) != 0;
     if (const char *env = getenv("MI355R_SKY_WITH_STRIPS")) g.sky_with_strips = atoi(env) != 0;
     if (const char *env = getenv("MI355R_CROWD_MIN")) { g.crowd_min = std::max(0, atoi(env)); g.crowd_always = true; }

@@ -937,7 +937,10 @@ extern "C" void graphics_flush(void) {
                     if (lane < 0 || lane >= lanes) { lane = g.next_lane % lanes; g.next_lane = (g.next_lane + 1) % lanes; }
                     b.lane = lane;
                     b.crowd = wants_crowd(b, plans);
-                    b.fast_start = l == 0 && g.fast_start;
+                    /* (a launch of a frame or two is as long as its chain of kernels; in a large batch the zeroing inside the
+                     * vertex kernel's launch, at that kernel's occupancy, costs more than the kernel it saves: 1.6 -> 1.9 us
+                     * per helmet frame) */
+                    b.fast_start = l == 0 && g.fast_start > 0 && (g.fast_start > 1 || b.members.size() <= 4);
                     batches.push_back(std::move(b));
                     b = Batch();
                 };
