@@ -423,10 +423,10 @@ static void launch_batch(const Batch &b, const std::vector<PassPlan> &plans, cha
      * kernel less in the chain of a frame drawn and waited for.  Any other batch (passes that may have to be left out,
      * passes run again) starts with rz_begin_kernel. */
     if (b.fast_start) {
-        rz_vertex_kernel<<<dim3(vgrid.x + RZ_BEGIN_BLOCKS, n), dim3(256), 0, st>>>(passes, vgrid.x);
+        rz_vertex_zero_kernel<<<dim3(vgrid.x + RZ_BEGIN_BLOCKS, n), dim3(256), 0, st>>>(passes, vgrid.x);
     } else {
         rz_begin_kernel<<<dim3(RZ_BEGIN_BLOCKS, n), dim3(256), 0, st>>>(passes);
-        rz_vertex_kernel<<<vgrid, dim3(256), 0, st>>>(passes, vgrid.x);      /* with the triangles' set-up */
+        rz_vertex_kernel<<<vgrid, dim3(256), 0, st>>>(passes);      /* with the triangles' set-up */
     }
     stamp();
     rz_clip_kernel<<<dim3(256, n), dim3(64), 0, st>>>(passes);
@@ -938,7 +938,7 @@ extern "C" void graphics_flush(void) {
                     b.lane = lane;
                     b.crowd = wants_crowd(b, plans);
                     /* (a launch of a frame or two is as long as its chain of kernels; in a large batch the zeroing inside the
-                     * vertex kernel's launch, at that kernel's occupancy, costs more than the kernel it saves: 1.6 -> 1.9 us
+                     * vertex kernel's launch, at that kernel's occupancy, costs more than the kernel it saves: 1.54 -> 1.66 us
                      * per helmet frame) */
                     b.fast_start = l == 0 && g.fast_start > 0 && (g.fast_start > 1 || b.members.size() <= 4);
                     batches.push_back(std::move(b));

@@ -97,11 +97,14 @@ RZ_DEV uint32_t draw_vary_groups(const DrawRec &D) {
  * other, so that a draw's record -- four matrices, flags, pointers -- comes through scalar loads once per wave; read
  * per lane those 60 words were three times the vertex itself and the kernel waited on the vector memory path. */
 #define RZ_VS_TRIS 85
-__global__ void __launch_bounds__(256) rz_vertex_kernel(const PassParams *__restrict__ passes, uint32_t vertex_blocks) {
+template <bool ZEROES>
+RZ_DEV void vertices_of_workgroup(const PassParams *__restrict__ passes, uint32_t vertex_blocks) {
     const PassParams &P = passes[blockIdx.y];
-    if (blockIdx.x >= vertex_blocks) {              /* (a batch without rz_begin_kernel: the workgroups behind the vertices') */
-        zero_lane_scratch(P, blockIdx.y, blockIdx.x - vertex_blocks);
-        return;
+    if constexpr (ZEROES) {
+        if (blockIdx.x >= vertex_blocks) {          /* (a batch without rz_begin_kernel: the workgroups behind the vertices') */
+            zero_lane_scratch(P, blockIdx.y, blockIdx.x - vertex_blocks);
+            return;
+        }
     }
     __shared__ float4 s_clip[256];
     __shared__ int s_fate[RZ_VS_TRIS + 1];          /* 0 culled, 1 alive, 2 for the clipper */
@@ -251,6 +254,15 @@ __global__ void __launch_bounds__(256) rz_vertex_kernel(const PassParams *__rest
     for (int i = 0; i < RZ_VARY_STRIDE / 4; i++)
         if ((groups >> i) & 1u) out[i] = make_float4(vary[4 * i], vary[4 * i + 1], vary[4 * i + 2], vary[4 * i + 3]);
 }
+__global__ void __launch_bounds__(256) rz_vertex_kernel(const PassParams *__restrict__ passes) {
+    vertices_of_workgroup<false>(passes, 0u);
+}
+/* ... with workgroups behind the vertices' that zero the lane's scratch (zero_lane_scratch): the first kernel of a batch
+ * that starts without rz_begin_kernel.  A kernel of its own: the branch alone cost the plain one a fifth of its time. */
+__global__ void __launch_bounds__(256) rz_vertex_zero_kernel(const PassParams *__restrict__ passes, uint32_t vertex_blocks) {
+    vertices_of_workgroup<true>(passes, vertex_blocks);
+}
+
 
 /* ========================================================================
  * K0  skeletal poses (renderer/core/skeleton.c:231-341), one wave per pose
