@@ -38,6 +38,7 @@ struct PassPlan {
     bool has_blend, samples_gpu_texture;
     bool narrow_texels;             /* every blinn / pbr draw samples 4-byte images only */
     int families;                   /* bit f: draws of family f that go through the bins */
+    bool sky_bytes;                 /* every sky box on the pass's table has its cube's plane of display bytes */
     size_t sky_first;               /* the pass's last sky_draws draws are sky boxes kept on its table of sky triangles: the first of them */
     int sky_draws;
     Fb *fb;
@@ -62,12 +63,14 @@ static void plan_pass(PassPlan &pl, size_t &total) {
     /* sky boxes drawn last in a pass without blending (the frame driver's order, test_helper.c:480-506) stay out of the bins */
     pl.sky_first = pl.last;
     pl.sky_draws = 0;
+    pl.sky_bytes = true;
     if (g.sky_table && !g.counting && !pl.has_blend)
         while (pl.sky_first > pl.first && pl.sky_draws < RZ_SKY_DRAWS) {
             const DrawRec &r = g.pending[pl.sky_first - 1].rec;
             if (r.family != RZ_FAMILY_SKYBOX || r.num_faces > RZ_SKY_FACES) break;
             pl.sky_first--;
             pl.sky_draws++;
+            pl.sky_bytes = pl.sky_bytes && (r.flags & RZ_DRAW_SKY_BYTES) != 0;
         }
     /* (a shadow pass's fragments are black: rz_strip_kernel writes them itself, no family's kernel has work from them) */
     for (size_t i = pl.first; i < pl.sky_first; i++)
@@ -153,6 +156,7 @@ struct Batch {
     bool has_blend;
     int families;
     bool sky_table = false;         /* one of its passes keeps sky boxes on its table of sky triangles */
+    bool sky_bytes = true;          /* ... and every such sky box has its cube's plane of display bytes */
     bool fast_start = false;        /* no pass of it waits for another pass of the flush, none is run again: no rz_begin_kernel */
     bool crowd = false;             /* its crowded bins are rz_crowd_kernel's (settled when the batch is put together: its passes' parameters and its launches must agree) */
 };
@@ -542,7 +546,7 @@ static void launch_batch(const Batch &b, const std::vector<PassPlan> &plans, cha
             }
             /* beside the shade kernels the sky keeps its hands off the bins of passes where it may hide a fragment they
              * shade (whichever wrote last would show); those bins follow behind the join */
-            auto sky_kernel = forked ? rz_sky_side_kernel<2> : rz_sky_kernel<2>;
+            auto sky_kernel = b.sky_bytes ? (forked ? rz_sky_side_kernel<2> : rz_sky_kernel<2>) : (forked ? rz_sky_side_float_kernel<2> : rz_sky_float_kernel<2>);
             sky_kernel<<<tiles, dim3(128), 0, sky_stream>>>(passes, L.tri.ptr, L.fan_tri.ptr, L.vary.ptr, L.fan_vary.ptr, db, L.sky_bins.ptr);
             if (forked) HIP_OK(hipEventRecord(L.join, L.side));
         }
@@ -609,6 +613,7 @@ static void run_again(FlushRecord &fr) {
             r.members.push_back(i);
             r.families |= fr.plans[i].families;
             r.sky_table = r.sky_table || fr.plans[i].sky_draws > 0;
+            r.sky_bytes = r.sky_bytes && fr.plans[i].sky_bytes;
             if (c[2] & RZ_ERR_FAN_OVERFLOW) g.fan_highwater = std::max<size_t>(g.fan_highwater, c[0]);
             if (c[2] & RZ_ERR_BIN_OVERFLOW) g.list_highwater = std::max<size_t>(g.list_highwater, c[1]);
         }
@@ -946,10 +951,11 @@ extern "C" void graphics_flush(void) {
                 };
                 for (size_t i = 0; i < plans.size(); i++) {
                     if (plans[i].level != l || (int)plans[i].has_blend != blend) continue;
-                    if (b.members.empty()) { b.has_blend = blend != 0; b.families = 0; b.sky_table = false; }
+                    if (b.members.empty()) { b.has_blend = blend != 0; b.families = 0; b.sky_table = false; b.sky_bytes = true; }
                     b.members.push_back(i);
                     b.families |= plans[i].families;
                     b.sky_table = b.sky_table || plans[i].sky_draws > 0;
+                    b.sky_bytes = b.sky_bytes && plans[i].sky_bytes;
                     if (b.members.size() >= g.max_batch) close();
                 }
                 close();

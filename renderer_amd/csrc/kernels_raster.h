@@ -39,8 +39,12 @@ RZ_DEV uint32_t sky_bytes_index(const DrawRec &D, const float *v) {
     const float x = s, y = 1 - t;                                   /* texture.c:257, 160-167 */
     return __umul24((uint32_t)face, (uint32_t)(w * h)) + texel_cell(w, h, flags, x - floorf(x), y - floorf(y));
 }
+/* BYTES_ONLY: every sky draw the kernel can meet has its cube's plane of display bytes (the host has looked); the
+ * float texels' path is left out of the kernel -- it is half of the sky kernel's code, and that kernel shares the
+ * instruction cache with the shade kernel that runs beside it */
+template <bool BYTES_ONLY = false>
 RZ_DEV uint32_t sky_fragment(const DrawRec &D, const float *v, uint32_t below) {
-    if (D.flags & RZ_DRAW_SKY_BYTES) {
+    if (BYTES_ONLY || (D.flags & RZ_DRAW_SKY_BYTES)) {
         const uint32_t word = D.maps[0].data.as<const uint32_t>()[sky_bytes_index(D, v)];
         return (word & 0x00ffffffu) | (below & 0xff000000u);
     }
@@ -1177,7 +1181,7 @@ RZ_DEV void strip_walk(const PassParams &P, uint32_t pass_index, int probe_bin, 
  * it resolves itself, so in a batch with a sky box the references of all blocks are written. */
 /* (for a workgroup of rz_strip_team_kernel: what the sky of its tile is read from, see sky_tile) */
 struct SkyTables { const TriRec *tri_base, *fan_base; const SkyBin *sky_base; };
-template <int PPL, bool DEFERS>
+template <int PPL, bool DEFERS, bool BYTES_ONLY = false>
 RZ_DEV void sky_tile(const PassParams &P, int tile_x, int tile_y, int wave, int lane, int WHICH,
         const TriRec *__restrict__ tri_base, const TriRec *__restrict__ fan_base,
         const float *__restrict__ vary_base, const float *__restrict__ fan_vary_base,
@@ -1250,7 +1254,7 @@ RZ_DEV void strips_of_workgroup(const PassParams *__restrict__ passes,
     }
     if constexpr (SKY) {
         if (sky_which >= 0 && P.sky_draws != 0)
-            sky_tile<2, false>(P, (int)tile_column, (int)strip_row, sky_half, lane, sky_which,
+            sky_tile<2, false, false>(P, (int)tile_column, (int)strip_row, sky_half, lane, sky_which,
                                sky.tri_base, sky.fan_base, vary_base, fan_vary_base, upload_base, sky.sky_base);
     }
 }

@@ -47,7 +47,7 @@ RZ_DEV void shade_pixel(const PassParams &P, const TriRec *__restrict__ tri_base
  * sky's depth (RZ_SKY_NEAR; the strips flag such a pass, control word 5): the bins with lists of a flagged pass are left
  * to rz_sky_late_kernel, which runs when the shade kernels are through. */
 enum { RZ_SKY_ALL = 0, RZ_SKY_FRESH_ONLY = 1, RZ_SKY_STALE_ONLY = 2 };
-template <int PPL, bool DEFERS>
+template <int PPL, bool DEFERS, bool BYTES_ONLY>
 RZ_DEV void sky_tile(const PassParams &P, int tile_x, int tile_y, int wave, int lane, int WHICH,
         const TriRec *__restrict__ tri_base, const TriRec *__restrict__ fan_base,
         const float *__restrict__ vary_base, const float *__restrict__ fan_vary_base,
@@ -146,14 +146,14 @@ RZ_DEV void sky_tile(const PassParams &P, int tile_x, int tile_y, int wave, int 
             const float norm = 1 / (q0 + q1 + q2);
             interpolate_uniform3(m0, m1, m2, q0, q1, q2, norm, v[q]);
         }
-        if (D.flags & RZ_DRAW_SKY_BYTES) {      /* both texels asked for before either is waited for */
+        if (BYTES_ONLY || (D.flags & RZ_DRAW_SKY_BYTES)) {      /* both texels asked for before either is waited for */
             const uint32_t RZ_GLOBAL *bytes = D.maps[0].data.as<const uint32_t>();
             for (int q = 0; q < PPL; q++) at[q] = sky_bytes_index(D, v[q]);
             uint32_t word[PPL];
             for (int q = 0; q < PPL; q++) word[q] = bytes[at[q]];
             for (int q = 0; q < PPL; q++) P.color[pixel[q]] = (word[q] & 0x00ffffffu) | (below[q] & 0xff000000u);
         } else {
-            for (int q = 0; q < PPL; q++) P.color[pixel[q]] = sky_fragment(D, v[q], below[q]);
+            for (int q = 0; q < PPL; q++) P.color[pixel[q]] = sky_fragment<BYTES_ONLY>(D, v[q], below[q]);
         }
         return;
     }
@@ -189,12 +189,13 @@ RZ_DEV void sky_tile(const PassParams &P, int tile_x, int tile_y, int wave, int 
                 v[0] = (a.x * q0 + b.x * q1 + c.x * q2) * norm;                                   /* :431-434 */
                 v[1] = (a.y * q0 + b.y * q1 + c.y * q2) * norm;
                 v[2] = (a.z * q0 + b.z * q1 + c.z * q2) * norm;
-                P.color[pixel[q]] = sky_fragment(D, v, below[q]);
+                P.color[pixel[q]] = sky_fragment<BYTES_ONLY>(D, v, below[q]);
             }
         }
     }
 }
 
+/* (every sky draw of the batch with its cube's display bytes: the usual case) */
 template <int PPL>
 __global__ void __launch_bounds__(256 / PPL) rz_sky_kernel(const PassParams *__restrict__ passes,
         const TriRec *__restrict__ tri_base, const TriRec *__restrict__ fan_base,
@@ -202,7 +203,18 @@ __global__ void __launch_bounds__(256 / PPL) rz_sky_kernel(const PassParams *__r
         const char *__restrict__ upload_base, const SkyBin *__restrict__ sky_base) {
     const PassParams P = passes[blockIdx.z];
     if ((int)blockIdx.x >= P.tiles_x || (int)blockIdx.y >= P.tiles_y || P.sky_draws == 0) return;
-    sky_tile<PPL, false>(P, (int)blockIdx.x, (int)blockIdx.y, (int)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), (int)(threadIdx.x & 63u), RZ_SKY_ALL,
+    sky_tile<PPL, false, true>(P, (int)blockIdx.x, (int)blockIdx.y, (int)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), (int)(threadIdx.x & 63u), RZ_SKY_ALL,
+                              tri_base, fan_base, vary_base, fan_vary_base, upload_base, sky_base);
+}
+/* ... a batch with a sky draw whose cube has no plane of display bytes (faces of different sizes, a blended sky) */
+template <int PPL>
+__global__ void __launch_bounds__(256 / PPL) rz_sky_float_kernel(const PassParams *__restrict__ passes,
+        const TriRec *__restrict__ tri_base, const TriRec *__restrict__ fan_base,
+        const float *__restrict__ vary_base, const float *__restrict__ fan_vary_base,
+        const char *__restrict__ upload_base, const SkyBin *__restrict__ sky_base) {
+    const PassParams P = passes[blockIdx.z];
+    if ((int)blockIdx.x >= P.tiles_x || (int)blockIdx.y >= P.tiles_y || P.sky_draws == 0) return;
+    sky_tile<PPL, false, false>(P, (int)blockIdx.x, (int)blockIdx.y, (int)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), (int)(threadIdx.x & 63u), RZ_SKY_ALL,
                               tri_base, fan_base, vary_base, fan_vary_base, upload_base, sky_base);
 }
 /* ... beside the shade kernels, on the lane's side stream */
@@ -213,8 +225,18 @@ __global__ void __launch_bounds__(256 / PPL) rz_sky_side_kernel(const PassParams
         const char *__restrict__ upload_base, const SkyBin *__restrict__ sky_base) {
     const PassParams P = passes[blockIdx.z];
     if ((int)blockIdx.x >= P.tiles_x || (int)blockIdx.y >= P.tiles_y || P.sky_draws == 0) return;
-    sky_tile<PPL, true>(P, (int)blockIdx.x, (int)blockIdx.y, (int)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), (int)(threadIdx.x & 63u), RZ_SKY_ALL,
-                                    tri_base, fan_base, vary_base, fan_vary_base, upload_base, sky_base);
+    sky_tile<PPL, true, true>(P, (int)blockIdx.x, (int)blockIdx.y, (int)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), (int)(threadIdx.x & 63u), RZ_SKY_ALL,
+                              tri_base, fan_base, vary_base, fan_vary_base, upload_base, sky_base);
+}
+template <int PPL>
+__global__ void __launch_bounds__(256 / PPL) rz_sky_side_float_kernel(const PassParams *__restrict__ passes,
+        const TriRec *__restrict__ tri_base, const TriRec *__restrict__ fan_base,
+        const float *__restrict__ vary_base, const float *__restrict__ fan_vary_base,
+        const char *__restrict__ upload_base, const SkyBin *__restrict__ sky_base) {
+    const PassParams P = passes[blockIdx.z];
+    if ((int)blockIdx.x >= P.tiles_x || (int)blockIdx.y >= P.tiles_y || P.sky_draws == 0) return;
+    sky_tile<PPL, true, false>(P, (int)blockIdx.x, (int)blockIdx.y, (int)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), (int)(threadIdx.x & 63u), RZ_SKY_ALL,
+                              tri_base, fan_base, vary_base, fan_vary_base, upload_base, sky_base);
 }
 /* ... and what that one left: the bins with lists of the passes flagged as holding fragments the sky may hide.  Hardly
  * ever any (geometry between the sky's depth and the far plane): the batch's flag word says so to every workgroup in one
@@ -230,7 +252,7 @@ __global__ void __launch_bounds__(256 / PPL) rz_sky_late_kernel(const PassParams
         const PassParams P = passes[p];
         if (P.sky_draws == 0 || P.control[5] == 0u) continue;
         for (uint32_t tile = blockIdx.x; tile < (uint32_t)(P.tiles_x * P.tiles_y); tile += gridDim.x)
-            sky_tile<PPL, false>(P, (int)(tile % (uint32_t)P.tiles_x), (int)(tile / (uint32_t)P.tiles_x), wave, lane, RZ_SKY_STALE_ONLY,
+            sky_tile<PPL, false, false>(P, (int)(tile % (uint32_t)P.tiles_x), (int)(tile / (uint32_t)P.tiles_x), wave, lane, RZ_SKY_STALE_ONLY,
                                                     tri_base, fan_base, vary_base, fan_vary_base, upload_base, sky_base);
     }
 }
