@@ -112,8 +112,17 @@ RZ_DEV void sky_tile(const PassParams &P, int tile_x, int tile_y, int wave, int 
         }
     };
     if (!overflow) {
+        /* (the first two entries in line -- the usual region has one or two --, the rest in a loop: eight copies of the
+         * test were a third of the kernel, which shares the instruction cache with the shade kernel beside it) */
+        if (entries & 1u) consider(refs[0]);
+        if (entries & 2u) consider(refs[1]);
+        for (uint32_t left = entries >> 2; left != 0u; left &= left - 1u) {
+            const uint32_t e = (uint32_t)__builtin_ctz(left);
+            uint32_t ref = refs[2];
 #pragma unroll
-        for (uint32_t e = 0; e < RZ_SKY_BIN_MAX; e++) if (entries >> e & 1u) consider(refs[e]);
+            for (uint32_t k = 3; k < RZ_SKY_BIN_MAX; k++) if (e + 2u == k) ref = refs[k];
+            consider(ref);
+        }
     } else {
         /* more table entries meet the bin than its record holds: all of the table, entry by entry */
         for (int at = 0; at < P.sky_draws * RZ_SKY_FACES * RZ_MAX_FAN; at++) {
