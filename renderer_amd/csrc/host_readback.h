@@ -29,6 +29,15 @@ static void read_framebuffer(Fb *fb, void *color, void *depth, hipMemcpyKind kin
     HIP_OK(hipStreamSynchronize(st));
 }
 
+/* a frame's RGBA8 colour as RGB8 at `rgb` (device memory), on `st` */
+static void launch_strip_alpha(const uint32_t *color, void *rgb, size_t n, hipStream_t st) {
+    if (n % 16 == 0 && n / 4 < 0xffffffffull && ((uintptr_t)rgb & 15u) == 0 && n != 0)
+        rz_strip_alpha_wide_kernel<<<dim3((unsigned)((n + RZ_ALPHA_CHUNK - 1) / RZ_ALPHA_CHUNK)), dim3(256), 0, st>>>(
+            (const uint4*)color, (uint4*)rgb, (uint32_t)(n / 4));
+    else
+        rz_strip_alpha_kernel<<<dim3((unsigned)((n / 16 + 1 + 255) / 256)), dim3(256), 0, st>>>(color, (uint32_t*)rgb, n);
+}
+
 extern "C" void framebuffer_read_device_rgb(rz_framebuffer *p, void *rgb) {
     Fb *fb = as_fb(p);
     if (!rgb || ((uintptr_t)rgb & 3u)) fatal("framebuffer_read_device_rgb: the destination must be a 4-byte aligned device pointer");
@@ -38,7 +47,7 @@ extern "C" void framebuffer_read_device_rgb(rz_framebuffer *p, void *rgb) {
     apply_pending_clear(fb);
     const size_t n = (size_t)fb->pub.width * fb->pub.height;
     hipStream_t st = g.lanes[fb->lane < 0 ? 0 : fb->lane].stream;
-    rz_strip_alpha_kernel<<<dim3((unsigned)((n / 16 + 1 + 255) / 256)), dim3(256), 0, st>>>(fb->d_color, (uint32_t*)rgb, n);
+    launch_strip_alpha(fb->d_color, rgb, n, st);
     HIP_OK(hipGetLastError());
     HIP_OK(hipStreamSynchronize(st));
 }
@@ -171,8 +180,7 @@ extern "C" void framebuffers_read_device_rgb(rz_framebuffer *const *fps, int cou
             apply_pending_clear(fb);
             const size_t n = (size_t)fb->pub.width * fb->pub.height;
             hipStream_t st = g.lanes[fb->lane < 0 ? 0 : fb->lane].stream;
-            rz_strip_alpha_kernel<<<dim3((unsigned)((n / 16 + 1 + 255) / 256)), dim3(256), 0, st>>>(
-                fb->d_color, (uint32_t*)((char*)rgb + (size_t)i * stride_bytes), n);
+            launch_strip_alpha(fb->d_color, (char*)rgb + (size_t)i * stride_bytes, n, st);
             HIP_OK(hipGetLastError());
         }
         for (int l = 0; l < g.num_lanes; l++) HIP_OK(hipStreamSynchronize(g.lanes[l].stream));
@@ -203,8 +211,7 @@ static void launch_frames_read(bool again) {
         Fb *fb = r.fbs[i];
         const size_t n = (size_t)fb->pub.width * fb->pub.height;
         const int lane = fb->lane < 0 ? 0 : fb->lane;
-        rz_strip_alpha_kernel<<<dim3((unsigned)((n / 16 + 1 + 255) / 256)), dim3(256), 0, g.lanes[lane].stream>>>(
-            fb->d_color, (uint32_t*)(r.rgb + i * r.stride), n);
+        launch_strip_alpha(fb->d_color, r.rgb + i * r.stride, n, g.lanes[lane].stream);
         HIP_OK(hipGetLastError());
         r.used[lane] = true;
     }

@@ -456,7 +456,7 @@ def test_gpu_overlays_equal_the_reference_overlays(gpu, oracle, size):
     assert (frames[0] != np.array([76, 153, 229, 127], np.uint8)).any()
 
 
-@pytest.mark.parametrize("size", [(320, 180), (67, 33), (5, 1)])
+@pytest.mark.parametrize("size", [(320, 180), (256, 64), (67, 33), (5, 1)])
 def test_gpu_frames_without_their_alpha_bytes(gpu, size):
     """framebuffer_read_device_rgb: the colour image as RGB8 in device memory (what the multi-GPU gather
     moves), for pixel counts that are and are not multiples of four."""
