@@ -173,7 +173,8 @@ struct Context {
     unsigned long long write_seq = 0;
     /* upload ring: pinned host memory mirrored 1:1 in device memory */
     char *ring_host = nullptr, *ring_dev = nullptr;
-    size_t ring_size = 0, ring_at = 0;
+    size_t ring_size = 0, ring_turn = 0;    /* the slot the next flush takes (ring_alloc) */
+    bool ring_whole = false;                /* the last flush took the whole ring */
     /* scratch estimates (scratch_entries): what passes that ran out turned out to need, and values forced for tests */
     size_t fan_highwater = 0, list_highwater = 0;
     size_t forced_fan_estimate = 0, forced_list_estimate = 0;

@@ -5,10 +5,18 @@
 
 static const size_t CONTROL_BYTES = 64;
 
+/* A flush's upload region.  The ring is taken in RING_SLOTS equal slots, one per flush, in turn: when a flush is put
+ * together only the flush before it can still be running (the one before that was settled, passes run again
+ * included, before that flush launched anything), so a slot that comes round again after RING_SLOTS flushes is free
+ * without asking the GPU -- and the processor writes the tables into memory it wrote a few flushes ago, which its
+ * caches still hold, instead of fetching 64 MB of lines in turn from memory only to overwrite them.  A flush that
+ * does not fit a slot (hundreds of thousands of triangles recorded one by one) takes the whole ring, grown if need
+ * be, behind a wait for everything that used it; so does the flush after such a one. */
+static const size_t RING_SLOTS = 4;
+
 static size_t ring_alloc(size_t bytes) {
     bytes = (bytes + 255) & ~(size_t)255;
     if (bytes > g.ring_size) {
-        /* a flush larger than the ring (hundreds of thousands of triangles recorded one by one): a larger ring */
         sync_stream();
         size_t size = g.ring_size;
         while (size < bytes) size *= 2;
@@ -17,15 +25,16 @@ static size_t ring_alloc(size_t bytes) {
         HIP_OK(hipHostMalloc((void**)&g.ring_host, size, hipHostMallocDefault));
         HIP_OK(hipMalloc((void**)&g.ring_dev, size));
         g.ring_size = size;
-        g.ring_at = 0;
+        g.ring_whole = true;        /* (nothing is in flight any more; the flag only sends the next flush through the wait below) */
     }
-    if (g.ring_at + bytes > g.ring_size) {
+    const size_t slot_bytes = (g.ring_size / RING_SLOTS) & ~(size_t)255;
+    if (bytes > slot_bytes || g.ring_whole) {
         sync_stream();              /* everything that used the ring has finished */
-        g.ring_at = 0;
+        g.ring_whole = bytes > slot_bytes;
+        g.ring_turn = 0;
+        if (g.ring_whole) return 0;
     }
-    size_t at = g.ring_at;
-    g.ring_at += bytes;
-    return at;
+    return (g.ring_turn++ % RING_SLOTS) * slot_bytes;
 }
 
 /* layout of one pass inside the flush's upload region */
@@ -436,7 +445,7 @@ static void launch_batch(const Batch &b, const std::vector<PassPlan> &plans, cha
     rz_clip_kernel<<<dim3(256, n), dim3(64), 0, st>>>(passes);
     stamp();
     rz_bin_count_kernel<<<tgrid, dim3(256), 0, st>>>(passes);
-    rz_bin_scan_kernel<<<dim3((unsigned)((max_bins + 63) / 64), n), dim3(64 * RZ_SCAN_SEGMENTS), 0, st>>>(passes);
+    rz_bin_scan_kernel<<<dim3((unsigned)((max_bins + RZ_SCAN_BINS - 1) / RZ_SCAN_BINS), n), dim3(RZ_SCAN_BINS * RZ_SCAN_SEGMENTS), 0, st>>>(passes);
     /* a pass with blended draws: either everything in the ordered kernel (visibility and shading
      * together, fragment stacks), or visibility first, the ordered kernel for the tiles where
      * blended fragments pile up and the shade kernels for the rest */

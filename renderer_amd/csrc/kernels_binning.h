@@ -131,14 +131,19 @@ __global__ void __launch_bounds__(256) rz_bin_count_kernel(const PassParams *__r
     }
 }
 
-/* 1024 threads = 64 bins x 16 segments of the chunk range */
+/* 256 threads = 16 bins x 16 segments of the chunk range.  (Not 64 bins: a workgroup of 16 waves finds room only on a
+ * compute unit with 16 free wave slots, and next to a kernel of another lane that keeps every slot taken by
+ * workgroups of a wave or two it waited for that kernel's end -- 20 us alone, 800 us beside a shade kernel, with
+ * its lane's strips and shading behind it.) */
 #define RZ_SCAN_SEGMENTS 16
-__global__ void __launch_bounds__(64 * RZ_SCAN_SEGMENTS) rz_bin_scan_kernel(const PassParams *__restrict__ passes) {
+#define RZ_SCAN_BINS 16
+__global__ void __launch_bounds__(RZ_SCAN_BINS * RZ_SCAN_SEGMENTS) rz_bin_scan_kernel(const PassParams *__restrict__ passes) {
     const PassParams &P = passes[blockIdx.y];
-    __shared__ uint32_t s_part[RZ_SCAN_SEGMENTS][64];
+    __shared__ uint32_t s_part[RZ_SCAN_SEGMENTS][RZ_SCAN_BINS];
     const int bins = P.bins_x * P.bins_y;
-    if ((int)(blockIdx.x * 64u) >= bins) return;
-    const int bin = (int)(blockIdx.x * 64u) + (threadIdx.x & 63), segment = threadIdx.x >> 6;
+    if ((int)(blockIdx.x * RZ_SCAN_BINS) >= bins) return;
+    const int column = threadIdx.x & (RZ_SCAN_BINS - 1);
+    const int bin = (int)(blockIdx.x * RZ_SCAN_BINS) + column, segment = threadIdx.x / RZ_SCAN_BINS;
     const uint32_t chunks = ((uint32_t)P.num_tris + 63u) / 64u;
     const uint32_t per = (chunks + RZ_SCAN_SEGMENTS - 1u) / RZ_SCAN_SEGMENTS;
     const uint32_t c0 = min((uint32_t)segment * per, chunks), c1 = min(c0 + per, chunks);
@@ -162,11 +167,11 @@ __global__ void __launch_bounds__(64 * RZ_SCAN_SEGMENTS) rz_bin_scan_kernel(cons
             for (int u = 0; u < 8; u++) sum += v[u];
         }
     }
-    s_part[segment][threadIdx.x & 63] = sum;
+    s_part[segment][column] = sum;
     __syncthreads();
     uint32_t before = 0, total = 0;
     for (int q = 0; q < RZ_SCAN_SEGMENTS; q++) {
-        uint32_t v = s_part[q][threadIdx.x & 63];
+        uint32_t v = s_part[q][column];
         if (q < segment) before += v;
         total += v;
     }
@@ -180,7 +185,7 @@ __global__ void __launch_bounds__(64 * RZ_SCAN_SEGMENTS) rz_bin_scan_kernel(cons
             total = 0;
         }
         P.bin_range[bin] = make_uint2(start, total);
-        s_part[0][threadIdx.x & 63] = total ? start : 0xffffffffu;
+        s_part[0][column] = total ? start : 0xffffffffu;
         /* a pass with blended draws: the bin's 32x8 tiles go on the work list of the kernel that rasterises it, unless
          * there is nothing for that kernel to do in them */
         if (P.scan_list >= 0 && (total != 0u || P.clear_color_pending || P.clear_depth_pending)) {
@@ -198,13 +203,13 @@ __global__ void __launch_bounds__(64 * RZ_SCAN_SEGMENTS) rz_bin_scan_kernel(cons
                 }
         }
     }
-    if (segment == 0) {             /* the pass's longest list, for the host's choice of strip height next time */
-        uint32_t longest = bin < bins ? total : 0u;
+    if (threadIdx.x < 64u) {        /* the pass's longest list, for the host's choice of strip height next time (segment 0 is in wave 0) */
+        uint32_t longest = (segment == 0 && bin < bins) ? total : 0u;
         longest = (uint32_t)wave_max_i((int)longest);           /* entry counts stay far below 2^31 */
-        if ((threadIdx.x & 63) == 0 && longest) atomicMax(&P.control[4], longest);
+        if (threadIdx.x == 0 && longest) atomicMax(&P.control[4], longest);
     }
     __syncthreads();
-    const uint32_t start = s_part[0][threadIdx.x & 63];
+    const uint32_t start = s_part[0][column];
     if (bin >= bins || start == 0xffffffffu) return;    /* empty or overflowed bin: its entries are never written */
     uint32_t run = start + before;
     if (few) {
