@@ -167,6 +167,7 @@ struct Batch {
     bool sky_table = false;         /* one of its passes keeps sky boxes on its table of sky triangles */
     bool sky_bytes = true;          /* ... and every such sky box has its cube's plane of display bytes */
     bool fast_start = false;        /* no pass of it waits for another pass of the flush, none is run again: no rz_begin_kernel */
+    bool beside = false;            /* other batches of its level run beside it on other lanes (a flush of more passes than a batch holds) */
     bool crowd = false;             /* its crowded bins are rz_crowd_kernel's (settled when the batch is put together: its passes' parameters and its launches must agree) */
 };
 
@@ -452,9 +453,12 @@ static void launch_batch(const Batch &b, const std::vector<PassPlan> &plans, cha
     const bool ordered_only = b.has_blend && !splits_blend(batch_tiles, n);
     {
         /* a chunk whose triangles lie far apart walks its bins in rounds of 64: with few chunks in the launch (a frame
-         * or two) the rounds are shared out over four waves, with many one wave per chunk keeps more chunks in flight */
+         * or two) the rounds are shared out over four or eight waves, with many one wave per chunk keeps more chunks in
+         * flight.  Not in a flush of several batches per level: beside other lanes' batches, whose workgroups of a wave
+         * or two take every wave slot as it frees, workgroups of 256 or 512 threads wait long for a CU with room for
+         * all their waves (the 60 small blended passes of a kgirl batch: 8.5 us alone, 75-160 us there) */
         const unsigned fill_blocks = (unsigned)((max_T + 63) / 64 * n);
-        const int waves = g.fill_waves ? g.fill_waves : fill_blocks < 1024u ? 8 : fill_blocks < 4096u ? 4 : 1;
+        const int waves = g.fill_waves ? g.fill_waves : b.beside ? 1 : fill_blocks < 1024u ? 8 : fill_blocks < 4096u ? 4 : 1;
         /* the strips' passes: what a strip has to do with its bin is worked out by the same launch, a wave per bin in
          * workgroups behind those that fill (empty bins are finished there; a pass with a table of sky triangles gets
          * its bins' records for rz_sky_kernel) */
@@ -970,6 +974,9 @@ extern "C" void graphics_flush(void) {
                 close();
             }
         }
+        size_t first_level = 0;
+        for (const Batch &b : batches) first_level += plans[b.members[0]].level == 0 ? 1 : 0;
+        for (Batch &b : batches) b.beside = first_level > 1;
     }
     prof.mark(1);
 
