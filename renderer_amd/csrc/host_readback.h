@@ -38,6 +38,41 @@ static void launch_strip_alpha(const uint32_t *color, void *rgb, size_t n, hipSt
         rz_strip_alpha_kernel<<<dim3((unsigned)((n / 16 + 1 + 255) / 256)), dim3(256), 0, st>>>(color, (uint32_t*)rgb, n);
 }
 
+/* the RGB8 copies of a set of frames, frame i at rgb + i * stride, each on its framebuffer's lane behind what was
+ * submitted there; frames of one lane, one size and an aligned destination share launches.  Returns the lanes used. */
+static void launch_frames_strip(const std::vector<Fb*> &fbs, char *rgb, size_t stride, bool used[MAX_LANES]) {
+    for (int lane = 0; lane < g.num_lanes; lane++) {
+        AlphaFrames group;
+        unsigned held = 0;
+        size_t group_n = 0;
+        auto send = [&]() {
+            if (!held) return;
+            rz_strip_alpha_frames_kernel<<<dim3((unsigned)((group_n + RZ_ALPHA_CHUNK - 1) / RZ_ALPHA_CHUNK), held), dim3(256), 0, g.lanes[lane].stream>>>(group, (uint32_t)(group_n / 4));
+            HIP_OK(hipGetLastError());
+            held = 0;
+        };
+        for (size_t i = 0; i < fbs.size(); i++) {
+            Fb *fb = fbs[i];
+            if ((fb->lane < 0 ? 0 : fb->lane) != lane) continue;
+            used[lane] = true;
+            const size_t n = (size_t)fb->pub.width * fb->pub.height;
+            char *dst = rgb + i * stride;
+            const bool wide = n % 16 == 0 && n / 4 < 0xffffffffull && ((uintptr_t)dst & 15u) == 0 && n != 0;
+            if (!wide) {
+                launch_strip_alpha(fb->d_color, dst, n, g.lanes[lane].stream);
+                HIP_OK(hipGetLastError());
+                continue;
+            }
+            if (held && (n != group_n || held == RZ_ALPHA_FRAMES)) send();
+            group_n = n;
+            group.color[held] = (const uint4*)fb->d_color;
+            group.rgb[held] = (uint4*)dst;
+            held++;
+        }
+        send();
+    }
+}
+
 extern "C" void framebuffer_read_device_rgb(rz_framebuffer *p, void *rgb) {
     Fb *fb = as_fb(p);
     if (!rgb || ((uintptr_t)rgb & 3u)) fatal("framebuffer_read_device_rgb: the destination must be a 4-byte aligned device pointer");
@@ -175,14 +210,9 @@ extern "C" void framebuffers_read_device_rgb(rz_framebuffer *const *fps, int cou
     }
     graphics_flush();
     for (int attempt = 0; attempt < 2; attempt++) {
-        for (int i = 0; i < count; i++) {
-            Fb *fb = fbs[i];
-            apply_pending_clear(fb);
-            const size_t n = (size_t)fb->pub.width * fb->pub.height;
-            hipStream_t st = g.lanes[fb->lane < 0 ? 0 : fb->lane].stream;
-            launch_strip_alpha(fb->d_color, (char*)rgb + (size_t)i * stride_bytes, n, st);
-            HIP_OK(hipGetLastError());
-        }
+        for (Fb *fb : fbs) apply_pending_clear(fb);
+        bool used[MAX_LANES] = {false};
+        launch_frames_strip(fbs, (char*)rgb, stride_bytes, used);
         for (int l = 0; l < g.num_lanes; l++) HIP_OK(hipStreamSynchronize(g.lanes[l].stream));
         bool left_out = false;
         for (const FlushRecord &fr : g_in_flight)
@@ -207,14 +237,7 @@ static void launch_frames_read(bool again) {
     /* (a clear on its own settles the flush in flight first, which may launch the copies: before the events below) */
     if (!again) for (Fb *fb : r.fbs) apply_pending_clear(fb);
     for (int l = 0; l < MAX_LANES; l++) if (r.used[l]) { HIP_OK(hipEventDestroy(r.done[l])); r.used[l] = false; }
-    for (size_t i = 0; i < r.fbs.size(); i++) {
-        Fb *fb = r.fbs[i];
-        const size_t n = (size_t)fb->pub.width * fb->pub.height;
-        const int lane = fb->lane < 0 ? 0 : fb->lane;
-        launch_strip_alpha(fb->d_color, r.rgb + i * r.stride, n, g.lanes[lane].stream);
-        HIP_OK(hipGetLastError());
-        r.used[lane] = true;
-    }
+    launch_frames_strip(r.fbs, r.rgb, r.stride, r.used);
     for (int l = 0; l < MAX_LANES; l++)
         if (r.used[l]) {
             HIP_OK(hipEventCreateWithFlags(&r.done[l], hipEventDisableTiming));

@@ -109,9 +109,8 @@ __global__ void rz_strip_alpha_kernel(const uint32_t *__restrict__ color, uint32
  * each makes go to LDS side by side (a stride of three words: no two lanes of a wave on one bank), and come out again
  * lane after lane 16 bytes.  (Sixteen pixels per thread, each lane its own 64 bytes in and 48 out: 4.6 us per 1080p frame.) */
 #define RZ_ALPHA_CHUNK 4096u
-__global__ void __launch_bounds__(256) rz_strip_alpha_wide_kernel(const uint4 *__restrict__ color, uint4 *__restrict__ rgb, uint32_t quads) {
-    __shared__ uint32_t s_out[RZ_ALPHA_CHUNK / 4u * 3u];
-    const uint32_t first = blockIdx.x * (RZ_ALPHA_CHUNK / 4u);      /* the workgroup's first group of four pixels */
+RZ_DEV void strip_alpha_chunk(const uint4 *__restrict__ color, uint4 *__restrict__ rgb, uint32_t quads, uint32_t chunk, uint32_t *s_out) {
+    const uint32_t first = chunk * (RZ_ALPHA_CHUNK / 4u);           /* the workgroup's first group of four pixels */
     const uint32_t here = min(RZ_ALPHA_CHUNK / 4u, quads - first);  /* a multiple of four: whole 16-byte pieces come out */
 #pragma unroll
     for (uint32_t turn = 0; turn < RZ_ALPHA_CHUNK / 4u / 256u; turn++) {
@@ -125,6 +124,20 @@ __global__ void __launch_bounds__(256) rz_strip_alpha_wide_kernel(const uint4 *_
     __syncthreads();
     uint4 *out = rgb + (size_t)first / 4u * 3u;
     for (uint32_t j = threadIdx.x; j < here / 4u * 3u; j += 256u) out[j] = ((const uint4*)s_out)[j];
+}
+
+__global__ void __launch_bounds__(256) rz_strip_alpha_wide_kernel(const uint4 *__restrict__ color, uint4 *__restrict__ rgb, uint32_t quads) {
+    __shared__ uint32_t s_out[RZ_ALPHA_CHUNK / 4u * 3u];
+    strip_alpha_chunk(color, rgb, quads, blockIdx.x, s_out);
+}
+
+/* ... and for up to RZ_ALPHA_FRAMES frames of one size in one launch (the frames of a step on one lane, about to be
+ * gathered: launched one by one, each 3.5 us kernel waited for the one before it to drain), blockIdx.y = frame */
+#define RZ_ALPHA_FRAMES 32
+struct AlphaFrames { const uint4 *color[RZ_ALPHA_FRAMES]; uint4 *rgb[RZ_ALPHA_FRAMES]; };
+__global__ void __launch_bounds__(256) rz_strip_alpha_frames_kernel(const AlphaFrames frames, uint32_t quads) {
+    __shared__ uint32_t s_out[RZ_ALPHA_CHUNK / 4u * 3u];
+    strip_alpha_chunk(frames.color[blockIdx.y], frames.rgb[blockIdx.y], quads, blockIdx.x, s_out);
 }
 
 /* private_blit_bgr / private_blit_rgb (private.c:8-50): vertical flip, optional red/blue swap; the
